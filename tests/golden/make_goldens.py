@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""Mint golden vectors by running the REFERENCE's own Python in the build container.
+
+Runs only where /root/reference exists (never on the GPU box, never from tests).
+It imports the reference modules by file path with the shims SURVEY.md 8(c)
+lists, feeds them seeded synthetic inputs, and writes small .npz fixtures next
+to this file.  Only arrays are written - no reference source text.
+
+Shims (harness-side only):
+  * clip/clip_surgery_model.py is loaded by path (imports only torch/numpy).
+  * clip/clip.py cannot be imported (torchvision missing): the two pure-torch
+    functions on the hot path are executed from the reference file's own text
+    via ast (function bodies are taken from /root/reference at run time).
+  * utils/affutils.py needs `cv2`: a stub module implements threshold /
+    findContours / boundingRect / contourArea / resize with scipy.ndimage and
+    torch (so everything AROUND the cv2 calls is the reference's code; the cv2
+    calls themselves stay "parity unpinned").
+  * Tensor.cuda / Module.cuda are patched to identity (no GPU here).
+  * model/load_attr.py: stub `clip` module in sys.modules, cwd=/root/reference.
+
+Usage:  python tests/golden/make_goldens.py
+"""
+import ast
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle.vit import VitConfig, make_vit_weights  # noqa: E402  (seeded weight generator only)
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+# ---------------------------------------------------------------- shims
+torch.Tensor.cuda = lambda self, *a, **k: self
+torch.nn.Module.cuda = lambda self, *a, **k: self
+
+
+def _load_by_path(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _functions_from_source(path, names, glb):
+    tree = ast.parse(open(path).read())
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    code = compile(ast.Module(body=body, type_ignores=[]), path, "exec")
+    exec(code, glb)
+    return [glb[n] for n in names]
+
+
+def _make_cv2_stub():
+    from scipy import ndimage
+    cv2 = types.ModuleType("cv2")
+    cv2.__version__ = "4.0.0-stub"
+    cv2.THRESH_BINARY = 0
+    cv2.RETR_TREE = 3
+    cv2.CHAIN_APPROX_SIMPLE = 2
+
+    def threshold(src, thresh, maxval, type):
+        return thresh, np.where(src > thresh, maxval, 0).astype(np.uint8)
+
+    def findContours(image, mode, method):
+        img = np.asarray(image)
+        if img.ndim == 3:
+            img = img[..., 0]
+        lab, n = ndimage.label(img > 0, structure=np.ones((3, 3), int))
+        contours = []
+        for sl in ndimage.find_objects(lab):
+            ys, xs = sl
+            contours.append(("box", xs.start, ys.start, xs.stop - xs.start, ys.stop - ys.start))
+        return contours, None
+
+    def boundingRect(c):
+        return c[1], c[2], c[3], c[4]
+
+    def contourArea(c):
+        return c[3] * c[4]
+
+    def resize(img, dsize):
+        w, h = dsize
+        t = torch.from_numpy(np.asarray(img, np.float32))[None, None]
+        return F.interpolate(t, size=(h, w), mode="bilinear", align_corners=False)[0, 0].numpy()
+
+    cv2.threshold, cv2.findContours, cv2.boundingRect = threshold, findContours, boundingRect
+    cv2.contourArea, cv2.resize = contourArea, resize
+    return cv2
+
+
+sys.modules["cv2"] = _make_cv2_stub()
+sys.path.insert(0, REF)
+csm = _load_by_path("ref_clip_surgery_model", os.path.join(REF, "clip/clip_surgery_model.py"))
+ref_clip_fs, = _functions_from_source(os.path.join(REF, "clip/clip.py"), ["clip_feature_surgery"],
+                                      {"torch": torch, "np": np})
+from utils import PAR as ref_PAR_mod          # noqa: E402
+from utils import evaluate as ref_eval        # noqa: E402
+from utils import affutils as ref_aff         # noqa: E402
+
+sys.modules.setdefault("clip", types.ModuleType("clip"))
+os.chdir(REF)
+from model.load_attr import attr_aggregate as ref_attr_aggregate  # noqa: E402
+
+
+def build_ref_vit(cfg: VitConfig, weights, feat_size, mode):
+    m = csm.VisionTransformer(cfg.input_resolution, cfg.patch, cfg.width, cfg.layers, cfg.heads, cfg.out_dim)
+    sd = {k: torch.from_numpy(v.copy()) for k, v in weights.items()}
+    missing = m.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    m.eval()
+    m.reload_self_attn(layers=6, feat_size=feat_size, mode=mode)
+    return m
+
+
+def ref_generate_clip_fts(vit, inputs):
+    # clip/clip.py:348-358 with model.encode_image == visual(...) (clip_surgery_model.py:548-549)
+    image_features, attn_list, feat_list = vit(inputs, True, None)
+    image_features_n = image_features / image_features.norm(dim=1, keepdim=True)
+    return image_features, image_features_n, torch.stack(attn_list, 0), [f.clone() for f in feat_list]
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **out)
+    print(f"wrote {name}: {os.path.getsize(path)/1024:.1f} KB")
+
+
+# ---------------------------------------------------------------- 1. tiny ViT + CAM
+TINY = VitConfig(width=64, layers=8, heads=2, patch=16, out_dim=32, input_resolution=64, n_surgery=5)
+
+
+def gold_vit_cam():
+    w = make_vit_weights(TINY, seed=11)
+    rs = np.random.RandomState(21)
+    imgs = rs.standard_normal((2, 3, 96, 96)).astype(np.float32)
+    out = {}
+    for mode in ("train", "val"):
+        vit = build_ref_vit(TINY, w, feat_size=6, mode=mode)
+        x, f, attn, feats = ref_generate_clip_fts(vit, torch.from_numpy(imgs))
+        text = rs.standard_normal((9, 32)).astype(np.float32)
+        text /= np.linalg.norm(text, axis=1, keepdims=True)
+        cam = ref_clip_fs(f, torch.from_numpy(text))
+        out.update({f"{mode}_x": x, f"{mode}_image_features": f, f"{mode}_attn": attn,
+                    f"{mode}_feat0": feats[0], f"{mode}_feat5": feats[2], f"{mode}_feat_last": feats[-1],
+                    f"{mode}_text": text, f"{mode}_cam": cam})
+    # a second resolution through the 'train' model (pos-emb re-interpolated from the 6x6 grid, quirk Q5)
+    vit = build_ref_vit(TINY, w, feat_size=6, mode="train")
+    imgs2 = rs.standard_normal((1, 3, 64, 64)).astype(np.float32)
+    x2, f2, attn2, _ = ref_generate_clip_fts(vit, torch.from_numpy(imgs2))
+    out.update(res2_imgs=imgs2, res2_x=x2, res2_attn_last=attn2[-1])
+    save("vit_cam_tiny.npz", seed_w=11, imgs=imgs, **out)
+
+
+# ---------------------------------------------------------------- 2. op-level goldens
+def gold_ops():
+    rs = np.random.RandomState(5)
+    # clip_feature_surgery on random normalised features
+    f = rs.standard_normal((2, 37, 64)).astype(np.float32)
+    f = f / np.linalg.norm(f, axis=1, keepdims=True)
+    t = rs.standard_normal((9, 64)).astype(np.float32)
+    t /= np.linalg.norm(t, axis=1, keepdims=True)
+    cam = ref_clip_fs(torch.from_numpy(f), torch.from_numpy(t))
+    # compute_trans_mat
+    a = rs.rand(36, 36).astype(np.float32) + 0.01
+    tm = ref_aff.compute_trans_mat(torch.from_numpy(a))
+    # PAR, non-square, odd sizes, dilation 24 > size/2
+    par = ref_PAR_mod.PAR(num_iter=20, dilations=[1, 2, 4, 8, 12, 24])
+    pimg = rs.standard_normal((1, 3, 24, 24)).astype(np.float32)
+    pmask = rs.rand(1, 3, 31, 45).astype(np.float32)
+    pout = par(torch.from_numpy(pimg), torch.from_numpy(pmask))
+    par3 = ref_PAR_mod.PAR(num_iter=3, dilations=[1, 2, 4, 8, 12, 24])
+    pimg2 = rs.standard_normal((2, 3, 40, 56)).astype(np.float32)
+    pmask2 = rs.rand(2, 4, 40, 56).astype(np.float32)
+    pout2 = par3(torch.from_numpy(pimg2), torch.from_numpy(pmask2))
+    # scores with 255s
+    gts = [rs.randint(0, 21, (17, 23)).astype(np.int16) for _ in range(3)]
+    for g in gts:
+        g[rs.rand(*g.shape) < 0.05] = 255
+    preds = [rs.randint(0, 21, (17, 23)).astype(np.int16) for _ in range(3)]
+    with np.errstate(all="ignore"):
+        sc = ref_eval.scores(gts, preds, num_classes=21)
+    hist = sum(ref_eval._fast_hist(g.flatten(), p.flatten(), 21) for g, p in zip(gts, preds))
+    save("ops.npz", cfs_f=f, cfs_t=t, cfs_out=cam, tm_in=a, tm_out=tm,
+         par_img=pimg, par_mask=pmask, par_out=pout, par2_img=pimg2, par2_mask=pmask2, par2_out=pout2,
+         sc_gts=np.stack(gts), sc_preds=np.stack(preds), sc_hist=hist,
+         sc_miou=sc["miou"], sc_pacc=sc["pAcc"], sc_macc=sc["mAcc"],
+         sc_iou=np.array(list(sc["iou"].values())), sc_prec=np.array(list(sc["precision"].values())),
+         sc_rec=np.array(list(sc["recall"].values())), sc_conf=np.array(list(sc["confusion"].values())))
+
+
+# ---------------------------------------------------------------- 3. attr_aggregate with the shipped banks
+def gold_attr():
+    rs = np.random.RandomState(9)
+    out = {}
+    for ds, F_, T, K in (("pascal_voc", 20, 45, 112), ("ms_coco", 80, 103, 224)):
+        bank, flag = torch.load(os.path.join(REF, f"attributes_text/{ds}_desc_clip_ViT-B-16_gpt4.0_cluster_{K}_embedding_bank.pth"))
+        tf = rs.standard_normal((T, 512)).astype(np.float32)
+        tf /= np.linalg.norm(tf, axis=1, keepdims=True)
+        agg, _ = ref_attr_aggregate(torch.from_numpy(tf), ds, F_, K, "unused.json")
+        out[f"{ds}_text"] = tf
+        out[f"{ds}_agg"] = agg
+        # the shipped bank itself is reference DATA (not source): kept as a fixture so the GPU box,
+        # which has no /root/reference, can build the same text bank.
+        np.savez_compressed(os.path.join(HERE, f"attr_bank_{ds}.npz"), bank=bank.numpy(), flag=flag.numpy())
+    save("attr_aggregate.npz", **out)
+
+
+# ---------------------------------------------------------------- 4. refine + bkg + PAR + label, and e2e harness trace
+def gold_pipeline():
+    w = make_vit_weights(TINY, seed=11)
+    vit = build_ref_vit(TINY, w, feat_size=6, mode="train")
+    rs = np.random.RandomState(33)
+    text = rs.standard_normal((9, 32)).astype(np.float32)
+    text /= np.linalg.norm(text, axis=1, keepdims=True)
+    par = ref_PAR_mod.PAR(num_iter=20, dilations=[1, 2, 4, 8, 12, 24])
+    F_ = 4
+    out = dict(text=text)
+    gts, preds = [], []
+    sizes = [(40, 56), (96, 96), (50, 33), (64, 80)]
+    cls_sets = [[0, 2], [1], [0, 1, 3], [3, 2]]
+    for i, ((H, W), cls) in enumerate(zip(sizes, cls_sets)):
+        img = rs.standard_normal((1, 3, H, W)).astype(np.float32)
+        gt = rs.randint(0, F_ + 1, (H, W)).astype(np.uint8)
+        gt[:2, :] = 255
+        cls_label = np.zeros(F_, np.float32)
+        cls_label[cls] = 1
+        inputs = F.interpolate(torch.from_numpy(img), size=[96, 96], mode="bilinear", align_corners=False)
+        _, f, attn, _ = ref_generate_clip_fts(vit, inputs)
+        maps = ref_clip_fs(f, torch.from_numpy(text))[:, 1:, :F_]
+        refined, cls_lst = ref_aff.refine_cams_with_aff(maps[0], attn[:, 0], torch.from_numpy(cls_label),
+                                                        size=inputs.shape[2:], caa_thre=0.79)
+        labels, cams = ref_aff.refine_cams_with_bkg_weclip(refined, inputs[0], cls_lst, par, (H, W))
+        out.update({f"s{i}_img": img[0], f"s{i}_gt": gt, f"s{i}_cls": cls_label, f"s{i}_inputs": inputs,
+                    f"s{i}_maps": maps, f"s{i}_refined": torch.stack(refined, 0), f"s{i}_cls_lst": cls_lst,
+                    f"s{i}_cams": cams, f"s{i}_label": labels[0]})
+        preds.append(labels[0].numpy().astype(np.int16))
+        gts.append(gt.astype(np.int16))
+    hist = sum(ref_eval._fast_hist(g.flatten(), p.flatten(), F_ + 1) for g, p in zip(gts, preds))
+    with np.errstate(all="ignore"):
+        sc = ref_eval.scores(gts, preds, num_classes=F_ + 1)
+    save("pipeline_tiny.npz", seed_w=11, hist=hist, miou=sc["miou"], **out)
+
+
+if __name__ == "__main__":
+    with torch.no_grad():
+        gold_vit_cam()
+        gold_ops()
+        gold_attr()
+        gold_pipeline()

@@ -1,0 +1,130 @@
+"""Pin the numpy oracle against goldens captured from the reference's own Python
+(tests/golden/make_goldens.py).  CPU only."""
+import numpy as np
+import pytest
+
+import oracle
+from oracle.vit import VitConfig, make_vit_weights
+
+TINY = VitConfig(width=64, layers=8, heads=2, patch=16, out_dim=32, input_resolution=64, n_surgery=5)
+
+
+def maxabs(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
+
+
+def relmax(a, b):
+    """max-abs error relative to the reference's largest magnitude (fp32 round-off is
+    amplified ~100x through the 8 gain-4 attention blocks of the tiny model)."""
+    return maxabs(a, b) / float(np.max(np.abs(b)))
+
+
+@pytest.mark.parametrize("mode", ["train", "val"])
+def test_vit_forward_and_cam(golden, mode):
+    g = golden("vit_cam_tiny.npz")
+    w = make_vit_weights(TINY, seed=int(g["seed_w"]))
+    w = oracle.vit.reload_self_attn(w, TINY, feat_size=6, mode=mode)
+    f, attn, feats = oracle.cam.generate_clip_fts(g["imgs"], w, TINY)
+    x, _, _ = oracle.vit.vit_forward(g["imgs"], w, TINY)
+    assert maxabs(x, g[f"{mode}_x"]) < 2e-5
+    assert maxabs(f, g[f"{mode}_image_features"]) < 1e-5
+    assert attn.shape == g[f"{mode}_attn"].shape
+    assert maxabs(attn, g[f"{mode}_attn"]) < 1e-4      # values up to heads=2; fp32 through 8 blocks
+    # block-6-style (index 2) weights are head-averaged, surgery ones head-summed (quirk Q3)
+    np.testing.assert_allclose(attn[2].sum(-1), 1.0, atol=1e-5)
+    np.testing.assert_allclose(attn[5].sum(-1), TINY.heads, atol=1e-5)
+    assert maxabs(feats[0], g[f"{mode}_feat0"]) < 2e-5
+    assert relmax(feats[-1], g[f"{mode}_feat_last"]) < 5e-5
+    cam = oracle.cam.clip_feature_surgery(f, g[f"{mode}_text"])
+    assert maxabs(cam, g[f"{mode}_cam"]) < 2e-5
+
+
+def test_vit_second_resolution_uses_resized_grid(golden):
+    g = golden("vit_cam_tiny.npz")
+    w = make_vit_weights(TINY, seed=int(g["seed_w"]))
+    w = oracle.vit.reload_self_attn(w, TINY, feat_size=6, mode="train")
+    x, attn, _ = oracle.vit.vit_forward(g["res2_imgs"], w, TINY)
+    assert maxabs(x, g["res2_x"]) < 2e-5
+    assert maxabs(attn[-1], g["res2_attn_last"]) < 1e-4
+
+
+def test_clip_feature_surgery(golden):
+    g = golden("ops.npz")
+    out = oracle.cam.clip_feature_surgery(g["cfs_f"], g["cfs_t"])
+    assert maxabs(out, g["cfs_out"]) < 1e-5
+
+
+def test_compute_trans_mat(golden):
+    g = golden("ops.npz")
+    out = oracle.aff.compute_trans_mat(g["tm_in"])
+    assert maxabs(out, g["tm_out"]) < 1e-7
+    np.testing.assert_allclose(out, g["tm_out"], rtol=2e-5)
+
+
+def test_par(golden):
+    g = golden("ops.npz")
+    par = oracle.par.PAR([1, 2, 4, 8, 12, 24], 20)
+    out = par(g["par_img"], g["par_mask"])
+    assert out.shape == g["par_out"].shape
+    assert maxabs(out, g["par_out"]) < 2e-5
+    par3 = oracle.par.PAR([1, 2, 4, 8, 12, 24], 3)
+    out2 = par3(g["par2_img"], g["par2_mask"])
+    assert maxabs(out2, g["par2_out"]) < 1e-5
+
+
+def test_par_position_softmax_constants():
+    # std48(pos) = 9.9003 ; d=1 straight tap weight 0.07645
+    par = oracle.par.PAR([1, 2, 4, 8, 12, 24], 1)
+    assert abs(float(par.pos.std(ddof=1)) - 9.9003) < 1e-3
+    z = -((par.pos / (par.pos.std(ddof=1) + 1e-8) / 0.3) ** 2)
+    sm = np.exp(z - z.max())
+    sm /= sm.sum()
+    assert abs(sm[1] - 0.07645) < 1e-4 and abs(sm[0] - 0.06826) < 1e-4
+
+
+def test_scores(golden):
+    g = golden("ops.npz")
+    hist = oracle.evaluate.hist_of(list(g["sc_gts"]), list(g["sc_preds"]), 21)
+    assert np.array_equal(hist, g["sc_hist"])
+    sc = oracle.evaluate.scores(list(g["sc_gts"]), list(g["sc_preds"]), 21)
+    assert abs(sc["miou"] - float(g["sc_miou"])) < 1e-12
+    assert abs(sc["pAcc"] - float(g["sc_pacc"])) < 1e-12
+    assert abs(sc["mAcc"] - float(g["sc_macc"])) < 1e-12
+    np.testing.assert_allclose(np.array(list(sc["iou"].values())), g["sc_iou"], rtol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(np.array(list(sc["precision"].values())), g["sc_prec"], rtol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(np.array(list(sc["recall"].values())), g["sc_rec"], rtol=1e-12, equal_nan=True)
+    np.testing.assert_allclose(np.array(list(sc["confusion"].values())), g["sc_conf"], rtol=1e-12, equal_nan=True)
+
+
+@pytest.mark.parametrize("ds,F,K", [("pascal_voc", 20, 112), ("ms_coco", 80, 224)])
+def test_attr_aggregate(golden, ds, F, K):
+    g = golden("attr_aggregate.npz")
+    bank = golden(f"attr_bank_{ds}.npz")["bank"]
+    assert bank.shape == (512, K)
+    out = oracle.attr.attr_aggregate(g[f"{ds}_text"], bank, F)
+    assert out.shape == g[f"{ds}_agg"].shape
+    assert maxabs(out, g[f"{ds}_agg"]) < 1e-6
+    np.testing.assert_allclose(np.linalg.norm(out, axis=0), 1.0, atol=1e-5)
+
+
+def test_pipeline_trace(golden):
+    g = golden("pipeline_tiny.npz")
+    w = make_vit_weights(TINY, seed=int(g["seed_w"]))
+    w = oracle.vit.reload_self_attn(w, TINY, feat_size=6, mode="train")
+    text_attr = g["text"].T.copy()
+    par = oracle.par.PAR([1, 2, 4, 8, 12, 24], 20)
+    samples = []
+    for i in range(4):
+        r = oracle.pipeline.run_sample(g[f"s{i}_img"], g[f"s{i}_cls"], g[f"s{i}_gt"].shape, w, TINY,
+                                       text_attr, 4, par, 96, return_all=True)
+        assert maxabs(r["inputs"], g[f"s{i}_inputs"]) < 1e-5
+        assert maxabs(r["attr_maps_raw"], g[f"s{i}_maps"]) < 5e-5
+        assert np.array_equal(r["cls_lst"], g[f"s{i}_cls_lst"])
+        assert maxabs(np.stack(r["refined"]), g[f"s{i}_refined"]) < 1e-5
+        assert maxabs(r["cams"], g[f"s{i}_cams"]) < 5e-5
+        agree = np.mean(r["label"] == g[f"s{i}_label"])
+        assert agree >= 0.999, agree
+        samples.append((g[f"s{i}_img"], g[f"s{i}_gt"], g[f"s{i}_cls"]))
+    hist, _ = oracle.pipeline.build_validation(samples, w, TINY, text_attr, num_classes=5, resize_size=96)
+    assert np.abs(hist - g["hist"]).sum() <= 4          # argmax near-ties only
+    assert abs(oracle.evaluate.scores_from_hist(hist)["miou"] - float(g["miou"])) < 1e-3
