@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Benchmark of the training-free CAM + affinity + PAR hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = one pass of the whole path over one resident batch of synthetic 448x448 images
+(ViT-B/16 surgery forward -> patch-text CAM -> attention random walk -> upsample+bg -> PAR x20 -> argmax ->
+confusion accumulate); BASELINE.json configs[2] ("VOC 448x448 batch=32, full HIP path incl. PAR") is the
+configuration its metric "images/sec (CAM+PAR refine, 448x448)" is quoted on.  Inputs are generated once and are
+resident in HBM before the timed region.  Images are sharded across ranks (independent images, weak scaling: fixed
+per-GPU batch); the only collective is one RCCL all-gather of the [21,21] int64 confusion matrix at the end
+(inside the timed region).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+F32_MATRIX_PEAK_TF = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (the dtype the GEMMs compute in)
+# SURVEY.md 8 flop table @448^2 (per image, GFLOP): rows that run on the gemm_f32 kernel
+GEMM_GFLOP_PER_IMG = 0.925 + 12 * (2.778 + 0.926 + 7.408) + 5 * (0.926 + 0.947) + 0.617 + 0.036
+VIT_CAM_GFLOP_PER_IMG = 181.2  # the reference algorithm's ViT + CAM work
+
+
+def par_bytes_per_image(C, H=448, W=448):
+    """20 x (48 + 2C) * H*W*4  +  aff build (3 + 48) * H*W*4."""
+    return 20 * (48 + 2 * C) * H * W * 4 + (3 + 48) * H * W * 4
+
+
+def cpu_baseline(n_images, seed):
+    """The numpy oracle (a port of the reference's algorithm, batch 1 like tools/infer_lam.py:167) timed on this
+    box's host cores over a bounded sample of the same workload."""
+    import oracle
+    from oracle.vit import VitConfig
+    from excel_amd.tools import synthetic
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    cfg = VitConfig(width=768, layers=12, heads=12, patch=16, out_dim=512, input_resolution=224, n_surgery=5)
+    w = oracle.vit.reload_self_attn(synthetic.make_vit_state_dict(seed=0), cfg, 28, "train")
+    bank = np.load(os.path.join(ROOT, "tests", "golden", "attr_bank_pascal_voc.npz"))["bank"]
+    text_attr = oracle.attr.attr_aggregate(synthetic.make_text_features(45), bank, 20)
+    ds = synthetic.SyntheticSegDataset(n_images, (448, 448), seed=seed)
+    samples = [(ds[i][1], ds[i][2], ds[i][3]) for i in range(n_images)]
+    t0 = time.time()
+    hist, _ = oracle.pipeline.build_validation(samples, w, cfg, text_attr, num_classes=21, resize_size=448)
+    dt = time.time() - t0
+    return {"value": n_images / dt, "unit": "images/s", "cores": int(threads), "kind": "port",
+            "sample": f"{n_images} synthetic 448x448 images, batch 1, numpy fp32 oracle (BLAS threads={threads}; "
+                      f"elementwise/PAR stages single-threaded), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step (BASELINE configs[2]: 32)")
+    ap.add_argument("--cpu-images", type=int, default=3, help="images in the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with HIP events")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP library is the only compute path (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")      # RCCL on ROCm
+
+    from excel_amd import ops
+    from excel_amd.model import ExCEL_model
+    from excel_amd.pipeline import TrainingFreePipeline
+    from excel_amd.tools import synthetic
+    from excel_amd.tools.infer_lam import gather_hists, shard_indices
+    from excel_amd.utils import evaluate
+
+    B, S, NC = args.batch, 448, 21
+    model = ExCEL_model(clip_model="ExCEL_ViT-B/16", num_classes=NC, img_size=S, mode="train", device=device,
+                        state_dict=synthetic.make_vit_state_dict(seed=0), text_features=synthetic.make_text_features(45))
+    # rank r takes images r, r+R, ... (tools/infer_lam.py:166); two distinct resident batches, alternated
+    n_batches = 2
+    ds = synthetic.SyntheticSegDataset(world * B * n_batches, (S, S), num_classes=NC, seed=1234)
+    mine = shard_indices(len(ds), rank, world)
+    batches = []
+    ks = []
+    for i in range(n_batches):
+        _, imgs, gts, cls = ds.batch(mine[i * B:(i + 1) * B])
+        ks.append(cls.sum(1))
+        batches.append((torch.from_numpy(imgs).to(device), torch.from_numpy(cls).to(device), torch.from_numpy(gts).to(device)))
+    pipe = TrainingFreePipeline(model, num_classes=NC, smax=ds.max_k())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        pipe.run_batch(*batches[i % n_batches])
+    pipe.reset()
+    timing = not args.no_kernel_timing
+    if timing:
+        ops.prof_collect()
+        ops.prof_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        pipe.run_batch(*batches[i % n_batches])
+    per_rank, total = gather_hists(pipe.hist)                       # the one collective (RCCL all-gather)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = None
+    if timing:
+        ops.prof_enable(False)
+        prof = ops.prof_collect()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        n_img = world * B * args.steps
+        value = n_img / dt
+        miou = evaluate.scores_from_hist(total)["miou"]
+        out = {
+            "metric": "images/sec (CAM+PAR refine, 448x448)", "value": round(value, 3), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: VOC-shaped 448x448, batch=32/GPU, ViT-B/16 surgery + patch-text CAM "
+                                   "(T=45,F=20) + affinity random walk + PAR(20 it, 6 dilations) + argmax + confusion, "
+                                   "full HIP path; seeded random weights, shipped VOC attribute bank",
+                       "batch_per_gpu": B, "image": "448x448", "parallelism": f"image-sharded x{world}, 1 RCCL all-gather of [21,21] int64",
+                       "k_present_classes_mean": float(np.mean(np.concatenate(ks)))},
+            "miou_synthetic": round(float(miou), 6),
+        }
+        if prof:
+            steps = args.steps
+            ms = {k: v["ms"] / steps for k, v in prof.items() if v["launches"]}
+            gemm_ms = prof["gemm_nt"]["ms"]
+            gemm_launches = max(prof["gemm_nt"]["launches"], 1)
+            gemm_flops = prof["gemm_nt"]["work"]                    # sum of 2*M*N*K over the launches (algorithmic)
+            achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get("gemm_f32_kernel_nt_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            out["roofline"] = {
+                "kernel": "gemm_f32_kernel<NT> (fp32 MFMA 32x32x2; all nn.Linear / patch-embed / proj / sim GEMMs)",
+                "bound": "mfma", "achieved": round(achieved, 3), "peak": F32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
+                "frac": round(achieved / F32_MATRIX_PEAK_TF, 4), "traffic": traffic,
+                "avg_launch_ms": round(gemm_ms / gemm_launches, 5), "launches_per_step": gemm_launches // steps,
+                "algorithmic_gflop_per_image": round(gemm_flops / steps / B / 1e9, 3),
+                "survey_gflop_per_image": round(GEMM_GFLOP_PER_IMG, 3),
+            }
+            # secondary rooflines (same event-timing source): PAR propagation (HBM) and the whole ViT (MFMA)
+            par_it = prof["par_iterate"]
+            if par_it["ms"] > 0:
+                par_bytes = sum(20 * (48 + 2 * (int(k) + 1)) * S * S * 4 for kk in ks for k in kk) * (steps / n_batches)
+                gbs = par_bytes / (par_it["ms"] * 1e-3) / 1e9
+                out["roofline_par_iterate"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                               "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                               "avg_launch_ms": round(par_it["ms"] / max(par_it["launches"], 1), 5)}
+            vit_ms = sum(prof[k]["ms"] for k in ("gemm_nt", "gemm_nn", "attn_rowpass", "attn_accum", "layernorm", "embed",
+                                                  "token_norm", "cam_epilogue"))
+            if vit_ms > 0:
+                tf = VIT_CAM_GFLOP_PER_IMG * 1e9 * B * steps / (vit_ms * 1e-3) / 1e12
+                out["roofline_vit_cam"] = {"bound": "mfma", "achieved": round(tf, 3), "peak": F32_MATRIX_PEAK_TF,
+                                           "unit": "TFLOP/s", "frac": round(tf / F32_MATRIX_PEAK_TF, 4)}
+            out["kernel_ms_per_step"] = {k: round(v, 4) for k, v in sorted(ms.items(), key=lambda kv: -kv[1])}
+        if world == 1 and args.cpu_images > 0:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_images, seed=1234)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

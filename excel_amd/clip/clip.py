@@ -1,0 +1,72 @@
+"""Mirror of the hot functions of the reference's clip/clip.py.
+
+  generate_clip_fts      clip/clip.py:348-358
+  clip_feature_surgery   clip/clip.py:288-310
+  load                   clip/clip.py:106-154 (weights come from a state_dict; no download, no JIT archive)
+"""
+import torch
+
+from .. import ops
+from .clip_surgery_model import ExCEL_CLIP, VisionTransformer
+
+
+class LazyAttnWeights:
+    """What generate_clip_fts returns as `attn_weights` on the fast path.
+
+    The reference stacks 12 x [B,N,N] matrices (29.6 MB/image) although only
+    attn_weights[-6:, 1:, 1:].mean(0) is ever consumed (utils/affutils.py:180,197).  The HIP ViT reduces
+    that mean inside the attention kernel; this object carries it (`w_aff`) and still supports the
+    reference's `attn_weights[:, i]` indexing.  Per-layer matrices are materialised only when asked for
+    (generate_clip_fts(..., n_attn_out=k)).
+    """
+
+    def __init__(self, w_aff, stacked=None, aff_layers=6):
+        self.w_aff = w_aff            # [B,P,P]
+        self.stacked = stacked        # [n,B,N,N] or None
+        self.aff_layers = aff_layers
+
+    def __getitem__(self, key):
+        if isinstance(key, tuple) and len(key) >= 2 and key[0] == slice(None):
+            i = key[1]
+            if isinstance(i, int):
+                return LazyAttnWeights(self.w_aff[i:i + 1], None if self.stacked is None else self.stacked[:, i:i + 1],
+                                       self.aff_layers)
+        if self.stacked is not None:
+            return self.stacked[key]
+        raise IndexError("per-layer attention weights were not materialised; call generate_clip_fts(..., n_attn_out=k)")
+
+    @property
+    def shape(self):
+        B, P, _ = self.w_aff.shape
+        return (self.aff_layers if self.stacked is None else self.stacked.shape[0], B, P + 1, P + 1)
+
+
+def generate_clip_fts(inputs, model, return_weights=True, ex_feats=None, n_attn_out=0, want_feats=False, aff_layers=6):
+    """-> (image_features [B,N,C] L2-normalised over the TOKEN axis (:353), attn_weights, all_feats).
+
+    attn_weights is a LazyAttnWeights (fast path) unless n_attn_out > 0, in which case it also holds the stacked
+    [n_attn_out,B,N,N] tensor of the last layers.  all_feats is [L,B,N,D] when want_feats else None."""
+    r = model.encode_image(inputs, return_weights, ex_feats, want_w_aff=True, aff_layers=aff_layers,
+                           n_attn_out=n_attn_out, want_feats=want_feats)
+    return r["image_features"], LazyAttnWeights(r["w_aff"], r["attn"], aff_layers), r["feats"]
+
+
+def clip_feature_surgery(image_features, text_features, redundant_feats=None, t=2):
+    """[B,N,C] x [T,C] -> attr maps [B,N,T] (:288-310)."""
+    if redundant_feats is not None:
+        raise NotImplementedError("redundant_feats branch (clip.py:290-291) is not on the training-free path")
+    full, _ = ops.clip_feature_surgery(image_features, text_features, t=float(t))
+    return full
+
+
+def load(name, device="cuda", state_dict=None, width=768, layers=12, heads=12, patch=16, output_dim=512,
+         input_resolution=224):
+    """clip.load("ExCEL_ViT-B/16") counterpart: builds the visual tower from a state_dict whose keys follow the
+    reference ("visual.conv1.weight" ... or without the "visual." prefix).  Returns (model, None)."""
+    if state_dict is None:
+        raise RuntimeError("excel_amd.clip.load needs state_dict= (no network: the CLIP checkpoint cannot be downloaded)")
+    sd = {}
+    for k, v in state_dict.items():
+        sd[k[len("visual."):] if k.startswith("visual.") else k] = v
+    vis = VisionTransformer(input_resolution, patch, width, layers, heads, output_dim, state_dict=sd, device=device)
+    return ExCEL_CLIP(vis), None

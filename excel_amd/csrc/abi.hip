@@ -1,0 +1,493 @@
+// extern "C" entry points of libexcel_hip (declared in include/excel_hip.h) and the host-side ViT driver.
+#include "../../include/excel_hip.h"
+#include "common.h"
+#include "excel_internal.h"
+
+#include <stdarg.h>
+#include <map>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+
+void excel_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* excel_last_error(void) { return g_err; }
+extern "C" int excel_abi_version(void) { return 1; }
+
+// ------------------------------------------------------------------------------------ profiling hooks
+bool g_excel_prof_on = false;
+namespace {
+struct ProfRec { int cat; hipEvent_t a, b; };
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_prof_pool;
+double g_prof_work[PROF_NCAT];
+const char* PROF_NAMES[PROF_NCAT] = {"gemm_nt", "gemm_nn", "attn_rowpass", "attn_accum", "layernorm", "embed", "token_norm",
+                                     "cam_epilogue", "sinkhorn", "bbox_mask", "matvec", "cam_upsample", "par_affinity",
+                                     "par_iterate", "argmax", "confusion", "other"};
+hipEvent_t prof_event() {
+    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+}  // namespace
+void excel_prof_begin(int cat, hipStream_t st, double work) {
+    ProfRec r{cat, prof_event(), prof_event()};
+    (void)hipEventRecord(r.a, st);
+    g_prof_recs.push_back(r);
+    g_prof_work[cat] += work;
+}
+void excel_prof_end(int cat, hipStream_t st) {
+    for (size_t i = g_prof_recs.size(); i-- > 0;)
+        if (g_prof_recs[i].cat == cat) { (void)hipEventRecord(g_prof_recs[i].b, st); return; }
+}
+extern "C" int excel_prof_enable(int on) {
+    g_excel_prof_on = on != 0;
+    return EXCEL_OK;
+}
+extern "C" int excel_prof_num_categories(void) { return PROF_NCAT; }
+extern "C" const char* excel_prof_category_name(int cat) { return (cat >= 0 && cat < PROF_NCAT) ? PROF_NAMES[cat] : ""; }
+// Synchronises on the recorded events, sums elapsed ms / launches / algorithmic work per category, resets the log.
+extern "C" int excel_prof_collect(double* ms, long long* launches, double* work) {
+    for (int c = 0; c < PROF_NCAT; ++c) { ms[c] = 0.0; launches[c] = 0; work[c] = g_prof_work[c]; g_prof_work[c] = 0.0; }
+    for (auto& r : g_prof_recs) {
+        float t = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+            ms[r.cat] += t;
+            launches[r.cat] += 1;
+        }
+        g_prof_pool.push_back(r.a);
+        g_prof_pool.push_back(r.b);
+    }
+    g_prof_recs.clear();
+    return EXCEL_OK;
+}
+
+#define ST(s) ((hipStream_t)(s))
+#define TRY(x)                  \
+    do {                        \
+        int rc__ = (x);         \
+        if (rc__) return rc__;  \
+    } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static GemmArgs gemm_args(const float* A, const float* B, float* C, const float* bias, const float* res, int M, int N, int K,
+                          int lda, int ldb, int ldc, int ldr, int act) {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.B = B; g.C = C; g.bias = bias; g.res = res;
+    g.M = M; g.N = N; g.K = K; g.Kld = (K + 3) / 4 * 4;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
+    g.act = act; g.out_mode = GEMM_OUT_PLAIN; g.alpha = 1.f; g.zdiv = 1;
+    return g;
+}
+
+// ------------------------------------------------------------------------------------ small helper kernels
+__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cc) {
+    __shared__ float t[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    for (int k = ty; k < 32; k += 8)
+        if (r0 + k < R && c0 + tx < Cc) t[k][tx] = in[(long long)(r0 + k) * Cc + c0 + tx];
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8)
+        if (c0 + k < Cc && r0 + tx < R) out[(long long)(c0 + k) * R + r0 + tx] = t[tx][k];
+}
+
+// positional grid resize, F.interpolate(bilinear, align_corners=False) on [1,D,side,side] (clip_surgery_model.py:430-433)
+__global__ void pos_resize_kernel(const float* __restrict__ pos, float* __restrict__ out, int side, int g, int D) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)(g * g + 1) * D;
+    if (i >= total) return;
+    const int d = (int)(i % D);
+    const int n = (int)(i / D);
+    if (n == 0) { out[i] = pos[d]; return; }
+    const int y = (n - 1) / g, x = (n - 1) % g;
+    const float sc = (float)side / (float)g;
+    float fy = fmaxf(sc * ((float)y + 0.5f) - 0.5f, 0.f), fx = fmaxf(sc * ((float)x + 0.5f) - 0.5f, 0.f);
+    const int y0 = min((int)fy, side - 1), x0 = min((int)fx, side - 1);
+    const int y1 = min(y0 + 1, side - 1), x1 = min(x0 + 1, side - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    auto at = [&](int yy, int xx) { return pos[(long long)(1 + yy * side + xx) * D + d]; };
+    out[i] = (1.f - ly) * ((1.f - lx) * at(y0, x0) + lx * at(y0, x1)) + ly * ((1.f - lx) * at(y1, x0) + lx * at(y1, x1));
+}
+
+__global__ void attn_layer_mean_kernel(const float* __restrict__ attn, int B, int N, int first, int nl, float* __restrict__ out) {
+    const long long P = N - 1;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * P * P) return;
+    const int c = (int)(i % P), r = (int)((i / P) % P);
+    const long long b = i / (P * P);
+    float s = 0.f;
+    for (int l = 0; l < nl; ++l) s += attn[(((long long)(first + l) * B + b) * N + (r + 1)) * N + (c + 1)];
+    out[i] = s / (float)nl;
+}
+
+// ------------------------------------------------------------------------------------ building blocks
+extern "C" int excel_gemm_f32(const float* A, const float* Bm, float* C, const float* bias, const float* residual, int M, int N,
+                              int K, int lda, int ldb, int ldc, int ldr, int b_kmajor, int act, int batch, long long sA,
+                              long long sB, long long sC, long long sR, void* stream) {
+    GemmArgs g = gemm_args(A, Bm, C, bias, residual, M, N, K, lda, ldb, ldc, ldr, act);
+    EXCEL_CHECK_ARG((K % 4) == 0 || !b_kmajor, "excel_gemm_f32: K must be a multiple of 4 in NT mode (K=%d)", K);
+    if (!b_kmajor) {
+        EXCEL_CHECK_ARG((K % 4) == 0, "excel_gemm_f32: K must be a multiple of 4 (pad A with zeros) (K=%d)", K);
+    }
+    g.sA = sA; g.sB = sB; g.sC = sC; g.sR = sR;
+    return excel_launch_gemm(g, b_kmajor != 0, batch, ST(stream));
+}
+
+extern "C" int excel_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int D, float eps, void* stream) {
+    return excel_launch_layernorm(x, nullptr, 1, w, b, y, rows, D, eps, ST(stream));
+}
+
+// ------------------------------------------------------------------------------------ ViT handle
+struct excel_vit {
+    excel_vit_config cfg;
+    excel_vit_weights w;
+    std::vector<excel_vit_block_weights> blocks;
+    float* projT = nullptr;             // [C, D]
+    std::map<int, float*> pos_cache;    // g -> [1+g*g, D]
+};
+
+extern "C" int excel_vit_create(const excel_vit_config* cfg, const excel_vit_weights* w, excel_vit_t* out) {
+    EXCEL_CHECK_ARG(cfg && w && out, "excel_vit_create: null argument");
+    EXCEL_CHECK_ARG(cfg->heads > 0 && cfg->width == cfg->heads * 64, "excel_vit_create: head_dim must be 64 (width=%d heads=%d)", cfg->width, cfg->heads);
+    EXCEL_CHECK_ARG(cfg->layers >= 1 && cfg->n_surgery >= 0 && cfg->n_surgery <= cfg->layers, "excel_vit_create: bad layer counts");
+    EXCEL_CHECK_ARG((cfg->out_dim % 4) == 0 && (cfg->patch % 4) == 0, "excel_vit_create: out_dim and patch must be multiples of 4");
+    excel_vit* h = new excel_vit();
+    h->cfg = *cfg;
+    h->w = *w;
+    h->blocks.assign(w->blocks, w->blocks + cfg->layers);
+    h->w.blocks = h->blocks.data();
+    if (hipMalloc(&h->projT, sizeof(float) * cfg->out_dim * cfg->width) != hipSuccess) {
+        delete h;
+        excel_set_error("excel_vit_create: hipMalloc failed");
+        return EXCEL_ERR_ALLOC;
+    }
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(cfg->out_dim, 32), cdiv(cfg->width, 32)), dim3(256), 0, 0, w->proj, h->projT,
+                       cfg->width, cfg->out_dim);
+    if (hipStreamSynchronize(0) != hipSuccess) {
+        excel_set_error("excel_vit_create: transpose failed: %s", hipGetErrorString(hipGetLastError()));
+        hipFree(h->projT);
+        delete h;
+        return EXCEL_ERR_LAUNCH;
+    }
+    *out = h;
+    return EXCEL_OK;
+}
+
+extern "C" void excel_vit_destroy(excel_vit_t h) {
+    if (!h) return;
+    if (h->projT) hipFree(h->projT);
+    for (auto& kv : h->pos_cache) hipFree(kv.second);
+    delete h;
+}
+
+struct VitWs {
+    float *x, *xo, *y, *ao, *qkvh, *hbuf, *stats, *a_sum, *fraw, *ss;
+    int NP;
+    size_t total;
+};
+
+static VitWs vit_ws_layout(const excel_vit_config& c, int B, int S, char* base) {
+    const int g = S / c.patch, N = g * g + 1;
+    const size_t M = (size_t)B * N, D = c.width;
+    VitWs w;
+    w.NP = (N + 3) / 4 * 4;
+    size_t off = 0;
+    auto take = [&](size_t floats) { float* p = (float*)(base + off); off += align_up(floats * sizeof(float), 256); return p; };
+    w.x = take(M * D);
+    w.xo = take(M * D);
+    w.y = take(M * D);
+    w.ao = take(M * D);                   // also the patch-embed GEMM output [B*P, D]
+    w.qkvh = take(M * 3 * D);
+    {   // MLP hidden [M,4D]; also holds the im2col matrix [B*P, 3*ps*ps]
+        const size_t col = (size_t)B * (N - 1) * 3 * c.patch * c.patch;
+        w.hbuf = take(M * 4 * D > col ? M * 4 * D : col);
+    }
+    w.stats = take((size_t)B * c.heads * 4 * N * 2);
+    w.a_sum = take((size_t)B * N * w.NP);
+    w.fraw = take(M * c.out_dim);
+    w.ss = take((size_t)B * c.out_dim);
+    w.total = off;
+    return w;
+}
+
+extern "C" size_t excel_vit_workspace_bytes(excel_vit_t h, int B, int S) {
+    if (!h || B <= 0 || S <= 0 || S % h->cfg.patch) return 0;
+    return vit_ws_layout(h->cfg, B, S, nullptr).total;
+}
+
+extern "C" int excel_vit_forward(excel_vit_t h, const float* img, int B, int S, void* workspace, size_t workspace_bytes,
+                                 float* image_features, float* x_raw, float* w_aff, int aff_layers, float* attn_out,
+                                 int n_attn_out, float* feats_out, void* stream) {
+    EXCEL_CHECK_ARG(h && img && workspace && image_features, "excel_vit_forward: null argument");
+    const excel_vit_config& c = h->cfg;
+    EXCEL_CHECK_ARG(B > 0 && S > 0 && S % c.patch == 0, "excel_vit_forward: S must be a positive multiple of the patch size");
+    const int ps = c.patch, g = S / ps, P = g * g, N = P + 1, D = c.width, H = c.heads, L = c.layers, C = c.out_dim;
+    EXCEL_CHECK_ARG(n_attn_out >= 0 && n_attn_out <= L && (n_attn_out == 0 || attn_out), "excel_vit_forward: bad attn_out request");
+    EXCEL_CHECK_ARG(!w_aff || (aff_layers >= 1 && aff_layers <= L), "excel_vit_forward: bad aff_layers");
+    hipStream_t st = ST(stream);
+    VitWs ws = vit_ws_layout(c, B, S, (char*)workspace);
+    EXCEL_CHECK_ARG(workspace_bytes >= ws.total, "excel_vit_forward: workspace too small (%zu < %zu)", workspace_bytes, ws.total);
+    const int M = B * N;
+    const float eps = 1e-5f;
+    const float scale = 0.125f;   // head_dim^-0.5 with head_dim = 64 (clip_surgery_model.py:82)
+
+    // positional embedding for this grid (cached)
+    const float* pos = h->w.pos_emb;
+    if (g != c.pos_grid) {
+        auto it = h->pos_cache.find(g);
+        if (it == h->pos_cache.end()) {
+            float* buf = nullptr;
+            if (hipMalloc(&buf, sizeof(float) * (size_t)N * D) != hipSuccess) {
+                excel_set_error("excel_vit_forward: hipMalloc(pos) failed");
+                return EXCEL_ERR_ALLOC;
+            }
+            hipLaunchKernelGGL(pos_resize_kernel, dim3((unsigned)cdivl((long long)N * D, 256)), dim3(256), 0, st, h->w.pos_emb, buf, c.pos_grid, g, D);
+            EXCEL_CHECK_LAUNCH("pos_resize");
+            it = h->pos_cache.emplace(g, buf).first;
+        }
+        pos = it->second;
+    }
+
+    // patch embedding: im2col -> GEMM (conv1 weight is [D, 3*ps*ps] K-major) -> +cls/pos, ln_pre
+    TRY(excel_launch_im2col(img, ws.hbuf, B, S, ps, st));
+    {
+        const int Kc = 3 * ps * ps;
+        GemmArgs ga = gemm_args(ws.hbuf, h->w.conv1_w, ws.ao, nullptr, nullptr, B * P, D, Kc, Kc, Kc, D, 0, GEMM_ACT_NONE);
+        TRY(excel_launch_gemm(ga, true, 1, st));
+    }
+    TRY(excel_launch_assemble_ln_pre(ws.ao, h->w.class_emb, pos, h->w.ln_pre_w, h->w.ln_pre_b, ws.x, B, N, D, eps, st));
+
+    const int first_surgery = L - c.n_surgery;
+    for (int l = 0; l < L; ++l) {
+        const excel_vit_block_weights& bw = h->blocks[l];
+        const bool surgery = l >= first_surgery;
+        float* src = (surgery && l > first_surgery) ? ws.xo : ws.x;   // :315 vs :323
+        TRY(excel_launch_layernorm(src, nullptr, 1, bw.ln1_w, bw.ln1_b, ws.y, M, D, eps, st));
+        {   // packed q|k|v projection, written head-major
+            GemmArgs ga = gemm_args(ws.y, bw.in_proj_w, ws.qkvh, bw.in_proj_b, nullptr, M, 3 * D, D, D, D, 0, 0, GEMM_ACT_NONE);
+            ga.out_mode = GEMM_OUT_QKV_HEADMAJOR; ga.tokN = N; ga.heads = H; ga.hd = 64;
+            TRY(excel_launch_gemm(ga, true, 1, st));
+        }
+        TRY(excel_launch_attn_rowpass(ws.qkvh, ws.ao, ws.stats, B, H, N, 64, scale, surgery ? 4 : 1, st));
+        const bool in_aff = w_aff && l >= L - aff_layers;
+        float* attn_l = (n_attn_out && l >= L - n_attn_out) ? attn_out + (size_t)(l - (L - n_attn_out)) * B * N * N : nullptr;
+        if (surgery || in_aff || attn_l) {
+            TRY(excel_launch_attn_accum(ws.qkvh, ws.stats, surgery ? ws.a_sum : nullptr, in_aff ? w_aff : nullptr, attn_l, B, H, N,
+                                        ws.NP, 64, scale, surgery ? 1 : 0, surgery ? 1.f : 1.f / (float)H, 1.f / (float)aff_layers,
+                                        (l == L - aff_layers) ? 1 : 0, st));
+        }
+        if (!surgery) {
+            GemmArgs ga = gemm_args(ws.ao, bw.out_proj_w, ws.x, bw.out_proj_b, ws.x, M, D, D, D, D, D, D, GEMM_ACT_NONE);
+            TRY(excel_launch_gemm(ga, true, 1, st));                                              // x += out_proj(attn)
+            TRY(excel_launch_layernorm(ws.x, nullptr, 1, bw.ln2_w, bw.ln2_b, ws.y, M, D, eps, st));
+            GemmArgs g1 = gemm_args(ws.y, bw.fc1_w, ws.hbuf, bw.fc1_b, nullptr, M, 4 * D, D, D, D, 4 * D, 0, GEMM_ACT_QUICKGELU);
+            TRY(excel_launch_gemm(g1, true, 1, st));
+            GemmArgs g2 = gemm_args(ws.hbuf, bw.fc2_w, ws.x, bw.fc2_b, ws.x, M, D, 4 * D, 4 * D, 4 * D, D, D, GEMM_ACT_NONE);
+            TRY(excel_launch_gemm(g2, true, 1, st));                                              // x += mlp(ln_2(x))
+            if (feats_out) hipMemcpyAsync(feats_out + (size_t)l * M * D, ws.x, sizeof(float) * (size_t)M * D, hipMemcpyDeviceToDevice, st);
+        } else {
+            // new path: (A_sum . V_h) for every head, heads concatenated -> y  (batched NN GEMM over (b,h))   :149
+            {
+                GemmArgs ga = gemm_args(ws.a_sum, ws.qkvh + (size_t)2 * H * N * 64, ws.y, nullptr, nullptr, N, 64, N, ws.NP, 64, D, 0, GEMM_ACT_NONE);
+                ga.Kld = ws.NP;
+                ga.zdiv = H;
+                ga.sA = (long long)N * ws.NP; ga.sA2 = 0;
+                ga.sB = (long long)3 * H * N * 64; ga.sB2 = (long long)N * 64;
+                ga.sC = (long long)N * D; ga.sC2 = 64;
+                TRY(excel_launch_gemm(ga, false, B * H, st));
+            }
+            // original path residual first (x_ori = src + proj(attn_ori.v), :317/:326), then the new path (x += proj(.), :319/:329)
+            GemmArgs go = gemm_args(ws.ao, bw.out_proj_w, ws.xo, bw.out_proj_b, src, M, D, D, D, D, D, D, GEMM_ACT_NONE);
+            TRY(excel_launch_gemm(go, true, 1, st));
+            GemmArgs gn = gemm_args(ws.y, bw.out_proj_w, ws.x, bw.out_proj_b, ws.x, M, D, D, D, D, D, D, GEMM_ACT_NONE);
+            TRY(excel_launch_gemm(gn, true, 1, st));
+            TRY(excel_launch_layernorm(ws.xo, nullptr, 1, bw.ln2_w, bw.ln2_b, ws.y, M, D, eps, st));
+            GemmArgs g1 = gemm_args(ws.y, bw.fc1_w, ws.hbuf, bw.fc1_b, nullptr, M, 4 * D, D, D, D, 4 * D, 0, GEMM_ACT_QUICKGELU);
+            TRY(excel_launch_gemm(g1, true, 1, st));
+            GemmArgs g2 = gemm_args(ws.hbuf, bw.fc2_w, ws.xo, bw.fc2_b, ws.xo, M, D, 4 * D, 4 * D, 4 * D, D, D, GEMM_ACT_NONE);
+            TRY(excel_launch_gemm(g2, true, 1, st));                                              // x_ori += mlp(ln_2(x_ori))
+            if (feats_out) hipMemcpyAsync(feats_out + (size_t)l * M * D, ws.xo, sizeof(float) * (size_t)M * D, hipMemcpyDeviceToDevice, st);
+        }
+    }
+    // x[0] = x_ori[0] (:442) fused into ln_post (:445), then @ proj (:446)
+    TRY(excel_launch_layernorm(ws.x, c.n_surgery > 0 ? ws.xo : nullptr, N, h->w.ln_post_w, h->w.ln_post_b, ws.y, M, D, eps, st));
+    float* fraw = x_raw ? x_raw : ws.fraw;
+    {
+        GemmArgs ga = gemm_args(ws.y, h->projT, fraw, nullptr, nullptr, M, C, D, D, D, C, 0, GEMM_ACT_NONE);
+        TRY(excel_launch_gemm(ga, true, 1, st));
+    }
+    TRY(excel_launch_token_axis_normalize(fraw, ws.ss, image_features, B, N, C, st));             // clip.py:353
+    return EXCEL_OK;
+}
+
+// ------------------------------------------------------------------------------------ CAM
+extern "C" size_t excel_cam_workspace_bytes(int B, int N, int T) {
+    return align_up((size_t)B * N * ((T + 3) / 4 * 4) * sizeof(float), 256);
+}
+
+extern "C" int excel_clip_feature_surgery(const float* image_features, const float* text, int B, int N, int C, int T, int F,
+                                          float temperature, float* out_full, float* out_slice, void* workspace, void* stream) {
+    EXCEL_CHECK_ARG(image_features && text && workspace && (out_full || out_slice), "clip_feature_surgery: null argument");
+    EXCEL_CHECK_ARG((C % 4) == 0, "clip_feature_surgery: C must be a multiple of 4");
+    const int ldT = (T + 3) / 4 * 4;
+    float* S = (float*)workspace;
+    // S[b*N+n, t] = f . text[t]  -- one NT GEMM over all B*N token rows (text shared)
+    GemmArgs ga = gemm_args(image_features, text, S, nullptr, nullptr, B * N, T, C, C, C, ldT, 0, GEMM_ACT_NONE);
+    TRY(excel_launch_gemm(ga, true, 1, ST(stream)));
+    return excel_launch_cam_epilogue(S, out_full, out_slice, B, N, T, ldT, F, temperature, ST(stream));
+}
+
+// ------------------------------------------------------------------------------------ affinity
+extern "C" int excel_attn_layer_mean(const float* attn, int Lw, int B, int N, int first_layer, int n_layers, float* w_aff, void* stream) {
+    EXCEL_CHECK_ARG(attn && w_aff && first_layer >= 0 && n_layers >= 1 && first_layer + n_layers <= Lw, "attn_layer_mean: bad layer range");
+    const long long n = (long long)B * (N - 1) * (N - 1);
+    hipLaunchKernelGGL(attn_layer_mean_kernel, dim3((unsigned)cdivl(n, 256)), dim3(256), 0, ST(stream), attn, B, N, first_layer, n_layers, w_aff);
+    EXCEL_CHECK_LAUNCH("attn_layer_mean");
+    return EXCEL_OK;
+}
+
+extern "C" size_t excel_trans_mat_workspace_bytes(int B, int P) {
+    return 2 * align_up((size_t)B * P * P * sizeof(float), 256) + align_up((size_t)B * P * sizeof(float), 256);
+}
+
+extern "C" int excel_compute_trans_mat(const float* w_aff, int B, int P, float* trans_out, void* workspace, void* stream) {
+    EXCEL_CHECK_ARG(w_aff && trans_out && workspace, "compute_trans_mat: null argument");
+    EXCEL_CHECK_ARG((P % 4) == 0, "compute_trans_mat: P must be a multiple of 4 (P=%d)", P);
+    char* base = (char*)workspace;
+    const size_t mat = align_up((size_t)B * P * P * sizeof(float), 256);
+    float* T = (float*)base;
+    float* Tsym = (float*)(base + mat);
+    float* cs = (float*)(base + 2 * mat);
+    TRY(excel_launch_trans_mat_sym(w_aff, T, Tsym, cs, B, P, ST(stream)));
+    // Tsym . Tsym ; Tsym symmetric => B operand [N,K] = Tsym itself (NT form)
+    GemmArgs ga = gemm_args(Tsym, Tsym, trans_out, nullptr, nullptr, P, P, P, P, P, P, 0, GEMM_ACT_NONE);
+    ga.sA = ga.sB = ga.sC = (long long)P * P;
+    return excel_launch_gemm(ga, true, B, ST(stream));
+}
+
+extern "C" int excel_cls_compact(const float* onehot, int B, int F, int Smax, int32_t* cls_idx, int32_t* ncls, int32_t* nchan,
+                                 void* stream) {
+    EXCEL_CHECK_ARG(onehot && cls_idx && ncls && Smax >= 1, "cls_compact: bad argument");
+    return excel_launch_cls_compact(onehot, B, F, Smax, cls_idx, ncls, nchan, ST(stream));
+}
+
+extern "C" int excel_scoremap_box_mask(const float* attr, const int32_t* cls_idx, const int32_t* ncls, int B, int g, int F, int Smax,
+                                       double caa_thre, float* v_out, uint8_t* mask_out, void* stream) {
+    EXCEL_CHECK_ARG(attr && cls_idx && ncls && v_out, "scoremap_box_mask: null argument");
+    return excel_launch_bbox_mask(attr, cls_idx, ncls, B, g, F, Smax, caa_thre, v_out, mask_out, ST(stream));
+}
+
+extern "C" size_t excel_refine_workspace_bytes(int B, int P, int Smax) {
+    return 2 * align_up((size_t)B * P * P * sizeof(float), 256) + align_up((size_t)B * P * sizeof(float), 256) +
+           2 * align_up((size_t)B * Smax * P * sizeof(float), 256);
+}
+
+extern "C" int excel_refine_cams_with_aff(const float* attr, const float* w_aff, const int32_t* cls_idx, const int32_t* ncls, int B,
+                                          int g, int F, int Smax, double caa_thre, float* refined, void* workspace, void* stream) {
+    EXCEL_CHECK_ARG(attr && w_aff && cls_idx && ncls && refined && workspace, "refine_cams_with_aff: null argument");
+    const int P = g * g;
+    char* base = (char*)workspace;
+    const size_t mat = align_up((size_t)B * P * P * sizeof(float), 256);
+    const size_t vec = align_up((size_t)B * Smax * P * sizeof(float), 256);
+    float* T = (float*)base;
+    float* Tsym = (float*)(base + mat);
+    float* cs = (float*)(base + 2 * mat);
+    float* v = (float*)(base + 2 * mat + align_up((size_t)B * P * sizeof(float), 256));
+    float* u = (float*)((char*)v + vec);
+    hipStream_t st = ST(stream);
+    TRY(excel_launch_trans_mat_sym(w_aff, T, Tsym, cs, B, P, st));
+    TRY(excel_launch_bbox_mask(attr, cls_idx, ncls, B, g, F, Smax, caa_thre, v, nullptr, st));
+    TRY(excel_launch_matvec(Tsym, v, ncls, u, B, P, Smax, st));          // u = Tsym (mask.g)
+    TRY(excel_launch_matvec(Tsym, u, ncls, refined, B, P, Smax, st));    // refined = Tsym u = (Tsym.Tsym)(mask.g)
+    return EXCEL_OK;
+}
+
+extern "C" int excel_cam_upsample_bkg(const float* refined, const int32_t* ncls, int B, int g, int Smax, int H, int W, float* cams,
+                                      void* workspace, void* stream) {
+    EXCEL_CHECK_ARG(refined && ncls && cams && workspace, "cam_upsample_bkg: null argument");
+    return excel_launch_cam_upsample_bkg(refined, ncls, (float*)workspace, cams, B, g, Smax, H, W, ST(stream));
+}
+
+// ------------------------------------------------------------------------------------ PAR / labels / metric
+extern "C" size_t excel_par_workspace_bytes(int B, int Cmax, int H, int W, int ndil) {
+    const size_t hw = (size_t)H * W;
+    return align_up((size_t)B * 8 * ndil * hw * sizeof(float), 256) + align_up((size_t)B * Cmax * hw * sizeof(float), 256) +
+           align_up((size_t)B * 3 * hw * sizeof(float), 256);
+}
+
+extern "C" int excel_par_forward(const float* imgs, int h, int w, const float* masks, const int32_t* nchan, int B, int Cmax, int H,
+                                 int W, const int32_t* dilations, int ndil, int n_iter, float w1, float w2, float* out,
+                                 void* workspace, void* stream) {
+    EXCEL_CHECK_ARG(imgs && masks && out && workspace && dilations, "par_forward: null argument");
+    EXCEL_CHECK_ARG(n_iter >= 0 && ndil >= 1 && ndil <= 8, "par_forward: bad n_iter/ndil");
+    const size_t hw = (size_t)H * W;
+    char* base = (char*)workspace;
+    float* aff = (float*)base;
+    float* pp = (float*)(base + align_up((size_t)B * 8 * ndil * hw * sizeof(float), 256));
+    float* guide = (float*)((char*)pp + align_up((size_t)B * Cmax * hw * sizeof(float), 256));
+    hipStream_t st = ST(stream);
+    const float* gimg = imgs;
+    if (h != H || w != W) {   // F.interpolate(..., align_corners=True) (PAR.py:67)
+        TRY(excel_launch_bilinear_ac(imgs, guide, B * 3, h, w, H, W, st));
+        gimg = guide;
+    }
+    TRY(excel_launch_par_affinity(gimg, aff, B, H, W, dilations, ndil, w1, w2, st));
+    if (n_iter == 0) {
+        hipMemcpyAsync(out, masks, sizeof(float) * (size_t)B * Cmax * hw, hipMemcpyDeviceToDevice, st);
+        return EXCEL_OK;
+    }
+    // ping-pong so that the LAST step writes `out`: out, pp alternate backwards from the end
+    const float* cur = masks;
+    for (int it = 0; it < n_iter; ++it) {
+        float* dst = (((n_iter - 1 - it) & 1) == 0) ? out : pp;
+        TRY(excel_launch_par_iterate(aff, cur, dst, nchan, B, Cmax, H, W, dilations, ndil, st));
+        cur = dst;
+    }
+    return EXCEL_OK;
+}
+
+extern "C" int excel_argmax_label(const float* cams, const int32_t* nchan, const int32_t* cls_idx, int B, int Smax, int Cmax,
+                                  long long HW, uint8_t* labels_u8, int64_t* labels_i64, void* stream) {
+    EXCEL_CHECK_ARG(cams && (labels_u8 || labels_i64), "argmax_label: null argument");
+    return excel_launch_argmax_label(cams, nchan, cls_idx, B, Smax, Cmax, HW, labels_u8, (long long*)labels_i64, ST(stream));
+}
+
+extern "C" int excel_confusion_accumulate(const uint8_t* gt, const uint8_t* pred, long long n, int num_classes, int64_t* hist,
+                                          void* stream) {
+    EXCEL_CHECK_ARG(gt && pred && hist && n >= 0, "confusion_accumulate: null argument");
+    if (n == 0) return EXCEL_OK;
+    return excel_launch_confusion(gt, pred, n, num_classes, (unsigned long long*)hist, ST(stream));
+}
+
+// ------------------------------------------------------------------------------------ one-time / auxiliary
+extern "C" int excel_attr_aggregate(const float* text, const float* bank, int F, int T, int C, int K, double topK, float* out,
+                                    void* stream) {
+    EXCEL_CHECK_ARG(text && bank && out, "attr_aggregate: null argument");
+    const int drop = (int)((1.0 - topK) * (double)K);       // topk = int((1-topK) * K)  (load_attr.py:100)
+    return excel_launch_attr_aggregate(text, bank, F, T, C, K, drop, out, ST(stream));
+}
+
+extern "C" int excel_bilinear_resize(const float* in, float* out, long long planes, int h, int w, int H, int W, int align_corners,
+                                     void* stream) {
+    EXCEL_CHECK_ARG(in && out && planes > 0 && h > 0 && w > 0 && H > 0 && W > 0, "bilinear_resize: bad argument");
+    return excel_launch_bilinear_resize(in, out, planes, h, w, H, W, align_corners, ST(stream));
+}
+
+extern "C" int excel_pos_embed_resize(const float* pos, int side, int g, int D, float* out, void* stream) {
+    EXCEL_CHECK_ARG(pos && out && side > 0 && g > 0, "pos_embed_resize: bad argument");
+    hipLaunchKernelGGL(pos_resize_kernel, dim3((unsigned)cdivl((long long)(g * g + 1) * D, 256)), dim3(256), 0, ST(stream), pos, out, side, g, D);
+    EXCEL_CHECK_LAUNCH("pos_resize");
+    return EXCEL_OK;
+}
+
+extern "C" int excel_flip_max_normalize(const float* attr, float* out, int B, int g, int F, void* stream) {
+    EXCEL_CHECK_ARG(attr && out, "flip_max_normalize: null argument");
+    return excel_launch_flip_max_normalize(attr, out, B, g, F, ST(stream));
+}

@@ -1,0 +1,306 @@
+// Self-attention kernels of the ExCEL "surgery" ViT (clip/clip_surgery_model.py:95-159, :307), fp32 on the
+// f32-input matrix core so the softmaxes see exactly-fp32 scores.
+//
+// Data layout: the QKV GEMM writes q|k|v head-major, qkvh[B][3][H][N][64], so that a (b, type, head) matrix is
+// one contiguous [N,64] slab and every 32/64-row tile is a single contiguous 8/16 KB read.
+//
+// Two kernels, both computing TRANSPOSED score tiles  S^T[key][q] = Y[key,:] . X[q,:]  so that a query row lives
+// in ONE lane (q = lane & 31): row max / row sum are in-lane reductions plus one cross-half shuffle, and the
+// probabilities feed the P.V product straight from their accumulator registers (no LDS round trip):
+//
+//   attn_rowpass  one pass over the keys per (b, head, type):
+//                 type 0 (q.k): flash-style online softmax + O^T = V^T P^T  -> attention output, plus row stats
+//                 type 1..3 (q.q, k.k, v.v; surgery blocks only): row stats (max, 1/sum) only
+//   attn_accum    recomputes the score tiles with the final row stats and reduces over heads IN REGISTERS:
+//                 A_sum = sum_h (softmax(qq)+softmax(kk)+softmax(vv))/3      (:125,:146)   [surgery blocks]
+//                 W     = sum_h softmax(qk) (head-sum, :154) or head-mean (nn.MultiheadAttention, block 6)
+//                 and folds W[1:,1:]/6 into the layer-mean affinity the random walk consumes (utils/affutils.py:180,197).
+//   The N x N x heads x 4 probability tensors the reference materialises (118 MB/image/layer) never exist;
+//   the price is one extra score GEMM per type, deterministic (no atomics).
+#include "common.h"
+#include "excel_internal.h"
+
+#define HD 64
+#define KP 68   // LDS pitch (floats) of a [rows][64] operand tile read with ds_read_b128: slot = 17*row mod 16 -> conflict-free
+
+// ------------------------------------------------------------------------------------------------ rowpass
+struct RowpassArgs {
+    const float* qkvh;   // [B,3,H,N,64]
+    float* out;          // [B,N,H*64] attention output of type 0 (pre out-proj)
+    float2* stats;       // [B,H,4,N] {row max (scaled scores), 1/row sum}
+    int B, H, N;
+    float scale;
+};
+
+template <bool FLASH>
+__device__ __forceinline__ void rowpass_body(const RowpassArgs& p, float* smem, int b, int h, int type, int qblk) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, kh = lane >> 5;
+    const int N = p.N;
+    // type -> (row operand X, column operand Y) among q=0,k=1,v=2
+    const int tx = (type == 0 || type == 1) ? 0 : (type == 2 ? 1 : 2);
+    const int ty = (type == 0) ? 1 : tx;
+    const float* X = p.qkvh + (((long long)b * 3 + tx) * p.H + h) * (long long)N * HD;
+    const float* Y = p.qkvh + (((long long)b * 3 + ty) * p.H + h) * (long long)N * HD;
+    const float* V = p.qkvh + (((long long)b * 3 + 2) * p.H + h) * (long long)N * HD;
+
+    float* Ks = smem;                    // [2][32*KP]
+    float* Vs = smem + 2 * 32 * KP;      // [2][32*64]
+
+    const int q0 = qblk * 128 + wave * 32;
+    const int qrow = min(q0 + r, N - 1);
+    f32x4 xf[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) xf[c] = *reinterpret_cast<const f32x4*>(X + (long long)qrow * HD + c * 8 + kh * 4);
+
+    float m = -INFINITY, l = 0.f;
+    f32x16 oT[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { oT[0][e] = 0.f; oT[1][e] = 0.f; }
+
+    // staging map: a 32x64 tile = 512 float4, 2 per thread
+    f32x4 rk[2], rv[2];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = min(kt * 32 + (idx >> 4), N - 1), c4 = idx & 15;
+            rk[i] = *reinterpret_cast<const f32x4*>(Y + (long long)row * HD + c4 * 4);
+            if (FLASH) rv[i] = *reinterpret_cast<const f32x4*>(V + (long long)row * HD + c4 * 4);
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx >> 4, c4 = idx & 15;
+            *reinterpret_cast<f32x4*>(&Ks[buf * 32 * KP + row * KP + c4 * 4]) = rk[i];
+            if (FLASH) *reinterpret_cast<f32x4*>(&Vs[buf * 32 * 64 + row * 64 + c4 * 4]) = rv[i];
+        }
+    };
+
+    const int nkt = (N + 31) / 32;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) load_tile(kt + 1);
+        const float* ks = Ks + cur * 32 * KP;
+        f32x16 s;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const f32x4 yf = *reinterpret_cast<const f32x4*>(&ks[r * KP + c * 8 + kh * 4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(yf[e], xf[c][e], s, 0, 0, 0);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int key = kt * 32 + c32_row(e, lane);
+            s[e] = (key < N) ? s[e] * p.scale : -INFINITY;
+            mx = fmaxf(mx, s[e]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m, mx);
+        const float alpha = __expf(m - m_new);
+        float ps = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            s[e] = __expf(s[e] - m_new);
+            ps += s[e];
+        }
+        ps += __shfl_xor(ps, 32, 64);
+        l = l * alpha + ps;
+        m = m_new;
+        if (FLASH) {
+            const float* vs = Vs + cur * 32 * 64;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { oT[0][e] *= alpha; oT[1][e] *= alpha; }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int krow = c32_row(e, lane);
+                const float v0 = vs[krow * 64 + r];
+                const float v1 = vs[krow * 64 + 32 + r];
+                oT[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s[e], oT[0], 0, 0, 0);
+                oT[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s[e], oT[1], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nkt) store_tile(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    const float linv = 1.f / l;
+    if (kh == 0 && q0 + r < N)
+        p.stats[(((long long)b * p.H + h) * 4 + type) * N + q0 + r] = make_float2(m, linv);
+
+    if (FLASH) {
+        // O^T (d spread over registers, q per lane) -> LDS [q][d] (pitch 65) -> coalesced 256-B row stores
+        float* ob = smem + wave * (32 * 65);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) ob[r * 65 + dt * 32 + c32_row(e, lane)] = oT[dt][e] * linv;
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes landed (same-wave readback)
+        for (int qq = 0; qq < 32; ++qq) {
+            const int q = q0 + qq;
+            if (q >= N) break;
+            p.out[((long long)b * N + q) * (p.H * HD) + h * HD + lane] = ob[qq * 65 + lane];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_rowpass_kernel(RowpassArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * 32 * KP + 2 * 32 * 64];   // 33.8 KB
+    const int bh = blockIdx.y;
+    const int b = bh / p.H, h = bh % p.H;
+    const int type = blockIdx.z;
+    if (type == 0)
+        rowpass_body<true>(p, smem, b, h, 0, blockIdx.x);
+    else
+        rowpass_body<false>(p, smem, b, h, type, blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------ accum
+struct AccumArgs {
+    const float* qkvh;    // [B,3,H,N,64]
+    const float2* stats;  // [B,H,4,N]
+    float* a_sum;         // [B,N,NP]  (surgery only) head-sum of (qq+kk+vv softmaxes)/3, zero in columns [N,NP)
+    float* w_aff;         // [B,P,P]   running layer-mean of W[1:,1:]   (may be null)
+    float* attn_out;      // [B,N,N]   W of this layer (may be null)
+    int B, H, N, NP;
+    float scale;
+    float w_scale;        // 1/H for nn.MultiheadAttention blocks (head-mean), 1 for surgery blocks (head-sum)
+    float aff_scale;      // 1/attn_layers
+    int aff_init;         // 1: w_aff = ..., 0: w_aff += ...
+};
+
+template <bool SURGERY>
+__global__ __launch_bounds__(256, 1) void attn_accum_kernel(AccumArgs p) {
+    constexpr int NT = SURGERY ? 6 : 2;
+    __shared__ __attribute__((aligned(16))) float tiles[NT * 64 * KP];   // 104,448 B / 34,816 B
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, kh = lane >> 5;
+    const int wk = wave >> 1, wq = wave & 1;
+    const int kt = blockIdx.x, qt = blockIdx.y, b = blockIdx.z;
+    const int N = p.N;
+    const int q = qt * 64 + wq * 32 + r;
+    const int qc = min(q, N - 1);
+
+    f32x16 accW, accA;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { accW[e] = 0.f; accA[e] = 0.f; }
+
+    // tile slots: X (query-side rows qt*64..) = q,k,v -> 0,1,2 ; Y (key-side rows kt*64..) = q,k,v -> 3,4,5
+    // non-surgery: slot 0 = X q, slot 1 = Y k
+    for (int h = 0; h < p.H; ++h) {
+        __syncthreads();   // previous head's fragment reads done
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            int typ, row0;
+            if (SURGERY) { typ = t % 3; row0 = (t < 3) ? qt * 64 : kt * 64; }
+            else { typ = t; row0 = (t == 0) ? qt * 64 : kt * 64; }
+            const float* src = p.qkvh + (((long long)b * 3 + typ) * p.H + h) * (long long)N * HD;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = tid + 256 * i;
+                const int row = idx >> 4, c4 = idx & 15;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(src + (long long)min(row0 + row, N - 1) * HD + c4 * 4);
+                *reinterpret_cast<f32x4*>(&tiles[t * 64 * KP + row * KP + c4 * 4]) = v;
+            }
+        }
+        __syncthreads();
+
+        const float2* st = p.stats + ((long long)b * p.H + h) * 4 * N;
+        auto score = [&](int slotY, int slotX, int type, f32x16& acc) {
+            const float2 ml = st[(long long)type * N + qc];
+            const float* ys = tiles + slotY * 64 * KP + (wk * 32 + r) * KP + kh * 4;
+            const float* xs = tiles + slotX * 64 * KP + (wq * 32 + r) * KP + kh * 4;
+            f32x16 s;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const f32x4 yf = *reinterpret_cast<const f32x4*>(ys + c * 8);
+                const f32x4 xf = *reinterpret_cast<const f32x4*>(xs + c * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(yf[e], xf[e], s, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = kt * 64 + wk * 32 + c32_row(e, lane);
+                const float pr = __expf(s[e] * p.scale - ml.x) * ml.y;
+                acc[e] += (key < N) ? pr : 0.f;
+            }
+        };
+        if (SURGERY) {
+            score(4, 0, 0, accW);   // q.k
+            score(3, 0, 1, accA);   // q.q
+            score(4, 1, 2, accA);   // k.k
+            score(5, 2, 3, accA);   // v.v
+        } else {
+            score(1, 0, 0, accW);
+        }
+    }
+    __syncthreads();
+
+    // transpose each wave's [key][q] tile through LDS (pitch 33) and store rows of q with consecutive keys
+    float* tb = tiles + wave * (32 * 33);
+    const int qbase = qt * 64 + wq * 32, kbase = kt * 64 + wk * 32;
+    auto emit = [&](const f32x16& acc, int which) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tb[r * 33 + c32_row(e, lane)] = acc[e];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        for (int i = 0; i < 16; ++i) {
+            const int qq = 2 * i + kh;
+            const int qg = qbase + qq, kg = kbase + r;
+            const float v = tb[qq * 33 + r];
+            if (qg >= N) continue;
+            if (which == 0) {
+                if (kg < p.NP) p.a_sum[((long long)b * N + qg) * p.NP + kg] = v * (1.f / 3.f);
+            } else {
+                const float pw = v * p.w_scale;
+                if (p.attn_out && kg < N) p.attn_out[((long long)b * N + qg) * N + kg] = pw;
+                if (p.w_aff && qg >= 1 && kg >= 1 && kg < N) {
+                    const long long P = N - 1;
+                    float* dst = p.w_aff + ((long long)b * P + (qg - 1)) * P + (kg - 1);
+                    const float add = pw * p.aff_scale;
+                    *dst = p.aff_init ? add : (*dst + add);
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+    };
+    if (SURGERY) emit(accA, 0);
+    emit(accW, 1);
+}
+
+int excel_launch_attn_rowpass(const float* qkvh, float* out, float* stats, int B, int H, int N, int hd, float scale,
+                              int ntypes, hipStream_t st) {
+    ProfScope prof__(PROF_ATTN_ROWPASS, st);
+    EXCEL_CHECK_ARG(hd == HD, "attention: head_dim must be 64 (got %d)", hd);
+    EXCEL_CHECK_ARG(ntypes == 1 || ntypes == 4, "attention: ntypes must be 1 or 4");
+    RowpassArgs a{qkvh, out, reinterpret_cast<float2*>(stats), B, H, N, scale};
+    hipLaunchKernelGGL(attn_rowpass_kernel, dim3(cdiv(N, 128), B * H, ntypes), dim3(256), 0, st, a);
+    EXCEL_CHECK_LAUNCH("attn_rowpass");
+    return EXCEL_OK;
+}
+
+int excel_launch_attn_accum(const float* qkvh, const float* stats, float* a_sum, float* w_aff, float* attn_out, int B, int H,
+                            int N, int NP, int hd, float scale, int surgery, float w_scale, float aff_scale, int aff_init,
+                            hipStream_t st) {
+    ProfScope prof__(PROF_ATTN_ACCUM, st);
+    EXCEL_CHECK_ARG(hd == HD, "attention: head_dim must be 64 (got %d)", hd);
+    EXCEL_CHECK_ARG(!surgery || (a_sum && NP >= N && NP <= cdiv(N, 64) * 64), "attn_accum: bad a_sum/NP");
+    AccumArgs a{qkvh, reinterpret_cast<const float2*>(stats), a_sum, w_aff, attn_out, B, H, N, NP, scale, w_scale, aff_scale, aff_init};
+    dim3 grid(cdiv(N, 64), cdiv(N, 64), B);
+    if (surgery)
+        hipLaunchKernelGGL(attn_accum_kernel<true>, grid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL(attn_accum_kernel<false>, grid, dim3(256), 0, st, a);
+    EXCEL_CHECK_LAUNCH("attn_accum");
+    return EXCEL_OK;
+}

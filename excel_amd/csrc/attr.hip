@@ -1,0 +1,133 @@
+// One-time / auxiliary kernels around the hot path:
+//   attr_aggregate      TSE text-bank fusion (model/load_attr.py:86-119), once per process
+//   bilinear_resize     F.interpolate(mode='bilinear', align_corners=False|True): harness input resize
+//                       (tools/infer_lam.py:74) and multi-scale CAM resize (utils/camutils.py:41,54)
+//   flip_max_normalize  flip-TTA fuse of cure_attr_map_flip (utils/camutils.py:21-26)
+#include "common.h"
+#include "excel_internal.h"
+
+#define AA_KMAX 256
+// one workgroup per text row t: fg rows get the top-(K-drop) soft attention over the attribute bank added, every
+// row is L2-normalised and written as a COLUMN of out [C,T].
+__global__ __launch_bounds__(256) void attr_aggregate_kernel(const float* __restrict__ text, const float* __restrict__ bank,
+                                                             int F, int T, int C, int K, int drop, float* __restrict__ out) {
+    __shared__ float logit[AA_KMAX];
+    __shared__ float corr[AA_KMAX];
+    __shared__ float red[4];
+    extern __shared__ float agg[];   // [C]
+    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* trow = text + (long long)t * C;
+    auto block_sum = [&](float v) {
+        v = wave_sum(v);
+        __syncthreads();
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        return (red[0] + red[1]) + (red[2] + red[3]);
+    };
+    auto block_max = [&](float v) {
+        v = wave_max(v);
+        __syncthreads();
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    };
+    if (t < F) {
+        float lg = 0.f;
+        if (tid < K)
+            for (int c = 0; c < C; ++c) lg += trow[c] * bank[(long long)c * K + tid];       // fg @ bank (:101)
+        if (tid < K) logit[tid] = lg;
+        __syncthreads();
+        // descending rank (stable): dropped iff rank >= K - drop  (sort + corr[:, -topk:] = -inf + scatter, :102-110)
+        bool keep = false;
+        if (tid < K) {
+            int rank = 0;
+            for (int j = 0; j < K; ++j) rank += (logit[j] > lg) || (logit[j] == lg && j < tid);
+            keep = rank < K - drop;
+        }
+        const float m = block_max(keep ? lg : -INFINITY);
+        const float e = keep ? __expf(lg - m) : 0.f;
+        const float s = block_sum(e);
+        if (tid < K) corr[tid] = e / s;                                                        // softmax (:112)
+        __syncthreads();
+        for (int c = tid; c < C; c += 256) {
+            float a = 0.f;
+            for (int k = 0; k < K; ++k) a += corr[k] * bank[(long long)c * K + k];
+            agg[c] = a + trow[c];                                                               // corr @ bank^T + fg (:113)
+        }
+    } else {
+        for (int c = tid; c < C; c += 256) agg[c] = trow[c];
+    }
+    __syncthreads();
+    float q = 0.f;
+    for (int c = tid; c < C; c += 256) q += agg[c] * agg[c];
+    const float nrm = sqrtf(block_sum(q));
+    for (int c = tid; c < C; c += 256) out[(long long)c * T + t] = agg[c] / nrm;              // :118
+}
+
+__global__ __launch_bounds__(256) void bilinear_resize_kernel(const float* __restrict__ in, float* __restrict__ out, long long planes,
+                                                              int h, int w, int H, int W, int align_corners) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= planes * H * W) return;
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const long long pl = i / ((long long)W * H);
+    float fy, fx;
+    if (align_corners) {
+        fy = ((H > 1) ? (float)(h - 1) / (float)(H - 1) : 0.f) * (float)y;
+        fx = ((W > 1) ? (float)(w - 1) / (float)(W - 1) : 0.f) * (float)x;
+    } else {   // ATen area_pixel_compute_source_index: scale*(dst+0.5)-0.5 clamped at 0
+        fy = fmaxf(((float)h / (float)H) * ((float)y + 0.5f) - 0.5f, 0.f);
+        fx = fmaxf(((float)w / (float)W) * ((float)x + 0.5f) - 0.5f, 0.f);
+    }
+    const int y0 = min((int)fy, h - 1), x0 = min((int)fx, w - 1);
+    const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float* p = in + pl * h * w;
+    const float top = (1.f - lx) * p[y0 * w + x0] + lx * p[y0 * w + x1];
+    const float bot = (1.f - lx) * p[y1 * w + x0] + lx * p[y1 * w + x1];
+    out[i] = (1.f - ly) * top + ly * bot;
+}
+
+// attr [2B,P,F] (second half computed from horizontally flipped inputs) -> out [B,P,F]:
+//   lam = max(lam[:B], flip_x(lam[B:])) ; lam -= min_hw ; lam /= max_hw + 1e-5        (camutils.py:21-25)
+__global__ __launch_bounds__(256) void flip_max_normalize_kernel(const float* __restrict__ attr, float* __restrict__ out, int B,
+                                                                 int g, int F) {
+    __shared__ float smn[4], smx[4];
+    const int f = blockIdx.x, b = blockIdx.y, P = g * g;
+    float mn = INFINITY, mx = -INFINITY;
+    auto val = [&](int p) {
+        const int y = p / g, x = p % g;
+        const float a = attr[((long long)b * P + p) * F + f];
+        const float c = attr[((long long)(b + B) * P + y * g + (g - 1 - x)) * F + f];
+        return fmaxf(a, c);
+    };
+    for (int p = threadIdx.x; p < P; p += 256) { const float v = val(p); mn = fminf(mn, v); mx = fmaxf(mx, v); }
+    mn = wave_min(mn); mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+    mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+    const float den = (mx - mn) + 1e-5f;
+    for (int p = threadIdx.x; p < P; p += 256) out[((long long)b * P + p) * F + f] = (val(p) - mn) / den;
+}
+
+int excel_launch_attr_aggregate(const float* text, const float* bank, int F, int T, int C, int K, int drop, float* out,
+                                hipStream_t st) {
+    EXCEL_CHECK_ARG(K >= 1 && K <= AA_KMAX && drop >= 0 && drop < K && F <= T, "attr_aggregate: need K <= %d, 0 <= drop < K", AA_KMAX);
+    hipLaunchKernelGGL(attr_aggregate_kernel, dim3(T), dim3(256), C * sizeof(float), st, text, bank, F, T, C, K, drop, out);
+    EXCEL_CHECK_LAUNCH("attr_aggregate");
+    return EXCEL_OK;
+}
+
+int excel_launch_bilinear_resize(const float* in, float* out, long long planes, int h, int w, int H, int W, int align_corners,
+                                 hipStream_t st) {
+    const long long n = planes * H * W;
+    hipLaunchKernelGGL(bilinear_resize_kernel, dim3((unsigned)cdivl(n, 256)), dim3(256), 0, st, in, out, planes, h, w, H, W, align_corners);
+    EXCEL_CHECK_LAUNCH("bilinear_resize");
+    return EXCEL_OK;
+}
+
+int excel_launch_flip_max_normalize(const float* attr, float* out, int B, int g, int F, hipStream_t st) {
+    hipLaunchKernelGGL(flip_max_normalize_kernel, dim3(F, B), dim3(256), 0, st, attr, out, B, g, F);
+    EXCEL_CHECK_LAUNCH("flip_max_normalize");
+    return EXCEL_OK;
+}

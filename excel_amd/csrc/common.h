@@ -1,0 +1,82 @@
+// Shared device/host helpers for libexcel_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define EXCEL_OK 0
+#define EXCEL_ERR_ARG (-1)
+#define EXCEL_ERR_LAUNCH (-2)
+#define EXCEL_ERR_ALLOC (-3)
+
+void excel_set_error(const char* fmt, ...);
+
+#define EXCEL_CHECK_ARG(cond, ...)                         \
+    do {                                                   \
+        if (!(cond)) {                                     \
+            excel_set_error(__VA_ARGS__);                  \
+            return EXCEL_ERR_ARG;                          \
+        }                                                  \
+    } while (0)
+
+#define EXCEL_CHECK_LAUNCH(name)                                                   \
+    do {                                                                           \
+        hipError_t e__ = hipGetLastError();                                        \
+        if (e__ != hipSuccess) {                                                   \
+            excel_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return EXCEL_ERR_LAUNCH;                                               \
+        }                                                                          \
+    } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline long long cdivl(long long a, long long b) { return (a + b - 1) / b; }
+
+#define WAVE 64
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// C/D fragment row of a 32x32 MFMA accumulator register (guide: cdna_hip_programming.md §3)
+__device__ __forceinline__ int c32_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// Bijective XCD-aware remap of a linear workgroup id: the hardware places id b on XCD b % 8;
+// give every XCD a contiguous chunk of the logical tile order so neighbouring tiles share an L2.
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+    const int q = n >> 3, r = n & 7;
+    const int xcd = id & 7, loc = id >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + loc;
+}
+
+// ---------------------------------------------------------------- optional per-category HIP-event profiling
+// (bench.py enables it to get live per-kernel durations on the launch stream; off by default: zero overhead)
+enum ExcelProfCat {
+    PROF_GEMM_NT = 0, PROF_GEMM_NN, PROF_ATTN_ROWPASS, PROF_ATTN_ACCUM, PROF_LAYERNORM, PROF_EMBED, PROF_TOKEN_NORM,
+    PROF_CAM_EPILOGUE, PROF_SINKHORN, PROF_BBOX, PROF_MATVEC, PROF_UPSAMPLE, PROF_PAR_AFFINITY, PROF_PAR_ITERATE,
+    PROF_ARGMAX, PROF_CONFUSION, PROF_OTHER, PROF_NCAT
+};
+extern bool g_excel_prof_on;
+void excel_prof_begin(int cat, hipStream_t st, double work);
+void excel_prof_end(int cat, hipStream_t st);
+struct ProfScope {
+    int cat; hipStream_t st; bool on;
+    ProfScope(int c, hipStream_t s, double work = 0.0) : cat(c), st(s), on(g_excel_prof_on) { if (on) excel_prof_begin(cat, st, work); }
+    ~ProfScope() { if (on) excel_prof_end(cat, st); }
+};

@@ -1,0 +1,63 @@
+// Internal (C++) launch interfaces shared between the .hip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+enum { GEMM_ACT_NONE = 0, GEMM_ACT_QUICKGELU = 1 };
+enum { GEMM_OUT_PLAIN = 0, GEMM_OUT_QKV_HEADMAJOR = 1 };
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;   // [N] or null
+    const float* res;    // [M,ldr] or null (may alias C: x += ...)
+    int M, N, K;         // K = true reduction length (rows of B guarded by it in NN mode)
+    int Kld;             // K rounded up to a multiple of 4 that A (and B in NT mode) can be read to;
+                         // the operands must hold zeros (or finite*0-safe data with the other side zero) there
+    int lda, ldb, ldc, ldr;
+    long long sA, sB, sC, sR, sBias;   // batch strides in elements, applied to z / zdiv
+    int zdiv;                          // blockIdx.z = z1*zdiv + z2 (zdiv >= 1)
+    long long sA2, sB2, sC2;           // strides applied to z % zdiv
+    int act;
+    int out_mode;
+    int tokN, heads, hd;  // GEMM_OUT_QKV_HEADMAJOR: C is [B,3,heads,tokN,hd]
+    float alpha;
+};
+
+int excel_launch_gemm(const GemmArgs& p, bool b_kmajor, int batch, hipStream_t stream);
+
+int excel_launch_layernorm(const float* x, const float* cls_src, int tokN, const float* w, const float* b, float* y,
+                           int rows, int D, float eps, hipStream_t st);
+int excel_launch_assemble_ln_pre(const float* patch, const float* cls_emb, const float* pos, const float* w, const float* b,
+                                 float* x, int B, int tokN, int D, float eps, hipStream_t st);
+int excel_launch_token_axis_normalize(const float* f, float* ss, float* out, int B, int tokN, int C, hipStream_t st);
+int excel_launch_im2col(const float* img, float* col, int B, int S, int ps, hipStream_t st);
+
+int excel_launch_attn_rowpass(const float* qkvh, float* out, float* stats, int B, int H, int N, int hd, float scale,
+                              int ntypes, hipStream_t st);
+int excel_launch_attn_accum(const float* qkvh, const float* stats, float* a_sum, float* w_aff, float* attn_out, int B, int H,
+                            int N, int NP, int hd, float scale, int surgery, float w_scale, float aff_scale, int aff_init,
+                            hipStream_t st);
+int excel_launch_cam_epilogue(float* S, float* out_full, float* out_slice, int B, int N, int T, int ldS, int F, float temp,
+                              hipStream_t st);
+int excel_launch_trans_mat_sym(const float* W, float* T, float* Tsym, float* cs, int B, int P, hipStream_t st);
+int excel_launch_cls_compact(const float* onehot, int B, int F, int Smax, int* cls_idx, int* ncls, int* nchan, hipStream_t st);
+int excel_launch_bbox_mask(const float* attr, const int* cls_idx, const int* ncls, int B, int g, int F, int Smax, double thre,
+                           float* v_out, unsigned char* mask_out, hipStream_t st);
+int excel_launch_matvec(const float* T, const float* v, const int* ncls, float* u, int B, int P, int Smax, hipStream_t st);
+int excel_launch_cam_upsample_bkg(const float* r, const int* ncls, float* rn, float* cams, int B, int g, int Smax, int H, int W,
+                                  hipStream_t st);
+int excel_launch_par_affinity(const float* img, float* aff, int B, int H, int W, const int* dil, int ndil, float w1, float w2,
+                              hipStream_t st);
+int excel_launch_par_iterate(const float* aff, const float* in, float* out, const int* nchan, int B, int Cmax, int H, int W,
+                             const int* dil, int ndil, hipStream_t st);
+int excel_launch_bilinear_ac(const float* in, float* out, int planes, int h, int w, int H, int W, hipStream_t st);
+int excel_launch_argmax_label(const float* cams, const int* nchan, const int* cls_idx, int B, int Smax, int Cmax, long long HW,
+                              unsigned char* lab8, long long* lab64, hipStream_t st);
+int excel_launch_confusion(const unsigned char* gt, const unsigned char* pred, long long n, int nc, unsigned long long* hist,
+                           hipStream_t st);
+int excel_launch_attr_aggregate(const float* text, const float* bank, int F, int T, int C, int K, int drop, float* out,
+                                hipStream_t st);
+int excel_launch_bilinear_resize(const float* in, float* out, long long planes, int h, int w, int H, int W, int align_corners,
+                                 hipStream_t st);
+int excel_launch_flip_max_normalize(const float* attr, float* out, int B, int g, int F, hipStream_t st);

@@ -1,0 +1,60 @@
+"""ExCEL_model: the drop-in boundary of the hot path (mirror of model/model_excel.py:16-78).
+
+Constructor signature and forward contract follow the reference; the learned decoder head
+(SegFormerHead + DecoderTransformer, :28-30, :61-76) is SURVEY 8(f) "next": in training-free mode its outputs
+are ignored by the caller (tools/infer_lam.py:79,92), so `seg`, `attn_fts` and `attn_pred` are returned as None.
+"""
+import torch
+
+from .. import clip, ops
+from .load_attr import attr_aggregate
+
+
+class ExCEL_model:
+    def __init__(self, clip_model=None, embedding_dim=256, in_channels=512, dataset_name="pascal_voc",
+                 num_classes=21, num_atrr_clusters=112, json_file=None, img_size=320, mode="train", device="cuda",
+                 state_dict=None, text_features=None, attr_bank=None, vit_cfg=None, text_attr=None):
+        """Extra keyword arguments (no network here): `state_dict` = CLIP visual weights, `text_features` [T,512] =
+        output of encode_text_with_prompt_ensemble (clip/clip.py:252-269, one-time, out of scope),
+        `attr_bank` [512,K] overrides the bank file, `vit_cfg` overrides the ViT-B/16 shape."""
+        self.num_classes = num_classes
+        self.embedding_dim = embedding_dim
+        self.in_channels = in_channels
+        self.device = device
+        cfg = dict(width=768, layers=12, heads=12, patch=16, output_dim=512, input_resolution=224)
+        cfg.update(vit_cfg or {})
+        self.encoder, _ = clip.load(clip_model, device=device, state_dict=state_dict, **cfg)          # :25
+        self.encoder.visual.reload_self_attn(layers=6, feat_size=img_size // cfg["patch"], mode=mode)   # :26
+        if text_attr is not None:          # a pre-aggregated [C,T] bank (tests / cached banks)
+            self.integral_text_features, self.attr_flag = None, None
+            self.text_attr = torch.as_tensor(text_attr).float().to(device)
+        else:
+            if text_features is None:
+                raise RuntimeError("ExCEL_model needs text_features= (the CLIP text tower is a one-time step outside the hot path)")
+            self.integral_text_features = torch.as_tensor(text_features).float().to(device)
+            self.text_attr, self.attr_flag = attr_aggregate(self.integral_text_features, dataset_name, num_classes - 1,
+                                                            num_atrr_clusters, json_file, bank=attr_bank, device=device)   # :34
+        self._text_rows = self.text_attr.permute(1, 0).contiguous()     # [T,C] view the CAM kernel consumes (:58)
+
+    def eval(self):
+        return self
+
+    def train(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def forward(self, img, ex_feats=None, n_attn_out=0, want_feats=False):
+        """model(img) -> (seg, attn_fts, attr_maps_raw [B,P,F], attn_weights, attn_pred)      (:48-78)"""
+        if ex_feats is not None:
+            raise NotImplementedError("ex_feats / LVC path (model_excel.py:50-53) is SURVEY 8(f) 'next'")
+        image_features, attn_weights, all_feats = clip.generate_clip_fts(img, self.encoder, return_weights=True,
+                                                                         n_attn_out=n_attn_out, want_feats=want_feats)   # :57
+        _, attr_maps_raw = ops.clip_feature_surgery(image_features, self._text_rows, num_fg=self.num_classes - 1,
+                                                    want_full=False)                                                    # :58
+        self.last_image_features = image_features
+        self.last_all_feats = all_feats
+        return None, None, attr_maps_raw, attn_weights, None
+
+    __call__ = forward

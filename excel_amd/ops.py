@@ -1,0 +1,331 @@
+"""torch.Tensor-facing wrappers of the C ABI (device memory + stream plumbing only).
+
+Every function here hands raw device pointers of CUDA(=HIP) tensors to
+libexcel_hip; nothing is computed with torch ops.  Tensors must be fp32,
+contiguous and on the GPU; outputs are fresh tensors.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, lib
+
+PAR_DILATIONS = (1, 2, 4, 8, 12, 24)
+
+
+def _p(t, dtype=torch.float32):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("excel_amd ops need GPU tensors (the HIP library is the only compute path)")
+    if t.dtype != dtype:
+        raise TypeError(f"expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def f32c(t):
+    return t.to(dtype=torch.float32).contiguous()
+
+
+# ------------------------------------------------------------------ building blocks
+def gemm(A, Bm, bias=None, residual=None, act=0, b_kmajor=True):
+    """C = act(A @ op(B) + bias) + residual.  A [M,K] (or [batch,M,K]); B [N,K] if b_kmajor else [K,N]."""
+    batched = A.dim() == 3
+    A3 = A if batched else A[None]
+    B3 = Bm if Bm.dim() == 3 else Bm[None]
+    batch, M, K = A3.shape
+    N = B3.shape[1] if b_kmajor else B3.shape[2]
+    out = torch.empty((batch, M, N), dtype=torch.float32, device=A.device)
+    sB = 0 if B3.shape[0] == 1 else B3.stride(0)
+    check(lib().excel_gemm_f32(_p(A3), _p(B3), _p(out), _p(bias), _p(residual), M, N, K, A3.stride(1), B3.stride(1), N,
+                               N, 1 if b_kmajor else 0, act, batch, A3.stride(0), sB, M * N, M * N, _stream()), "excel_gemm_f32")
+    return out if batched else out[0]
+
+
+def layernorm(x, w, b, eps=1e-5):
+    D = x.shape[-1]
+    y = torch.empty_like(x)
+    check(lib().excel_layernorm(_p(x), _p(w), _p(b), _p(y), x.numel() // D, D, eps, _stream()), "excel_layernorm")
+    return y
+
+
+# ------------------------------------------------------------------ ViT
+class VitHandle:
+    """Owns device copies of the ViT weights (state_dict naming of the reference's VisionTransformer,
+    clip/clip_surgery_model.py:374-394) and the C handle bound to them."""
+
+    def __init__(self, state_dict, width, layers, heads, patch, out_dim, n_surgery=5, device="cuda", prefix=""):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("excel_amd.VitHandle needs a GPU device: the HIP library is the only compute path")
+        g = lambda k: f32c(torch.as_tensor(state_dict[prefix + k])).to(self.device)
+        self.cfg = dict(width=width, layers=layers, heads=heads, patch=patch, out_dim=out_dim, n_surgery=n_surgery)
+        self.t = {}
+        top = {"conv1_w": "conv1.weight", "class_emb": "class_embedding", "pos_emb": "positional_embedding",
+               "ln_pre_w": "ln_pre.weight", "ln_pre_b": "ln_pre.bias", "ln_post_w": "ln_post.weight",
+               "ln_post_b": "ln_post.bias", "proj": "proj"}
+        for f, k in top.items():
+            self.t[f] = g(k)
+        pos_rows = self.t["pos_emb"].shape[0]
+        pos_grid = int(round((pos_rows - 1) ** 0.5))
+        assert pos_grid * pos_grid + 1 == pos_rows
+        self.blocks = (_lib.VitBlockWeights * layers)()
+        for i in range(layers):
+            p = f"transformer.resblocks.{i}."
+            # surgery blocks of a reloaded reference model carry attn.qkv/attn.proj instead of in_proj/out_proj (:401-404)
+            def pick(*names):
+                for n in names:
+                    if prefix + p + n in state_dict:
+                        return g(p + n)
+                raise KeyError(p + names[0])
+            fields = {
+                "ln1_w": pick("ln_1.weight"), "ln1_b": pick("ln_1.bias"),
+                "in_proj_w": pick("attn.in_proj_weight", "attn.qkv.weight"),
+                "in_proj_b": pick("attn.in_proj_bias", "attn.qkv.bias"),
+                "out_proj_w": pick("attn.out_proj.weight", "attn.proj.weight"),
+                "out_proj_b": pick("attn.out_proj.bias", "attn.proj.bias"),
+                "ln2_w": pick("ln_2.weight"), "ln2_b": pick("ln_2.bias"),
+                "fc1_w": pick("mlp.c_fc.weight"), "fc1_b": pick("mlp.c_fc.bias"),
+                "fc2_w": pick("mlp.c_proj.weight"), "fc2_b": pick("mlp.c_proj.bias"),
+            }
+            for f, t in fields.items():
+                self.t[f"{i}.{f}"] = t
+                setattr(self.blocks[i], f, t.data_ptr())
+        w = _lib.VitWeights()
+        for f in top:
+            setattr(w, f, self.t[f].data_ptr())
+        w.blocks = self.blocks
+        cfg = _lib.VitConfig(width, layers, heads, patch, out_dim, n_surgery, pos_grid)
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib().excel_vit_create(C.byref(cfg), C.byref(w), C.byref(self._h)), "excel_vit_create")
+        self._ws = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().excel_vit_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def workspace(self, B, S):
+        need = lib().excel_vit_workspace_bytes(self._h, B, S)
+        if need == 0:
+            raise ValueError(f"bad ViT input shape B={B} S={S}")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws, need
+
+    def forward(self, imgs, want_w_aff=True, aff_layers=6, n_attn_out=0, want_feats=False, want_raw=False):
+        """-> dict(image_features [B,N,C], w_aff [B,P,P]|None, attn [n,B,N,N]|None, feats [L,B,N,D]|None, x_raw|None)"""
+        imgs = f32c(imgs)
+        B, _, S, S2 = imgs.shape
+        assert S == S2
+        c = self.cfg
+        g = S // c["patch"]
+        N = g * g + 1
+        dev = imgs.device
+        f = torch.empty((B, N, c["out_dim"]), dtype=torch.float32, device=dev)
+        raw = torch.empty_like(f) if want_raw else None
+        w_aff = torch.empty((B, N - 1, N - 1), dtype=torch.float32, device=dev) if want_w_aff else None
+        attn = torch.empty((n_attn_out, B, N, N), dtype=torch.float32, device=dev) if n_attn_out else None
+        feats = torch.empty((c["layers"], B, N, c["width"]), dtype=torch.float32, device=dev) if want_feats else None
+        ws, need = self.workspace(B, S)
+        check(lib().excel_vit_forward(self._h, _p(imgs), B, S, _p(ws, torch.uint8), need, _p(f), _p(raw), _p(w_aff),
+                                      aff_layers, _p(attn), n_attn_out, _p(feats), _stream()), "excel_vit_forward")
+        return dict(image_features=f, w_aff=w_aff, attn=attn, feats=feats, x_raw=raw)
+
+
+# ------------------------------------------------------------------ CAM
+def clip_feature_surgery(image_features, text_features, num_fg=None, t=2.0, want_full=True):
+    """image_features [B,N,C], text_features [T,C] -> (full [B,N,T] | None, slice [B,N-1,F] | None)."""
+    image_features = f32c(image_features)
+    text_features = f32c(text_features)
+    B, N, Cc = image_features.shape
+    T = text_features.shape[0]
+    dev = image_features.device
+    full = torch.empty((B, N, T), dtype=torch.float32, device=dev) if want_full else None
+    F_ = T if num_fg is None else num_fg
+    sl = torch.empty((B, N - 1, F_), dtype=torch.float32, device=dev) if num_fg is not None else None
+    ws = _ws(lib().excel_cam_workspace_bytes(B, N, T), dev)
+    check(lib().excel_clip_feature_surgery(_p(image_features), _p(text_features), B, N, Cc, T, F_, float(t), _p(full), _p(sl),
+                                           _p(ws, torch.uint8), _stream()), "excel_clip_feature_surgery")
+    return full, sl
+
+
+# ------------------------------------------------------------------ affinity random walk
+def attn_layer_mean(attn, n_layers=6):
+    """attn [Lw,B,N,N] -> mean of the last n_layers of attn[:, :, 1:, 1:]  -> [B,P,P]"""
+    attn = f32c(attn)
+    Lw, B, N, _ = attn.shape
+    n = min(n_layers, Lw)
+    out = torch.empty((B, N - 1, N - 1), dtype=torch.float32, device=attn.device)
+    check(lib().excel_attn_layer_mean(_p(attn), Lw, B, N, Lw - n, n, _p(out), _stream()), "excel_attn_layer_mean")
+    return out
+
+
+def compute_trans_mat(w_aff):
+    """[B,P,P] (or [P,P]) -> trans_mat, same shape (utils/affutils.py:8-24)."""
+    single = w_aff.dim() == 2
+    w = f32c(w_aff[None] if single else w_aff)
+    B, P, _ = w.shape
+    out = torch.empty_like(w)
+    ws = _ws(lib().excel_trans_mat_workspace_bytes(B, P), w.device)
+    check(lib().excel_compute_trans_mat(_p(w), B, P, _p(out), _p(ws, torch.uint8), _stream()), "excel_compute_trans_mat")
+    return out[0] if single else out
+
+
+def cls_compact(onehot, smax, want_nchan=False):
+    """one-hot [B,F] -> (cls_idx [B,smax] int32, ncls [B] int32[, nchan = ncls+1])."""
+    onehot = f32c(onehot)
+    B, F_ = onehot.shape
+    idx = torch.empty((B, smax), dtype=torch.int32, device=onehot.device)
+    n = torch.empty((B,), dtype=torch.int32, device=onehot.device)
+    nch = torch.empty((B,), dtype=torch.int32, device=onehot.device) if want_nchan else None
+    check(lib().excel_cls_compact(_p(onehot), B, F_, smax, _p(idx, torch.int32), _p(n, torch.int32), _p(nch, torch.int32),
+                                  _stream()), "excel_cls_compact")
+    return (idx, n, nch) if want_nchan else (idx, n)
+
+
+def scoremap_box_mask(attr, cls_idx, ncls, g, caa_thre=0.79, want_mask=False):
+    attr = f32c(attr)
+    B, P, F_ = attr.shape
+    smax = cls_idx.shape[1]
+    v = torch.zeros((B, smax, P), dtype=torch.float32, device=attr.device)
+    m = torch.zeros((B, smax, P), dtype=torch.uint8, device=attr.device) if want_mask else None
+    check(lib().excel_scoremap_box_mask(_p(attr), _p(cls_idx, torch.int32), _p(ncls, torch.int32), B, g, F_, smax, float(caa_thre),
+                                        _p(v), _p(m, torch.uint8), _stream()), "excel_scoremap_box_mask")
+    return v, m
+
+
+def refine_cams_with_aff_batched(attr, w_aff, cls_idx, ncls, g, caa_thre=0.79):
+    """attr [B,P,F], w_aff [B,P,P] -> refined [B,Smax,P] (rows >= ncls[b] are zero)."""
+    attr = f32c(attr)
+    w_aff = f32c(w_aff)
+    B, P, F_ = attr.shape
+    smax = cls_idx.shape[1]
+    out = torch.zeros((B, smax, P), dtype=torch.float32, device=attr.device)
+    ws = _ws(lib().excel_refine_workspace_bytes(B, P, smax), attr.device)
+    check(lib().excel_refine_cams_with_aff(_p(attr), _p(w_aff), _p(cls_idx, torch.int32), _p(ncls, torch.int32), B, g, F_, smax,
+                                           float(caa_thre), _p(out), _p(ws, torch.uint8), _stream()), "excel_refine_cams_with_aff")
+    return out
+
+
+def cam_upsample_bkg(refined, ncls, g, H, W):
+    """refined [B,Smax,P] -> cams [B,Smax+1,H,W] (channel 0 background; channels > ncls[b] are zero)."""
+    refined = f32c(refined)
+    B, smax, P = refined.shape
+    cams = torch.zeros((B, smax + 1, H, W), dtype=torch.float32, device=refined.device)
+    ws = _ws(B * smax * P * 4, refined.device)
+    check(lib().excel_cam_upsample_bkg(_p(refined), _p(ncls, torch.int32), B, g, smax, H, W, _p(cams), _p(ws, torch.uint8),
+                                       _stream()), "excel_cam_upsample_bkg")
+    return cams
+
+
+# ------------------------------------------------------------------ PAR / labels / metric
+def par_forward(imgs, masks, dilations=PAR_DILATIONS, num_iter=20, nchan=None, w1=0.3, w2=0.01):
+    imgs = f32c(imgs)
+    masks = f32c(masks)
+    B, Cmax, H, W = masks.shape
+    assert imgs.shape[0] == B and imgs.shape[1] == 3
+    h, w = imgs.shape[-2:]
+    out = torch.zeros_like(masks)
+    dil = (C.c_int32 * len(dilations))(*dilations)
+    ws = _ws(lib().excel_par_workspace_bytes(B, Cmax, H, W, len(dilations)), masks.device)
+    check(lib().excel_par_forward(_p(imgs), h, w, _p(masks), _p(nchan, torch.int32), B, Cmax, H, W, dil, len(dilations), num_iter,
+                                  w1, w2, _p(out), _p(ws, torch.uint8), _stream()), "excel_par_forward")
+    return out
+
+
+def argmax_label(cams, nchan=None, cls_idx=None, want_i64=False):
+    """cams [B,Cmax,H,W] -> labels u8 [B,H,W] (and int64 copy if asked), valid_key lookup applied."""
+    cams = f32c(cams)
+    B, Cmax, H, W = cams.shape
+    smax = cls_idx.shape[1] if cls_idx is not None else Cmax - 1
+    l8 = torch.empty((B, H, W), dtype=torch.uint8, device=cams.device)
+    l64 = torch.empty((B, H, W), dtype=torch.int64, device=cams.device) if want_i64 else None
+    check(lib().excel_argmax_label(_p(cams), _p(nchan, torch.int32), _p(cls_idx, torch.int32), B, smax, Cmax, H * W,
+                                   _p(l8, torch.uint8), _p(l64, torch.int64), _stream()), "excel_argmax_label")
+    return (l8, l64) if want_i64 else l8
+
+
+def confusion_accumulate(gt_u8, pred_u8, num_classes, hist=None):
+    """hist (int64 [nc,nc], device) += bincount(nc*gt + pred) over gt < nc."""
+    gt = gt_u8.contiguous().view(-1)
+    pr = pred_u8.contiguous().view(-1)
+    assert gt.numel() == pr.numel()
+    if hist is None:
+        hist = torch.zeros((num_classes, num_classes), dtype=torch.int64, device=gt.device)
+    check(lib().excel_confusion_accumulate(_p(gt, torch.uint8), _p(pr, torch.uint8), gt.numel(), num_classes,
+                                           _p(hist, torch.int64), _stream()), "excel_confusion_accumulate")
+    return hist
+
+
+# ------------------------------------------------------------------ one-time / auxiliary
+def attr_aggregate(text_features, bank, num_fg, topK=0.9):
+    """text [T,C], bank [C,K] -> text_attr [C,T] (model/load_attr.py:86-119)."""
+    text_features = f32c(text_features)
+    bank = f32c(bank)
+    T, Cc = text_features.shape
+    K = bank.shape[1]
+    out = torch.empty((Cc, T), dtype=torch.float32, device=text_features.device)
+    check(lib().excel_attr_aggregate(_p(text_features), _p(bank), num_fg, T, Cc, K, float(topK), _p(out), _stream()),
+          "excel_attr_aggregate")
+    return out
+
+
+def bilinear_resize(x, H, W, align_corners=False):
+    """x [..., h, w] -> [..., H, W]  (F.interpolate mode='bilinear')."""
+    x = f32c(x)
+    h, w = x.shape[-2:]
+    planes = x.numel() // (h * w)
+    out = torch.empty(x.shape[:-2] + (H, W), dtype=torch.float32, device=x.device)
+    check(lib().excel_bilinear_resize(_p(x), _p(out), planes, h, w, H, W, 1 if align_corners else 0, _stream()),
+          "excel_bilinear_resize")
+    return out
+
+
+def pos_embed_resize(pos, g):
+    pos = f32c(pos)
+    side = int(round((pos.shape[0] - 1) ** 0.5))
+    D = pos.shape[1]
+    out = torch.empty((g * g + 1, D), dtype=torch.float32, device=pos.device)
+    check(lib().excel_pos_embed_resize(_p(pos), side, g, D, _p(out), _stream()), "excel_pos_embed_resize")
+    return out
+
+
+def flip_max_normalize(attr, g):
+    """attr [2B,P,F] (second half from flipped inputs) -> [B,P,F] (utils/camutils.py:21-26)."""
+    attr = f32c(attr)
+    B2, P, F_ = attr.shape
+    out = torch.empty((B2 // 2, P, F_), dtype=torch.float32, device=attr.device)
+    check(lib().excel_flip_max_normalize(_p(attr), _p(out), B2 // 2, g, F_, _stream()), "excel_flip_max_normalize")
+    return out
+
+
+# ------------------------------------------------------------------ live kernel timing (HIP events on the launch stream)
+def prof_enable(on=True):
+    check(lib().excel_prof_enable(1 if on else 0), "excel_prof_enable")
+
+
+def prof_collect():
+    """-> {category: dict(ms=summed elapsed, launches=count, work=algorithmic FLOPs or 0)} and clears the log."""
+    n = lib().excel_prof_num_categories()
+    ms = (C.c_double * n)()
+    cnt = (C.c_longlong * n)()
+    work = (C.c_double * n)()
+    check(lib().excel_prof_collect(ms, cnt, work), "excel_prof_collect")
+    return {lib().excel_prof_category_name(i).decode(): dict(ms=ms[i], launches=cnt[i], work=work[i]) for i in range(n)}

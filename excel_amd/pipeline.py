@@ -1,0 +1,46 @@
+"""Batched, fully device-resident training-free pipeline over the same HIP kernels the per-image API uses.
+
+One `run_batch` = tools/infer_lam.py:74-114 for B images at once:
+    ViT surgery forward (+ fused affinity mean) -> patch-text CAM -> box-masked attention random walk
+    -> min-max + cv2-style up-sampling + background -> PAR x20 -> arg-max -> confusion accumulate.
+No host round trip happens inside a step (the reference makes ~2k+5 per image).
+"""
+import torch
+
+from . import ops
+
+
+class TrainingFreePipeline:
+    def __init__(self, model, num_classes=21, dilations=ops.PAR_DILATIONS, num_iter=20, caa_thre=0.79, smax=6):
+        """`smax` = the largest number of present classes of any image that will be fed (known from the host-side
+        image-level labels; VOC train_aug: 6)."""
+        self.model = model
+        self.num_classes = num_classes
+        self.dilations = tuple(dilations)
+        self.num_iter = num_iter
+        self.caa_thre = caa_thre
+        self.smax = smax
+        self.hist = None
+
+    def reset(self):
+        self.hist = None
+
+    @torch.no_grad()
+    def run_batch(self, inputs, cls_labels, gts=None, label_hw=None, return_intermediates=False):
+        """inputs [B,3,S,S] f32 (normalised, already at the network size), cls_labels [B,F] f32 one-hot,
+        gts [B,H,W] uint8 (255 = ignore) or None.  Returns labels [B,H,W] uint8 (device)."""
+        B, _, S, _ = inputs.shape
+        g = S // 16
+        H, W = (gts.shape[-2:] if gts is not None else (label_hw or (S, S)))
+        _, _, attr, attn_w, _ = self.model(inputs)                                                  # infer_lam.py:79
+        idx, ncls, nchan = ops.cls_compact(cls_labels, self.smax, want_nchan=True)                  # affutils.py:203
+        refined = ops.refine_cams_with_aff_batched(attr, attn_w.w_aff, idx, ncls, g, self.caa_thre)  # infer_lam.py:93
+        cams = ops.cam_upsample_bkg(refined, ncls, g, H, W)                                         # affutils.py:164-166
+        par_out = ops.par_forward(inputs, cams, self.dilations, self.num_iter, nchan=nchan)        # affutils.py:84
+        labels = ops.argmax_label(par_out, nchan, idx)                                              # affutils.py:86-87
+        if gts is not None:
+            self.hist = ops.confusion_accumulate(gts, labels, self.num_classes, self.hist)          # evaluate.py:9-20
+        if return_intermediates:
+            return labels, dict(attr=attr, w_aff=attn_w.w_aff, refined=refined, cams=cams, par_out=par_out,
+                                cls_idx=idx, ncls=ncls)
+        return labels

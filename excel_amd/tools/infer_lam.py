@@ -1,0 +1,159 @@
+"""Training-free LAM evaluation harness - mirror of tools/infer_lam.py (build_validation :63-128, validate :130-176).
+
+Differences from the reference, all deliberate:
+  * batches of B > 1 images run through the device-resident TrainingFreePipeline (the reference is batch 1 with
+    per-class host round trips); `--api_path` runs the reference's per-image call sequence instead;
+  * ranks take images r, r+R, ... exactly like :166, accumulate a device-side [nc,nc] int64 confusion matrix and
+    exchange it ONCE with an all_gather over RCCL (the reference scores each shard separately and never aggregates);
+  * `--synthetic N` feeds seeded synthetic samples (no VOC / CLIP checkpoint offline); `--model_path` is optional
+    when `--training_free` (the reference loads and then ignores it, :150-152).
+Launch: python -m torch.distributed.run --nproc-per-node R -m excel_amd.tools.infer_lam --synthetic 64 ...
+"""
+import argparse
+import logging
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+VOC_CLASSES = ["_background_", "aeroplane", "bicycle", "bird", "boat", "bottle", "bus", "car", "cat", "chair", "cow",
+               "diningtable", "dog", "horse", "motorbike", "person", "pottedplant", "sheep", "sofa", "train", "tvmonitor"]
+
+
+def _bool(x):
+    return x.lower() in ["true", "1", "yes"]
+
+
+def get_parser():
+    p = argparse.ArgumentParser()
+    # flags kept from the reference (tools/infer_lam.py:30-60)
+    p.add_argument("--model_path", default=None, type=str)
+    p.add_argument("--model", default="ExCEL_ViT-B/16", type=str)
+    p.add_argument("--dataset_name", default="pascal_voc", type=str)
+    p.add_argument("--attr_json", default=None, type=str)
+    p.add_argument("--num_attri", default=112, type=int)
+    p.add_argument("--embedding_dim", default=256, type=int)
+    p.add_argument("--in_channels", default=768, type=int)
+    p.add_argument("--resize_size", default=448, type=int)
+    p.add_argument("--infer_set", default="train", type=str)
+    p.add_argument("--training_free", default=True, type=_bool)
+    p.add_argument("--num_classes", default=21, type=int)
+    p.add_argument("--ignore_index", default=255, type=int)
+    p.add_argument("--local_rank", default=int(os.environ.get("LOCAL_RANK", 0)), type=int)
+    p.add_argument("--backend", default="nccl")
+    # additions
+    p.add_argument("--batch_size", default=32, type=int)
+    p.add_argument("--synthetic", default=64, type=int, help="number of seeded synthetic samples")
+    p.add_argument("--seed", default=1234, type=int)
+    p.add_argument("--api_path", default=False, type=_bool, help="per-image reference call sequence instead of the batched pipeline")
+    return p
+
+
+# ------------------------------------------------------------------ sharding + the one collective
+def shard_indices(n, rank, world):
+    """Subset(np.arange(i, len, n_gpus)) (tools/infer_lam.py:166)."""
+    return np.arange(rank, n, world)
+
+
+def gather_hists(hist, group=None):
+    """all_gather of the per-rank [nc,nc] int64 confusion matrices -> ([R,nc,nc], summed [nc,nc]).
+    One small message per rank (3.5 KB VOC / 52 KB COCO): latency-bound, issued once per evaluation."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return hist[None], hist
+    world = dist.get_world_size(group)
+    parts = [torch.empty_like(hist) for _ in range(world)]
+    dist.all_gather(parts, hist.contiguous(), group=group)
+    stacked = torch.stack(parts, 0)
+    return stacked, stacked.sum(0)
+
+
+def format_scores_table(score, cat_list, metric_names=("confusion", "precision", "recall", "iou")):
+    """The table of utils/pyutils.py:37-58 (format_tabs_multi_metircs) without the texttable dependency."""
+    rows = [["Class"] + list(metric_names)]
+    vals = np.array([list(score[m].values()) for m in metric_names], np.float64)
+    for i in range(vals.shape[1]):
+        rows.append([cat_list[i] if i < len(cat_list) else str(i)] + [f"{v:.4f}" for v in vals[:, i]])
+    rows.append(["average_metrics"] + [f"{v:.4f}" for v in vals.mean(1)])
+    widths = [max(len(r[c]) for r in rows) for c in range(len(rows[0]))]
+    line = "+" + "+".join("-" * (w + 2) for w in widths) + "+"
+    out = [line]
+    for i, r in enumerate(rows):
+        out.append("|" + "|".join(" " + r[c].ljust(widths[c]) + " " for c in range(len(r))) + "|")
+        if i == 0 or i == len(rows) - 2:
+            out.append(line)
+    out.append(line)
+    return "\n".join(out)
+
+
+# ------------------------------------------------------------------ the loop
+def build_validation(model=None, par=None, dataset=None, indices=None, device="cuda", args=None):
+    """-> (hist [nc,nc] int64 on device, images processed, seconds).  Mirrors :63-128."""
+    from ..pipeline import TrainingFreePipeline
+    from ..utils import evaluate
+    from ..utils.affutils import refine_cams_with_aff, refine_cams_with_bkg_weclip
+    from .. import ops
+    S = args.resize_size
+    pipe = TrainingFreePipeline(model, num_classes=args.num_classes, dilations=par.dilations, num_iter=par.num_iter,
+                                caa_thre=0.79, smax=dataset.max_k())
+    hist = torch.zeros((args.num_classes, args.num_classes), dtype=torch.int64, device=device)
+    t0 = time.time()
+    nimg = 0
+    bs = 1 if args.api_path else args.batch_size
+    for s in range(0, len(indices), bs):
+        _, imgs, gts, cls = dataset.batch(indices[s:s + bs])
+        inputs = torch.from_numpy(imgs).to(device, non_blocking=True)
+        if inputs.shape[-2:] != (S, S):
+            inputs = ops.bilinear_resize(inputs, S, S, align_corners=False)                 # :74
+        cls_labels = torch.from_numpy(cls).to(device, non_blocking=True)
+        gt_dev = torch.from_numpy(gts).to(device, non_blocking=True)
+        if args.api_path:
+            _, _, attr_maps_raw, attn_weights, _ = model(inputs)                            # :79
+            for i, attr_map in enumerate(attr_maps_raw):                                    # :88
+                refined, cls_lst = refine_cams_with_aff(attr_map, attn_weights[:, i], cls_labels[i], size=inputs.shape[2:],
+                                                        caa_thre=0.79)                      # :93
+                labels, _ = refine_cams_with_bkg_weclip(refined, inputs[i], cls_lst, par, gts.shape[-2:])   # :94
+                hist = evaluate.hist_from_labels([gt_dev[i]], [labels[0]], args.num_classes, device, hist)
+        else:
+            pipe.hist = hist
+            pipe.run_batch(inputs, cls_labels, gt_dev)
+            hist = pipe.hist
+        nimg += len(imgs)
+    torch.cuda.synchronize()
+    return hist, nimg, time.time() - t0
+
+
+def validate(args=None):
+    from ..model.model_excel import ExCEL_model
+    from ..utils import evaluate
+    from ..utils.PAR import PAR
+    from . import synthetic
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    rank = int(os.environ.get("RANK", 0))
+    torch.cuda.set_device(args.local_rank)
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group(backend=args.backend)                                       # :133
+    device = torch.device("cuda", args.local_rank)
+    dataset = synthetic.SyntheticSegDataset(args.synthetic, (args.resize_size, args.resize_size),
+                                            num_classes=args.num_classes, seed=args.seed)
+    T = 45 if args.num_classes <= 21 else 103
+    model = ExCEL_model(clip_model=args.model, embedding_dim=args.embedding_dim, in_channels=args.in_channels,
+                        dataset_name=args.dataset_name, num_classes=args.num_classes, num_atrr_clusters=args.num_attri,
+                        json_file=args.attr_json, img_size=args.resize_size, mode=args.infer_set, device=device,
+                        state_dict=synthetic.make_vit_state_dict(seed=0), text_features=synthetic.make_text_features(T))
+    par = PAR(num_iter=20, dilations=[1, 2, 4, 8, 12, 24])                                  # :168
+    idx = shard_indices(len(dataset), rank, world)                                          # :166
+    hist, nimg, secs = build_validation(model, par, dataset, idx, device, args)
+    per_rank, total = gather_hists(hist)
+    score = evaluate.scores_from_hist(total)
+    if rank == 0:
+        logging.info(f"Training_free:{args.training_free}, LAM_score:")
+        logging.info("\n" + format_scores_table(score, VOC_CLASSES))
+        logging.info(f"mIoU {score['miou'] * 100:.3f}  images {int(nimg) * world}  ({nimg / secs:.1f} img/s/rank)")
+    return score, total
+
+
+if __name__ == "__main__":
+    logging.basicConfig(level=logging.INFO, format="%(message)s")
+    validate(get_parser().parse_args())

@@ -1,0 +1,95 @@
+"""Seeded synthetic stand-ins for the data the path consumes (no VOC images / CLIP checkpoint exist offline).
+
+Shapes and statistics follow BASELINE.md section 2 / SURVEY 8(d): images N(0,1) already "normalised", gt uniform in
+{0..nc-1} with 2 % ignore (255), present-class count k drawn from the VOC train_aug histogram, ViT weights with
+the CLIP ViT-B/16 shapes, text bank = the shipped attribute bank through attr_aggregate with random unit-norm
+class/background text features.  numpy RandomState only, so every box regenerates identical data.
+"""
+import numpy as np
+
+VOC_K_HIST = {1: 6249, 2: 3104, 3: 969, 4: 210, 5: 46, 6: 4}     # datasets/voc/cls_labels_onehot.npy, train_aug
+
+
+def vit_b16_config():
+    return dict(width=768, layers=12, heads=12, patch=16, output_dim=512, input_resolution=224)
+
+
+def make_vit_state_dict(cfg=None, seed=0, attn_gain=2.0):
+    """Random weights keyed like the reference VisionTransformer.state_dict() (clip/clip_surgery_model.py:374-394)."""
+    c = dict(vit_b16_config())
+    c.update(cfg or {})
+    rs = np.random.RandomState(seed)
+    D, L, ps, out = c["width"], c["layers"], c["patch"], c["output_dim"]
+    g = c["input_resolution"] // ps
+    f32 = np.float32
+
+    def rn(*shape, std=1.0):
+        return (rs.standard_normal(shape) * std).astype(f32)
+
+    w = {"conv1.weight": rn(D, 3, ps, ps, std=(3 * ps * ps) ** -0.5), "class_embedding": rn(D, std=D ** -0.5),
+         "positional_embedding": rn(g * g + 1, D, std=D ** -0.5 * 4)}
+    for nm in ("ln_pre", "ln_post"):
+        w[nm + ".weight"] = (1.0 + 0.1 * rs.standard_normal(D)).astype(f32)
+        w[nm + ".bias"] = rn(D, std=0.1)
+    for i in range(L):
+        p = f"transformer.resblocks.{i}."
+        for nm in ("ln_1", "ln_2"):
+            w[p + nm + ".weight"] = (1.0 + 0.1 * rs.standard_normal(D)).astype(f32)
+            w[p + nm + ".bias"] = rn(D, std=0.1)
+        w[p + "attn.in_proj_weight"] = rn(3 * D, D, std=attn_gain ** 0.5 * D ** -0.5)
+        w[p + "attn.in_proj_bias"] = rn(3 * D, std=0.1)
+        w[p + "attn.out_proj.weight"] = rn(D, D, std=0.5 * D ** -0.5)
+        w[p + "attn.out_proj.bias"] = rn(D, std=0.02)
+        w[p + "mlp.c_fc.weight"] = rn(4 * D, D, std=D ** -0.5)
+        w[p + "mlp.c_fc.bias"] = rn(4 * D, std=0.1)
+        w[p + "mlp.c_proj.weight"] = rn(D, 4 * D, std=0.5 * (4 * D) ** -0.5)
+        w[p + "mlp.c_proj.bias"] = rn(D, std=0.02)
+    w["proj"] = rn(D, out, std=D ** -0.5)
+    return w
+
+
+def make_text_features(T=45, C=512, seed=7):
+    rs = np.random.RandomState(seed)
+    t = rs.standard_normal((T, C)).astype(np.float32)
+    return t / np.linalg.norm(t, axis=1, keepdims=True)
+
+
+def draw_k(rs, hist=VOC_K_HIST):
+    ks = np.array(sorted(hist))
+    p = np.array([hist[k] for k in ks], np.float64)
+    return int(rs.choice(ks, p=p / p.sum()))
+
+
+class SyntheticSegDataset:
+    """Index -> (name, image [3,h,w] f32, label [H,W] u8, cls_label [F] f32), like VOC12SegDataset.__getitem__
+    (datasets/voc.py:212-230).  Every sample is generated from its own seed, so shards are order independent."""
+
+    def __init__(self, n, image_hw=(448, 448), label_hw=None, num_classes=21, seed=1234, fixed_k=None):
+        self.n = n
+        self.image_hw = tuple(image_hw)
+        self.label_hw = tuple(label_hw or image_hw)
+        self.num_classes = num_classes
+        self.seed = seed
+        self.fixed_k = fixed_k
+
+    def __len__(self):
+        return self.n
+
+    def max_k(self):
+        return self.fixed_k or max(VOC_K_HIST)
+
+    def __getitem__(self, i):
+        rs = np.random.RandomState((self.seed * 1000003 + i) % (2 ** 31 - 1))
+        F = self.num_classes - 1
+        img = rs.standard_normal((3,) + self.image_hw).astype(np.float32)
+        gt = rs.randint(0, self.num_classes, self.label_hw).astype(np.uint8)
+        gt[rs.rand(*self.label_hw) < 0.02] = 255
+        k = self.fixed_k or draw_k(rs)
+        cls = np.zeros(F, np.float32)
+        cls[rs.choice(F, size=k, replace=False)] = 1
+        return f"syn_{i:06d}", img, gt, cls
+
+    def batch(self, indices):
+        items = [self[i] for i in indices]
+        return ([it[0] for it in items], np.stack([it[1] for it in items]), np.stack([it[2] for it in items]),
+                np.stack([it[3] for it in items]))

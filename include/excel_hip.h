@@ -1,0 +1,181 @@
+/* libexcel_hip -- C ABI of the MI355X-native ExCEL training-free CAM + affinity + PAR hot path.
+ *
+ * The reference (zwyang6/ExCEL) is pure Python on PyTorch: it has no FFI/plugin boundary, its drop-in
+ * boundary is the Python call surface (model_excel / clip / affutils / PAR / evaluate).  excel_amd/ keeps
+ * that surface and binds THIS library underneath it with ctypes.  Every entry point
+ * below cites the reference interface it replaces (paths relative to the reference repo).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless marked (host); tensors are dense row-major fp32 unless noted
+ *   - every call takes an explicit hipStream_t (passed as void*), launches asynchronously, never syncs,
+ *     never allocates (callers own all buffers; *_workspace_bytes tell how much scratch to bring),
+ *     except excel_vit_create / excel_vit_destroy
+ *   - return 0 on success, <0 on error (-1 bad argument, -2 launch failure, -3 allocation failure);
+ *     excel_last_error() returns a thread-local message
+ *   - B images, S x S input, g = S/patch, P = g*g patches, N = P+1 tokens, D = width, H = heads (D/H must be 64),
+ *     C = out_dim, T text rows, F foreground classes, L layers
+ */
+#ifndef EXCEL_HIP_H
+#define EXCEL_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* excel_last_error(void);
+int excel_abi_version(void);
+
+/* ------------------------------------------------------------------ building blocks (exported for tests / reuse) */
+
+/* C = act(A . op(B) + bias) + residual on the f32-input matrix core (exact-fp32 numerics).
+ * b_kmajor=1: B is [N,K] (torch nn.Linear weight layout); 0: B is [K,N].  act: 0 none, 1 QuickGELU
+ * (clip/clip_surgery_model.py:280-282).  Batched: `batch` problems with element strides sA/sB/sC.
+ * Replaces the cuBLAS GEMMs behind nn.Linear / torch.matmul on the path. */
+int excel_gemm_f32(const float* A, const float* Bm, float* C, const float* bias, const float* residual,
+                   int M, int N, int K, int lda, int ldb, int ldc, int ldr, int b_kmajor, int act,
+                   int batch, long long sA, long long sB, long long sC, long long sR, void* stream);
+
+/* LayerNorm over the last dim, fp32, eps as given (clip/clip_surgery_model.py:271-277). */
+int excel_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int D, float eps, void* stream);
+
+/* ------------------------------------------------------------------ ViT "surgery" forward */
+
+typedef struct {
+    int width, layers, heads, patch, out_dim;
+    int n_surgery;   /* blocks [layers-n_surgery, layers) use q-q/k-k/v-v attention; reload_self_attn(layers=6) -> 5
+                        (clip/clip_surgery_model.py:396-405) */
+    int pos_grid;    /* side of the stored positional grid (positional_embedding has 1 + pos_grid^2 rows) */
+} excel_vit_config;
+
+typedef struct {
+    const float *ln1_w, *ln1_b;
+    const float *in_proj_w, *in_proj_b;    /* [3D,D], [3D]  rows q|k|v (nn.MultiheadAttention.in_proj_* == Attention.qkv.*) */
+    const float *out_proj_w, *out_proj_b;  /* [D,D], [D] */
+    const float *ln2_w, *ln2_b;
+    const float *fc1_w, *fc1_b;            /* mlp.c_fc   [4D,D], [4D] */
+    const float *fc2_w, *fc2_b;            /* mlp.c_proj [D,4D], [D] */
+} excel_vit_block_weights;
+
+typedef struct {
+    const float* conv1_w;    /* [D,3,patch,patch] */
+    const float* class_emb;  /* [D] */
+    const float* pos_emb;    /* [1+pos_grid^2, D] */
+    const float *ln_pre_w, *ln_pre_b, *ln_post_w, *ln_post_b;
+    const float* proj;       /* [D, out_dim] */
+    const excel_vit_block_weights* blocks;   /* (host) array of `layers` entries of device pointers */
+} excel_vit_weights;
+
+typedef struct excel_vit* excel_vit_t;
+
+/* Binds device weight pointers (NOT copied, must outlive the handle) and prepares derived weights
+ * (proj^T; bilinearly resized positional grids are cached per g on first use, clip_surgery_model.py:426-435).
+ * Replaces ExCEL_CLIP.visual construction + reload_self_attn (clip/clip_surgery_model.py:396-416). */
+int excel_vit_create(const excel_vit_config* cfg, const excel_vit_weights* w, excel_vit_t* out);
+void excel_vit_destroy(excel_vit_t h);
+
+size_t excel_vit_workspace_bytes(excel_vit_t h, int B, int S);
+
+/* VisionTransformer.forward + generate_clip_fts (clip/clip_surgery_model.py:419-448, clip/clip.py:348-358).
+ *   img            [B,3,S,S]
+ *   image_features [B,N,C]  token-axis L2-normalised (clip.py:353)                         (required)
+ *   x_raw          [B,N,C]  ln_post(x) @ proj before the normalisation                      (optional, may be NULL)
+ *   w_aff          [B,P,P]  mean over the last `aff_layers` layers of attn[:,1:,1:] -- exactly what
+ *                           refine_cams_with_aff consumes (utils/affutils.py:180,197); block weights are head-MEAN
+ *                           for nn.MultiheadAttention blocks, head-SUM for surgery blocks    (optional)
+ *   attn_out       [n_attn_out,B,N,N] per-layer weights of the LAST n_attn_out layers (0..L) (optional)
+ *   feats_out      [L,B,N,D] per-block original-path features ("all_feats", clean copies)   (optional)
+ */
+int excel_vit_forward(excel_vit_t h, const float* img, int B, int S, void* workspace, size_t workspace_bytes,
+                      float* image_features, float* x_raw, float* w_aff, int aff_layers,
+                      float* attn_out, int n_attn_out, float* feats_out, void* stream);
+
+/* ------------------------------------------------------------------ patch-text CAM */
+
+/* clip_feature_surgery (clip/clip.py:288-310, redundant_feats=None) on normalised features:
+ *   image_features [B,N,C], text [T,C] (unit rows) -> out_full [B,N,T] and/or the caller's slice
+ *   out_slice [B,N-1,F] = out_full[:, 1:, :F] (model/model_excel.py:58).  workspace: B*N*ldT floats, ldT = T rounded up to 4. */
+size_t excel_cam_workspace_bytes(int B, int N, int T);
+int excel_clip_feature_surgery(const float* image_features, const float* text, int B, int N, int C, int T, int F,
+                               float temperature, float* out_full, float* out_slice, void* workspace, void* stream);
+
+/* ------------------------------------------------------------------ affinity random walk */
+
+/* mean over layers of attn[l, 1:, 1:] for one stacked tensor [Lw,B,N,N] -> [B,P,P] (utils/affutils.py:180,197). */
+int excel_attn_layer_mean(const float* attn, int Lw, int B, int N, int first_layer, int n_layers, float* w_aff, void* stream);
+
+/* compute_trans_mat (utils/affutils.py:8-24): 3x(col,row) normalise, symmetrise, square (batched fp32 MFMA GEMM).
+ * workspace: (2*B*P*P + B*P) floats. */
+size_t excel_trans_mat_workspace_bytes(int B, int P);
+int excel_compute_trans_mat(const float* w_aff, int B, int P, float* trans_out, void* workspace, void* stream);
+
+/* present-class compaction of one-hot labels [B,F] -> cls_idx [B,Smax] (-1 padded), ncls [B], and optionally
+ * nchan [B] = min(ncls,Smax)+1 (channels incl. background)  (cls_lst = torch.where(cls_label)[0], utils/affutils.py:203). */
+int excel_cls_compact(const float* onehot, int B, int F, int Smax, int32_t* cls_idx, int32_t* ncls, int32_t* nchan, void* stream);
+
+/* scoremap2bbox + box mask (utils/affutils.py:26-53, :208-214) for every (image, present class):
+ *   attr [B,P,F] -> v [B,Smax,P] = mask .* attr[:, :, cls]; mask_out [B,Smax,P] u8 optional. */
+int excel_scoremap_box_mask(const float* attr, const int32_t* cls_idx, const int32_t* ncls, int B, int g, int F, int Smax,
+                            double caa_thre, float* v_out, uint8_t* mask_out, void* stream);
+
+/* refine_cams_with_aff, batched and fused (utils/affutils.py:177-223, seg_attn=None):
+ *   refined[b,s,:] = T2 (mask_s .* attr[:, cls_s]) with T2 = Tsym.Tsym applied as two mat-vecs.
+ *   workspace: excel_refine_workspace_bytes.  refined [B,Smax,P]. */
+size_t excel_refine_workspace_bytes(int B, int P, int Smax);
+int excel_refine_cams_with_aff(const float* attr, const float* w_aff, const int32_t* cls_idx, const int32_t* ncls,
+                               int B, int g, int F, int Smax, double caa_thre, float* refined, void* workspace, void* stream);
+
+/* generate_cam_label/scale_cam_image + background channel (utils/affutils.py:55-78, :164-166):
+ *   refined [B,Smax,P] -> cams [B,Smax+1,H,W]: channel 0 = 1 - max_c, channels 1..ncls[b] = min-max normalised,
+ *   bilinearly (cv2.resize INTER_LINEAR rule) up-sampled maps.  workspace: B*Smax*P floats. */
+int excel_cam_upsample_bkg(const float* refined, const int32_t* ncls, int B, int g, int Smax, int H, int W, float* cams,
+                           void* workspace, void* stream);
+
+/* ------------------------------------------------------------------ PAR + labels + metric */
+
+/* PAR.forward (utils/PAR.py:64-92): imgs [B,3,h,w], masks [B,Cmax,H,W] -> out [B,Cmax,H,W] after n_iter steps.
+ * nchan (optional) [B]: only channels < nchan[b] of image b are refined (ragged class counts).
+ * workspace: excel_par_workspace_bytes (aff planes + ping-pong + resized guide). */
+size_t excel_par_workspace_bytes(int B, int Cmax, int H, int W, int ndil);
+int excel_par_forward(const float* imgs, int h, int w, const float* masks, const int32_t* nchan, int B, int Cmax, int H, int W,
+                      const int32_t* dilations /*host*/, int ndil, int n_iter, float w1, float w2, float* out,
+                      void* workspace, void* stream);
+
+/* refined.argmax(1) -> valid_key lookup (utils/affutils.py:86-87, :168).  cls_idx may be NULL (identity keys). */
+int excel_argmax_label(const float* cams, const int32_t* nchan, const int32_t* cls_idx, int B, int Smax, int Cmax,
+                       long long HW, uint8_t* labels_u8, int64_t* labels_i64, void* stream);
+
+/* _fast_hist accumulated on device (utils/evaluate.py:9-20): hist[nc*gt+pred] += 1 for gt < nc; hist is int64 [nc*nc]. */
+int excel_confusion_accumulate(const uint8_t* gt, const uint8_t* pred, long long n, int num_classes, int64_t* hist, void* stream);
+
+/* ------------------------------------------------------------------ one-time / auxiliary */
+
+/* attr_aggregate (model/load_attr.py:86-119): text [T,C] (F fg rows first), bank [C,K] -> text_attr [C,T], columns unit-norm.
+ * topK as in the reference (0.9): the lowest int((1-topK)*K) logits per fg row are dropped before the softmax. */
+int excel_attr_aggregate(const float* text, const float* bank, int F, int T, int C, int K, double topK, float* out, void* stream);
+
+/* F.interpolate(mode='bilinear', align_corners=0|1) on `planes` images of h x w -> H x W
+ * (tools/infer_lam.py:74 input resize; utils/camutils.py:41,54 multi-scale CAM resize; utils/PAR.py:67). */
+int excel_bilinear_resize(const float* in, float* out, long long planes, int h, int w, int H, int W, int align_corners, void* stream);
+
+/* positional_embedding [1+side^2, D] -> [1+g^2, D] (clip/clip_surgery_model.py:407-414 and :426-435). */
+int excel_pos_embed_resize(const float* pos, int side, int g, int D, float* out, void* stream);
+
+/* flip-TTA fuse of cure_attr_map_flip (utils/camutils.py:21-26): attr [2B,P,F] -> out [B,P,F]. */
+int excel_flip_max_normalize(const float* attr, float* out, int B, int g, int F, void* stream);
+
+/* ------------------------------------------------------------------ live per-kernel timing (bench.py) */
+
+/* When enabled, every kernel launch is bracketed by hipEvents on its launch stream, grouped by category.
+ * excel_prof_collect synchronises, fills ms[c] (summed elapsed), launches[c], work[c] (algorithmic FLOPs for the GEMM
+ * categories, 0 otherwise) for c < excel_prof_num_categories(), and clears the log. */
+int excel_prof_enable(int on);
+int excel_prof_num_categories(void);
+const char* excel_prof_category_name(int cat);
+int excel_prof_collect(double* ms /*host*/, long long* launches /*host*/, double* work /*host*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -141,7 +141,7 @@ def save(name, **arrs):
 
 
 # ---------------------------------------------------------------- 1. tiny ViT + CAM
-TINY = VitConfig(width=64, layers=8, heads=2, patch=16, out_dim=32, input_resolution=64, n_surgery=5)
+TINY = VitConfig(width=128, layers=8, heads=2, patch=16, out_dim=64, input_resolution=64, n_surgery=5)
 
 
 def gold_vit_cam():
@@ -152,7 +152,7 @@ def gold_vit_cam():
     for mode in ("train", "val"):
         vit = build_ref_vit(TINY, w, feat_size=6, mode=mode)
         x, f, attn, feats = ref_generate_clip_fts(vit, torch.from_numpy(imgs))
-        text = rs.standard_normal((9, 32)).astype(np.float32)
+        text = rs.standard_normal((9, 64)).astype(np.float32)
         text /= np.linalg.norm(text, axis=1, keepdims=True)
         cam = ref_clip_fs(f, torch.from_numpy(text))
         out.update({f"{mode}_x": x, f"{mode}_image_features": f, f"{mode}_attn": attn,
@@ -225,7 +225,7 @@ def gold_pipeline():
     w = make_vit_weights(TINY, seed=11)
     vit = build_ref_vit(TINY, w, feat_size=6, mode="train")
     rs = np.random.RandomState(33)
-    text = rs.standard_normal((9, 32)).astype(np.float32)
+    text = rs.standard_normal((9, 64)).astype(np.float32)
     text /= np.linalg.norm(text, axis=1, keepdims=True)
     par = ref_PAR_mod.PAR(num_iter=20, dilations=[1, 2, 4, 8, 12, 24])
     F_ = 4

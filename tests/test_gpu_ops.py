@@ -1,0 +1,400 @@
+"""GPU parity tests, op level: every C-ABI entry point against the numpy oracle on seeded inputs
+(and against the committed golden fixtures where one exists).  Run with `pytest -m gpu` on an MI355X."""
+import numpy as np
+import pytest
+
+import oracle
+from oracle.vit import VitConfig, make_vit_weights
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+TINY = VitConfig(width=128, layers=8, heads=2, patch=16, out_dim=64, input_resolution=64, n_surgery=5)
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def maxabs(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))))
+
+
+def relmax(a, b):
+    return maxabs(a, b) / max(float(np.max(np.abs(b))), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from excel_amd import ops as _ops
+    return _ops
+
+
+def make_handle(ops, cfg, w):
+    return ops.VitHandle(w, cfg.width, cfg.layers, cfg.heads, cfg.patch, cfg.out_dim, n_surgery=cfg.n_surgery)
+
+
+# ------------------------------------------------------------------ GEMM / LN
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 45, 512), (257, 384, 768), (785, 2304, 768), (37, 64, 128)])
+def test_gemm_nt(ops, M, N, K):
+    rs = np.random.RandomState(M + N + K)
+    A = rs.standard_normal((M, K)).astype(np.float32)
+    W = rs.standard_normal((N, K)).astype(np.float32)      # asymmetric operands: a transposed write cannot pass
+    bias = rs.standard_normal(N).astype(np.float32)
+    res = rs.standard_normal((M, N)).astype(np.float32)
+    ref = A.astype(np.float64) @ W.T.astype(np.float64)
+    out = host(ops.gemm(dev(A), dev(W)))
+    assert relmax(out, ref) < 2e-6
+    y = ref + bias
+    y = y * (1.0 / (1.0 + np.exp(-1.702 * y))) + res
+    out2 = host(ops.gemm(dev(A), dev(W), bias=dev(bias), residual=dev(res), act=1))
+    assert relmax(out2, y) < 3e-6
+
+
+def test_gemm_identity_detects_transpose(ops):
+    I = np.eye(64, dtype=np.float32)
+    Bm = np.arange(64 * 64, dtype=np.float32).reshape(64, 64) / 100.0     # asymmetric
+    out = host(ops.gemm(dev(I), dev(Bm)))           # I @ Bm^T
+    assert np.array_equal(out, Bm.T)
+
+
+@pytest.mark.parametrize("M,N,K", [(785, 64, 788), (100, 128, 64), (37, 64, 40)])
+def test_gemm_nn_batched(ops, M, N, K):
+    rs = np.random.RandomState(7)
+    A = rs.standard_normal((3, M, K)).astype(np.float32)
+    Bm = rs.standard_normal((3, K, N)).astype(np.float32)
+    ref = A.astype(np.float64) @ Bm.astype(np.float64)
+    out = host(ops.gemm(dev(A), dev(Bm), b_kmajor=False))
+    assert relmax(out, ref) < 2e-6
+
+
+def test_layernorm(ops):
+    rs = np.random.RandomState(3)
+    x = (rs.standard_normal((300, 768)) * 3 + 1).astype(np.float32)
+    w = rs.standard_normal(768).astype(np.float32)
+    b = rs.standard_normal(768).astype(np.float32)
+    ref = oracle.vit.layer_norm(x, w, b)
+    assert maxabs(host(ops.layernorm(dev(x), dev(w), dev(b))), ref) < 2e-5
+
+
+# ------------------------------------------------------------------ ViT
+def _check_vit(ops, cfg, w, imgs, tol_rel, check_feats=True):
+    L = cfg.layers
+    h = make_handle(ops, cfg, w)
+    nl = min(6, L)
+    r = h.forward(dev(imgs), want_w_aff=True, aff_layers=nl, n_attn_out=L, want_feats=check_feats, want_raw=True)
+    x, attn, feats = oracle.vit.vit_forward(imgs, w, cfg)
+    f_ref, _, _ = oracle.cam.generate_clip_fts(imgs, w, cfg)
+    got_attn = host(r["attn"])
+    for l in range(L):
+        assert maxabs(got_attn[l], attn[l]) < tol_rel * max(1.0, cfg.heads if l >= L - cfg.n_surgery else 1.0) * 10, f"attn layer {l}"
+    if check_feats:
+        got_feats = host(r["feats"])
+        for l in range(L):
+            assert relmax(got_feats[l], feats[l]) < tol_rel, f"feats layer {l}"
+    assert relmax(host(r["x_raw"]), x) < tol_rel
+    assert relmax(host(r["image_features"]), f_ref) < tol_rel
+    w_ref = attn[-nl:, :, 1:, 1:].mean(0, dtype=np.float32)
+    assert relmax(host(r["w_aff"]), w_ref) < tol_rel
+    return r, (x, attn, feats, f_ref)
+
+
+def test_vit_tiny_vs_oracle(ops):
+    w = make_vit_weights(TINY, seed=11)
+    imgs = np.random.RandomState(21).standard_normal((2, 3, 96, 96)).astype(np.float32)
+    _check_vit(ops, TINY, w, imgs, 5e-5)
+
+
+def test_vit_tiny_vs_golden(ops, golden):
+    g = golden("vit_cam_tiny.npz")
+    w = make_vit_weights(TINY, seed=int(g["seed_w"]))
+    for mode in ("train", "val"):
+        wm = oracle.vit.reload_self_attn(w, TINY, feat_size=6, mode=mode)
+        h = make_handle(ops, TINY, wm)
+        r = h.forward(dev(g["imgs"]), n_attn_out=TINY.layers, want_raw=True, want_feats=True)
+        assert relmax(host(r["x_raw"]), g[f"{mode}_x"]) < 5e-5
+        assert relmax(host(r["image_features"]), g[f"{mode}_image_features"]) < 5e-5
+        assert maxabs(host(r["attn"]), g[f"{mode}_attn"]) < 2e-4
+        assert relmax(host(r["feats"])[-1], g[f"{mode}_feat_last"]) < 5e-5
+        full, _ = ops.clip_feature_surgery(r["image_features"], dev(g[f"{mode}_text"]))
+        assert maxabs(host(full), g[f"{mode}_cam"]) < 1e-3      # north-star CAM gate
+        assert maxabs(host(full), g[f"{mode}_cam"]) < 1e-4      # what fp32 actually delivers
+    # second resolution through the pre-resized grid (quirk Q5)
+    wm = oracle.vit.reload_self_attn(w, TINY, feat_size=6, mode="train")
+    h = make_handle(ops, TINY, wm)
+    r = h.forward(dev(g["res2_imgs"]), n_attn_out=1, want_raw=True)
+    assert relmax(host(r["x_raw"]), g["res2_x"]) < 5e-5
+    assert maxabs(host(r["attn"])[0], g["res2_attn_last"]) < 2e-4
+
+
+def test_vit_odd_batch_and_no_surgery(ops):
+    cfg = VitConfig(width=128, layers=3, heads=2, patch=16, out_dim=64, input_resolution=64, n_surgery=0)
+    w = make_vit_weights(cfg, seed=5)
+    imgs = np.random.RandomState(2).standard_normal((3, 3, 80, 80)).astype(np.float32)
+    _check_vit(ops, cfg, w, imgs, 5e-5)
+
+
+def test_vit_b16_448_single_image_vs_oracle(ops):
+    """BASELINE shape (ViT-B/16, 448x448, N=785) on one image, seeded weights."""
+    cfg = VitConfig(width=768, layers=12, heads=12, patch=16, out_dim=512, input_resolution=224, n_surgery=5)
+    w = make_vit_weights(cfg, seed=1, attn_gain=2.0)
+    imgs = np.random.RandomState(4).standard_normal((1, 3, 448, 448)).astype(np.float32)
+    h = make_handle(ops, cfg, w)
+    r = h.forward(dev(imgs), want_w_aff=True, n_attn_out=6, want_raw=True)
+    x, attn, _ = oracle.vit.vit_forward(imgs, w, cfg)
+    f_ref, _, _ = oracle.cam.generate_clip_fts(imgs, w, cfg)
+    assert relmax(host(r["x_raw"]), x) < 2e-4
+    assert relmax(host(r["image_features"]), f_ref) < 2e-4
+    assert maxabs(host(r["attn"]), attn[-6:]) < 2e-3
+    assert relmax(host(r["w_aff"]), attn[-6:, :, 1:, 1:].mean(0, dtype=np.float32)) < 2e-4
+    # CAM gate on the full-size features
+    rs = np.random.RandomState(8)
+    text = rs.standard_normal((45, 512)).astype(np.float32)
+    text /= np.linalg.norm(text, axis=1, keepdims=True)
+    full, sl = ops.clip_feature_surgery(r["image_features"], dev(text), num_fg=20)
+    ref = oracle.cam.clip_feature_surgery(f_ref, text)
+    assert maxabs(host(full), ref) < 1e-3
+    assert np.array_equal(host(sl), host(full)[:, 1:, :20])
+
+
+# ------------------------------------------------------------------ CAM
+@pytest.mark.parametrize("B,N,C,T,F", [(2, 37, 64, 9, 4), (3, 785, 512, 45, 20), (1, 1025, 512, 103, 80)])
+def test_clip_feature_surgery(ops, B, N, C, T, F):
+    rs = np.random.RandomState(N + T)
+    f = rs.standard_normal((B, N, C)).astype(np.float32)
+    f = f / np.linalg.norm(f, axis=1, keepdims=True)
+    t = rs.standard_normal((T, C)).astype(np.float32)
+    t /= np.linalg.norm(t, axis=1, keepdims=True)
+    ref = oracle.cam.clip_feature_surgery(f, t)
+    full, sl = ops.clip_feature_surgery(dev(f), dev(t), num_fg=F)
+    assert maxabs(host(full), ref) < 2e-5
+    assert maxabs(host(sl), ref[:, 1:, :F]) < 2e-5
+
+
+def test_clip_feature_surgery_golden(ops, golden):
+    g = golden("ops.npz")
+    full, _ = ops.clip_feature_surgery(dev(g["cfs_f"]), dev(g["cfs_t"]))
+    assert maxabs(host(full), g["cfs_out"]) < 2e-5
+
+
+# ------------------------------------------------------------------ affinity
+def test_compute_trans_mat(ops, golden):
+    g = golden("ops.npz")
+    out = host(ops.compute_trans_mat(dev(g["tm_in"])))
+    np.testing.assert_allclose(out, g["tm_out"], rtol=5e-5, atol=1e-9)
+    rs = np.random.RandomState(1)
+    a = (rs.rand(2, 784, 784).astype(np.float32) ** 4 + 1e-4)
+    ref = np.stack([oracle.aff.compute_trans_mat(x) for x in a])
+    out = host(ops.compute_trans_mat(dev(a)))
+    np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-12)
+
+
+def test_attn_layer_mean(ops):
+    rs = np.random.RandomState(0)
+    attn = rs.rand(8, 2, 37, 37).astype(np.float32)
+    out = host(ops.attn_layer_mean(dev(attn), 6))
+    assert maxabs(out, attn[-6:, :, 1:, 1:].mean(0)) < 1e-6
+
+
+def _smooth_maps(rs, B, g, F):
+    """Random smooth-ish maps in [0,1] with several blobs per class."""
+    yy, xx = np.mgrid[0:g, 0:g].astype(np.float32)
+    out = np.zeros((B, g * g, F), np.float32)
+    for b in range(B):
+        for f in range(F):
+            m = np.zeros((g, g), np.float32)
+            for _ in range(rs.randint(1, 5)):
+                cy, cx, s = rs.uniform(0, g), rs.uniform(0, g), rs.uniform(0.8, 4.0)
+                m += rs.uniform(0.3, 1.0) * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * s * s))
+            m += 0.05 * rs.rand(g, g)
+            m = (m - m.min()) / (m.max() - m.min())
+            out[b, :, f] = m.reshape(-1)
+    return out
+
+
+KNOWN = {
+    # name: (map rows as strings, expected mask rows)  -- threshold 0.5 on maps holding 0 / 1 values
+    "single_pixel_centre": (["00000", "00000", "00100", "00000", "00000"], ["00000", "00000", "00100", "00000", "00000"]),
+    "border_box_loses_last_col_row": (["00000", "00000", "00011", "00011", "00011"], ["00000", "00000", "00010", "00010", "00000"]),
+    "corner_pixel_vanishes": (["00000", "00000", "00000", "00000", "00001"], ["00000", "00000", "00000", "00000", "00000"]),
+    "hole_filled_by_box": (["11100", "10100", "11100", "00000", "00000"], ["11100", "11100", "11100", "00000", "00000"]),
+    "diagonal_touch_is_one_component": (["10000", "01000", "00000", "00000", "00000"], ["11000", "11000", "00000", "00000", "00000"]),
+    "two_separate_blobs": (["10000", "00000", "00100", "00000", "00000"], ["10000", "00000", "00100", "00000", "00000"]),
+    "all_zero": (["00000", "00000", "00000", "00000", "00000"], ["00000", "00000", "00000", "00000", "00000"]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(KNOWN))
+def test_box_mask_known_answers(ops, name):
+    rows, exp = KNOWN[name]
+    m = np.array([[float(c) for c in r] for r in rows], np.float32)
+    e = np.array([[int(c) for c in r] for r in exp], np.uint8)
+    assert np.array_equal(oracle.aff.box_mask(m, 0.5).astype(np.uint8), e), "oracle known-answer"
+    attr = dev(m.reshape(1, 25, 1))
+    idx, n = ops.cls_compact(dev(np.ones((1, 1), np.float32)), 2)
+    v, mask = ops.scoremap_box_mask(attr, idx, n, 5, 0.5, want_mask=True)
+    assert np.array_equal(host(mask)[0, 0].reshape(5, 5), e)
+    assert np.array_equal(host(v)[0, 0].reshape(5, 5), m * e)
+
+
+@pytest.mark.parametrize("g", [6, 28, 32])
+def test_box_mask_random(ops, g):
+    rs = np.random.RandomState(g)
+    B, F = 4, 5
+    attr = _smooth_maps(rs, B, g, F)
+    onehot = (rs.rand(B, F) < 0.6).astype(np.float32)
+    onehot[:, 0] = 1
+    idx, n = ops.cls_compact(dev(onehot), F)
+    assert np.array_equal(host(n), onehot.sum(1).astype(np.int32))
+    v, mask = ops.scoremap_box_mask(dev(attr), idx, n, g, 0.79, want_mask=True)
+    idx_h, mask_h = host(idx), host(mask)
+    for b in range(B):
+        present = np.where(onehot[b])[0]
+        assert np.array_equal(idx_h[b, :len(present)], present)
+        for s, cls in enumerate(present):
+            ref = oracle.aff.box_mask(attr[b, :, cls].reshape(g, g), 0.79)
+            assert np.array_equal(mask_h[b, s].reshape(g, g), ref.astype(np.uint8)), (b, cls)
+
+
+def test_box_mask_snake_converges(ops):
+    """A long 1-pixel-wide serpentine: worst case for label propagation."""
+    g = 28
+    m = np.zeros((g, g), np.float32)
+    for y in range(0, g, 2):
+        m[y, :] = 1
+        if y + 1 < g:
+            m[y + 1, (g - 1) if (y // 2) % 2 == 0 else 0] = 1
+    ref = oracle.aff.box_mask(m, 0.5)
+    idx, n = ops.cls_compact(dev(np.ones((1, 1), np.float32)), 1)
+    _, mask = ops.scoremap_box_mask(dev(m.reshape(1, g * g, 1)), idx, n, g, 0.5, want_mask=True)
+    assert np.array_equal(host(mask)[0, 0].reshape(g, g), ref.astype(np.uint8))
+
+
+def test_refine_cams_with_aff_batched(ops):
+    rs = np.random.RandomState(12)
+    B, g, F = 3, 28, 20
+    P = g * g
+    attr = _smooth_maps(rs, B, g, F)
+    w_aff = (rs.rand(B, P, P).astype(np.float32) ** 6 + 1e-4)
+    onehot = np.zeros((B, F), np.float32)
+    onehot[0, [3]] = 1
+    onehot[1, [0, 7, 19]] = 1
+    onehot[2, [5, 6]] = 1
+    idx, n = ops.cls_compact(dev(onehot), 3)
+    out = host(ops.refine_cams_with_aff_batched(dev(attr), dev(w_aff), idx, n, g, 0.79))
+    for b in range(B):
+        present = np.where(onehot[b])[0]
+        trans = oracle.aff.compute_trans_mat(w_aff[b])
+        for s, cls in enumerate(present):
+            gmap = attr[b, :, cls].reshape(g, g)
+            mask = oracle.aff.box_mask(gmap, 0.79).reshape(1, -1)
+            ref = ((trans * mask) @ gmap.reshape(-1, 1)).reshape(-1)
+            assert relmax(out[b, s], ref) < 2e-5, (b, cls)
+        assert not out[b, len(present):].any()
+
+
+@pytest.mark.parametrize("g,H,W", [(6, 40, 56), (28, 448, 448), (28, 375, 500), (32, 333, 512)])
+def test_cam_upsample_bkg(ops, g, H, W):
+    rs = np.random.RandomState(H)
+    B, smax = 2, 3
+    r = rs.rand(B, smax, g * g).astype(np.float32) * 0.3
+    ncls = np.array([3, 1], np.int32)
+    cams = host(ops.cam_upsample_bkg(dev(r), dev(ncls), g, H, W))
+    for b in range(B):
+        maps = np.stack([oracle.aff.scale_cam_image(r[b, s].reshape(g, g), (W, H)) for s in range(ncls[b])])
+        bg = 1 - maps.max(0)
+        assert maxabs(cams[b, 1:1 + ncls[b]], maps) < 2e-6
+        assert maxabs(cams[b, 0], bg) < 2e-6
+
+
+# ------------------------------------------------------------------ PAR / labels / metric
+def test_par_golden(ops, golden):
+    g = golden("ops.npz")
+    out = host(ops.par_forward(dev(g["par_img"]), dev(g["par_mask"]), num_iter=20))
+    assert maxabs(out, g["par_out"]) < 1e-4
+    out2 = host(ops.par_forward(dev(g["par2_img"]), dev(g["par2_mask"]), num_iter=3))
+    assert maxabs(out2, g["par2_out"]) < 2e-5
+
+
+@pytest.mark.parametrize("B,C,H,W,it", [(2, 3, 64, 80, 5), (1, 7, 96, 96, 20), (2, 9, 50, 33, 2)])
+def test_par_vs_oracle(ops, B, C, H, W, it):
+    rs = np.random.RandomState(C * H)
+    img = rs.standard_normal((B, 3, H, W)).astype(np.float32)
+    masks = rs.rand(B, C, H, W).astype(np.float32)
+    ref = oracle.par.PAR([1, 2, 4, 8, 12, 24], it)(img, masks)
+    out = host(ops.par_forward(dev(img), dev(masks), num_iter=it))
+    assert maxabs(out, ref) < 5e-5
+
+
+def test_par_ragged_channels(ops):
+    rs = np.random.RandomState(2)
+    B, Cmax, H, W = 3, 4, 40, 48
+    img = rs.standard_normal((B, 3, H, W)).astype(np.float32)
+    masks = rs.rand(B, Cmax, H, W).astype(np.float32)
+    nchan = np.array([2, 4, 3], np.int32)
+    out = host(ops.par_forward(dev(img), dev(masks), num_iter=4, nchan=dev(nchan)))
+    par = oracle.par.PAR([1, 2, 4, 8, 12, 24], 4)
+    for b in range(B):
+        ref = par(img[b:b + 1], masks[b:b + 1, :nchan[b]])
+        assert maxabs(out[b, :nchan[b]], ref[0]) < 5e-5
+
+
+def test_par_guide_resize_align_corners(ops):
+    rs = np.random.RandomState(3)
+    img = rs.standard_normal((1, 3, 24, 30)).astype(np.float32)
+    masks = rs.rand(1, 2, 41, 37).astype(np.float32)
+    ref = oracle.par.PAR([1, 2, 4, 8, 12, 24], 2)(img, masks)
+    out = host(ops.par_forward(dev(img), dev(masks), num_iter=2))
+    assert maxabs(out, ref) < 5e-5
+
+
+def test_argmax_label(ops):
+    rs = np.random.RandomState(5)
+    B, smax, H, W = 3, 3, 17, 29
+    cams = rs.rand(B, smax + 1, H, W).astype(np.float32)
+    cams[0, 1] = cams[0, 2]                      # exact ties -> first index wins
+    onehot = np.zeros((B, 20), np.float32)
+    onehot[0, [2, 5, 9]] = 1
+    onehot[1, [0]] = 1
+    onehot[2, [18, 19]] = 1
+    idx, n, nchan = ops.cls_compact(dev(onehot), smax, want_nchan=True)
+    l8, l64 = ops.argmax_label(dev(cams), nchan, idx, want_i64=True)
+    l8, l64 = host(l8), host(l64)
+    for b in range(B):
+        cls = np.where(onehot[b])[0]
+        key = np.pad(cls + 1, (1, 0))
+        ref = key[cams[b, :len(cls) + 1].argmax(0)]
+        assert np.array_equal(l8[b], ref.astype(np.uint8))
+        assert np.array_equal(l64[b], ref.astype(np.int64))
+
+
+@pytest.mark.parametrize("nc,n", [(21, 448 * 448 * 3 + 5), (81, 100003), (5, 7)])
+def test_confusion(ops, nc, n):
+    rs = np.random.RandomState(nc)
+    gt = rs.randint(0, nc, n).astype(np.uint8)
+    gt[rs.rand(n) < 0.03] = 255
+    pred = rs.randint(0, nc, n).astype(np.uint8)
+    hist = ops.confusion_accumulate(dev(gt), dev(pred), nc)
+    hist = ops.confusion_accumulate(dev(gt), dev(pred), nc, hist)        # accumulates
+    ref = oracle.evaluate.fast_hist(gt, pred, nc)
+    assert np.array_equal(host(hist), 2 * ref)
+
+
+def test_confusion_golden(ops, golden):
+    g = golden("ops.npz")
+    gts = g["sc_gts"].astype(np.int64)
+    gts[gts == 255] = 255
+    hist = None
+    for gt, pr in zip(gts, g["sc_preds"]):
+        hist = ops.confusion_accumulate(dev(gt.astype(np.uint8)), dev(pr.astype(np.uint8)), 21, hist)
+    assert np.array_equal(host(hist), g["sc_hist"])

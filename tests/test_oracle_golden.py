@@ -6,7 +6,7 @@ import pytest
 import oracle
 from oracle.vit import VitConfig, make_vit_weights
 
-TINY = VitConfig(width=64, layers=8, heads=2, patch=16, out_dim=32, input_resolution=64, n_surgery=5)
+TINY = VitConfig(width=128, layers=8, heads=2, patch=16, out_dim=64, input_resolution=64, n_surgery=5)
 
 
 def maxabs(a, b):
@@ -26,14 +26,14 @@ def test_vit_forward_and_cam(golden, mode):
     w = oracle.vit.reload_self_attn(w, TINY, feat_size=6, mode=mode)
     f, attn, feats = oracle.cam.generate_clip_fts(g["imgs"], w, TINY)
     x, _, _ = oracle.vit.vit_forward(g["imgs"], w, TINY)
-    assert maxabs(x, g[f"{mode}_x"]) < 2e-5
+    assert relmax(x, g[f"{mode}_x"]) < 2e-5
     assert maxabs(f, g[f"{mode}_image_features"]) < 1e-5
     assert attn.shape == g[f"{mode}_attn"].shape
     assert maxabs(attn, g[f"{mode}_attn"]) < 1e-4      # values up to heads=2; fp32 through 8 blocks
     # block-6-style (index 2) weights are head-averaged, surgery ones head-summed (quirk Q3)
     np.testing.assert_allclose(attn[2].sum(-1), 1.0, atol=1e-5)
     np.testing.assert_allclose(attn[5].sum(-1), TINY.heads, atol=1e-5)
-    assert maxabs(feats[0], g[f"{mode}_feat0"]) < 2e-5
+    assert relmax(feats[0], g[f"{mode}_feat0"]) < 2e-5
     assert relmax(feats[-1], g[f"{mode}_feat_last"]) < 5e-5
     cam = oracle.cam.clip_feature_surgery(f, g[f"{mode}_text"])
     assert maxabs(cam, g[f"{mode}_cam"]) < 2e-5
@@ -44,7 +44,7 @@ def test_vit_second_resolution_uses_resized_grid(golden):
     w = make_vit_weights(TINY, seed=int(g["seed_w"]))
     w = oracle.vit.reload_self_attn(w, TINY, feat_size=6, mode="train")
     x, attn, _ = oracle.vit.vit_forward(g["res2_imgs"], w, TINY)
-    assert maxabs(x, g["res2_x"]) < 2e-5
+    assert relmax(x, g["res2_x"]) < 2e-5
     assert maxabs(attn[-1], g["res2_attn_last"]) < 1e-4
 
 
