@@ -9,6 +9,8 @@
 //                  traffic per step = (48 + 2C) * H * W * 4 bytes.
 //   argmax_label : label = valid_key[argmax_c]                                      (affutils.py:86-87)
 //   confusion    : hist[nc*gt + pred] += 1 over gt < nc                             (evaluate.py:10-14)
+#include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 #include "excel_internal.h"
 
@@ -107,6 +109,217 @@ __global__ __launch_bounds__(256) void par_iterate_kernel(const float* __restric
 #pragma unroll
         for (int c = 0; c < PAR_CCH; ++c)
             if (c0 + c < nch) ob[(long long)(c0 + c) * HW] = acc[c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Vectorised Jacobi step: one thread = 4 consecutive pixels of a row, every global access a 16-byte float4:
+//   * the aff stream (the dominant traffic, 48 floats/pixel) is read with full-width coalesced float4 loads;
+//   * taps whose dilation is a multiple of 4 (4, 8, 12, 24) are aligned float4 loads of the shifted group;
+//   * dilations 1..3 read the 12-float window [x0-4, x0+8) of the row once (3 float4) and pick the shifted values
+//     from registers;
+//   * replicate padding: rows clamp by index; column groups are either fully inside or fully outside (W % 4 == 0),
+//     an outside group is a splat of the edge pixel -> branch-free, no per-element clamps.
+//   * channel count is a compile-time constant per image (switch on the block-uniform nchan[b]): no predicated
+//     loads, so hipcc keeps every load in flight instead of serialising round trips.
+__device__ __forceinline__ f32x4 par_ldg4(const float* __restrict__ rowp, int xg, int W) {
+    const int xc = min(max(xg, 0), W - 4);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(rowp + xc);
+    // branch-free edge replication (selects, so the load is never wrapped in an exec-masked branch)
+    const bool lo = xg < 0, out = lo || (xg > W - 4);
+    const float e = lo ? v[0] : v[3];
+    return f32x4{out ? e : v[0], out ? e : v[1], out ? e : v[2], out ? e : v[3]};
+}
+
+template <int ND, int NC>
+__device__ __forceinline__ void par_body4(const float* __restrict__ a, const float* __restrict__ ib, float* __restrict__ ob,
+                                          const int (&dils)[8], int x0, int y, int H, int W, long long HW) {
+    f32x4 acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int di = 0; di < ND; ++di) {   // not unrolled: 8 aff float4 + one dilation's taps in flight keeps VGPRs low
+        int d = dils[0];                // select chain with static indices: a dynamically indexed kernarg struct goes to scratch
+#pragma unroll
+        for (int q = 1; q < ND; ++q) d = (di == q) ? dils[q] : d;
+        f32x4 w8[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w8[k] = *reinterpret_cast<const f32x4*>(a + (long long)(di * 8 + k) * HW);
+        const int yy[3] = {min(max(y - d, 0), H - 1), y, min(max(y + d, 0), H - 1)};
+        if ((d & 3) == 0) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float* ch = ib + (long long)c * HW;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const float* rowp = ch + (long long)yy[r] * W;
+#pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        if (r == 1 && dx == 0) continue;
+                        const int k = (r == 0) ? dx + 1 : (r == 1 ? (dx < 0 ? 3 : 4) : dx + 6);
+                        acc[c] += par_ldg4(rowp, x0 + dx * d, W) * w8[k];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);   // keep one channel's 8 loads in flight, not NC x 8 (VGPR cap)
+            }
+        } else {   // 1 <= d <= 3: register window; d is wave-uniform -> scalar branch over three fixed shifts
+            auto window = [&](auto shift_tag) {
+                constexpr int SH = decltype(shift_tag)::value;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const float* ch = ib + (long long)c * HW;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const float* rowp = ch + (long long)yy[r] * W;
+                        const f32x4 L = par_ldg4(rowp, x0 - 4, W), M = par_ldg4(rowp, x0, W), R = par_ldg4(rowp, x0 + 4, W);
+                        const float win[12] = {L[0], L[1], L[2], L[3], M[0], M[1], M[2], M[3], R[0], R[1], R[2], R[3]};
+#pragma unroll
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            if (r == 1 && dx == 0) continue;
+                            const int k = (r == 0) ? dx + 1 : (r == 1 ? (dx < 0 ? 3 : 4) : dx + 6);
+                            const f32x4 v = {win[4 + SH * dx], win[5 + SH * dx], win[6 + SH * dx], win[7 + SH * dx]};
+                            acc[c] += v * w8[k];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            if (d == 1) window(std::integral_constant<int, 1>{});
+            else if (d == 2) window(std::integral_constant<int, 2>{});
+            else window(std::integral_constant<int, 3>{});
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) *reinterpret_cast<f32x4*>(ob + (long long)c * HW) = acc[c];
+}
+
+template <int ND>
+__global__ __launch_bounds__(256) void par_iterate4_kernel(const float* __restrict__ aff, const float* __restrict__ in,
+                                                           float* __restrict__ out, const int* __restrict__ nchan, ParDil dl,
+                                                           int Cmax, int H, int W) {
+    constexpr int NT = 8 * ND;
+    const int b = blockIdx.z;
+    const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x0 >= W || y >= H) return;
+    const int nch = nchan ? min(nchan[b], Cmax) : Cmax;
+    const long long HW = (long long)H * W;
+    const float* a = aff + (long long)b * NT * HW + (long long)y * W + x0;
+    const float* ib = in + (long long)b * Cmax * HW;
+    float* ob = out + (long long)b * Cmax * HW + (long long)y * W + x0;
+    const int dils[8] = {dl.d[0], dl.d[1], dl.d[2], dl.d[3], dl.d[4], dl.d[5], dl.d[6], dl.d[7]};
+    for (int c0 = 0; c0 < nch; c0 += 4) {
+        const float* ic = ib + (long long)c0 * HW;
+        float* oc = ob + (long long)c0 * HW;
+        switch (min(nch - c0, 4)) {
+            case 1: par_body4<ND, 1>(a, ic, oc, dils, x0, y, H, W, HW); break;
+            case 2: par_body4<ND, 2>(a, ic, oc, dils, x0, y, H, W, HW); break;
+            case 3: par_body4<ND, 3>(a, ic, oc, dils, x0, y, H, W, HW); break;
+            default: par_body4<ND, 4>(a, ic, oc, dils, x0, y, H, W, HW); break;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-tiled Jacobi step (the production kernel).  One workgroup = a 64 x 16 pixel tile, one thread = 4 pixels.
+//   1. every thread issues its 48 aff float4 loads up front (the HBM stream: 192 B/pixel, fully coalesced,
+//      all in flight at once -> bandwidth-, not latency-bound) and keeps them in registers;
+//   2. the mask tile + replicate-padded halo (max dilation, here 24 -> 64 x 112 floats per channel) is staged
+//      through LDS two channels at a time with aligned float4 loads (L2 hits: masks are 0.8 MB/channel/image);
+//   3. taps are conflict-free ds_read_b128: dilations that are multiples of 4 read the shifted aligned group,
+//      dilations 1..3 read the 3 aligned groups around the pixel once per row and shift in registers.
+// aff is read exactly once per step whatever the channel count (it stays in registers across channel pairs).
+template <int ND, int HALO>
+__global__ __launch_bounds__(256, 2) void par_iterate_lds_kernel(const float* __restrict__ aff, const float* __restrict__ in,
+                                                                 float* __restrict__ out, const int* __restrict__ nchan,
+                                                                 ParDil dl, int Cmax, int H, int W) {
+    constexpr int NT = 8 * ND;
+    constexpr int halo = HALO, TR = 16 + 2 * HALO, TP = 64 + 2 * HALO, TP4 = TP >> 2;
+    __shared__ __attribute__((aligned(16))) float tile[2 * TR * TP];   // [2][TR][TP]
+    const int b = blockIdx.z, x0 = blockIdx.x * 64, y0 = blockIdx.y * 16;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int px = x0 + 4 * tx, py = y0 + ty;
+    const bool valid = px < W && py < H;
+    const int nch = nchan ? min(nchan[b], Cmax) : Cmax;
+    const long long HW = (long long)H * W;
+
+    const float* a = aff + (long long)b * NT * HW + (long long)min(py, H - 1) * W + min(px, W - 4);
+    const int cb = halo + 4 * tx;
+    for (int c0 = 0; c0 < nch; c0 += 2) {
+        const int nc = min(2, nch - c0);
+        // aff weights: one dilation (8 float4) in use, the next one in flight (static double buffer by unrolling).
+        // Channel pairs beyond the first re-read aff (MALL/L2-resident: the block just streamed it).
+        // The first dilation's loads are issued BEFORE the tile staging so their HBM latency overlaps it.
+        f32x4 wbuf[2][8];
+        const float* ac = a;
+        asm volatile("" : "+v"(ac));   // opaque per channel pair: stops LICM from hoisting all 48 loads (192 VGPRs) out of the loop
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wbuf[0][k] = *reinterpret_cast<const f32x4*>(ac + (long long)k * HW);
+        __syncthreads();
+        const int per_ch = TR * TP4;
+        for (int i = tid; i < nc * per_ch; i += 256) {
+            const int ch = i >= per_ch ? 1 : 0;
+            const int rem = i - ch * per_ch;
+            const int r = rem / TP4, g = rem - r * TP4;
+            const int gy = min(max(y0 - halo + r, 0), H - 1);
+            const f32x4 v = par_ldg4(in + ((long long)b * Cmax + c0 + ch) * HW + (long long)gy * W, x0 - halo + 4 * g, W);
+            *reinterpret_cast<f32x4*>(&tile[(ch * TR + r) * TP + 4 * g]) = v;
+        }
+        __syncthreads();
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int di = 0; di < ND; ++di) {
+            if (di + 1 < ND) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    wbuf[(di + 1) & 1][k] = *reinterpret_cast<const f32x4*>(ac + (long long)((di + 1) * 8 + k) * HW);
+            }
+            const int d = dl.d[di];
+            const int rr[3] = {ty + halo - d, ty + halo, ty + halo + d};
+            if ((d & 3) == 0) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        if (r == 1 && dx == 0) continue;
+                        const int k = (r == 0) ? dx + 1 : (r == 1 ? (dx < 0 ? 3 : 4) : dx + 6);
+                        const int off = rr[r] * TP + cb + dx * d;
+                        acc0 += *reinterpret_cast<const f32x4*>(&tile[off]) * wbuf[di & 1][k];
+                        if (nc > 1) acc1 += *reinterpret_cast<const f32x4*>(&tile[TR * TP + off]) * wbuf[di & 1][k];
+                    }
+            } else {
+                auto window = [&](auto shift_tag) {
+                    constexpr int SH = decltype(shift_tag)::value;
+#pragma unroll
+                    for (int ch = 0; ch < 2; ++ch) {
+                        if (ch == 1 && nc < 2) break;
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) {
+                            const float* rowp = &tile[(ch * TR + rr[r]) * TP + cb];
+                            const f32x4 L = *reinterpret_cast<const f32x4*>(rowp - 4), M = *reinterpret_cast<const f32x4*>(rowp),
+                                        R = *reinterpret_cast<const f32x4*>(rowp + 4);
+                            const float win[12] = {L[0], L[1], L[2], L[3], M[0], M[1], M[2], M[3], R[0], R[1], R[2], R[3]};
+#pragma unroll
+                            for (int dx = -1; dx <= 1; ++dx) {
+                                if (r == 1 && dx == 0) continue;
+                                const int k = (r == 0) ? dx + 1 : (r == 1 ? (dx < 0 ? 3 : 4) : dx + 6);
+                                const f32x4 v = {win[4 + SH * dx], win[5 + SH * dx], win[6 + SH * dx], win[7 + SH * dx]};
+                                if (ch == 0) acc0 += v * wbuf[di & 1][k]; else acc1 += v * wbuf[di & 1][k];
+                            }
+                        }
+                    }
+                };
+                if (d == 1) window(std::integral_constant<int, 1>{});
+                else if (d == 2) window(std::integral_constant<int, 2>{});
+                else window(std::integral_constant<int, 3>{});
+            }
+            __builtin_amdgcn_sched_barrier(0);   // do not hoist the aff loads of later dilations above this point (VGPR cap)
+        }
+        if (valid) {
+            float* o = out + ((long long)b * Cmax + c0) * HW + (long long)py * W + px;
+            *reinterpret_cast<f32x4*>(o) = acc0;
+            if (nc > 1) *reinterpret_cast<f32x4*>(o + HW) = acc1;
+        }
     }
 }
 
@@ -215,7 +428,19 @@ static void par_aff_launch(const float* img, float* aff, const ParDil& dl, int B
 template <int ND>
 static void par_it_launch(const float* aff, const float* in, float* out, const int* nchan, const ParDil& dl, int B, int Cmax,
                           int H, int W, hipStream_t st) {
-    hipLaunchKernelGGL(par_iterate_kernel<ND>, dim3(cdiv(W, 64), cdiv(H, 4), B), dim3(256), 0, st, aff, in, out, nchan, dl, Cmax, H, W);
+    bool vec = (W % 4) == 0 && W >= 8 && ((((uintptr_t)aff | (uintptr_t)in | (uintptr_t)out) & 15) == 0);
+    for (int i = 0; i < ND; ++i) vec = vec && ((dl.d[i] & 3) == 0 || dl.d[i] <= 3);
+    int halo = 0;
+    for (int i = 0; i < ND; ++i) halo = dl.d[i] > halo ? dl.d[i] : halo;
+    halo = (halo + 3) / 4 * 4;
+    if (vec && halo == 24 && !getenv("EXCEL_PAR_NO_LDS"))
+        hipLaunchKernelGGL((par_iterate_lds_kernel<ND, 24>), dim3(cdiv(W, 64), cdiv(H, 16), B), dim3(256), 0, st, aff, in, out, nchan, dl, Cmax, H, W);
+    else if (vec && halo == 8 && !getenv("EXCEL_PAR_NO_LDS"))
+        hipLaunchKernelGGL((par_iterate_lds_kernel<ND, 8>), dim3(cdiv(W, 64), cdiv(H, 16), B), dim3(256), 0, st, aff, in, out, nchan, dl, Cmax, H, W);
+    else if (vec)
+        hipLaunchKernelGGL(par_iterate4_kernel<ND>, dim3(cdiv(W, 256), cdiv(H, 4), B), dim3(256), 0, st, aff, in, out, nchan, dl, Cmax, H, W);
+    else
+        hipLaunchKernelGGL(par_iterate_kernel<ND>, dim3(cdiv(W, 64), cdiv(H, 4), B), dim3(256), 0, st, aff, in, out, nchan, dl, Cmax, H, W);
 }
 
 #define ND_SWITCH(nd, CALL)                 \
