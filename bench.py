@@ -24,7 +24,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
-F32_MATRIX_PEAK_TF = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (the dtype the GEMMs compute in)
+F32_MATRIX_PEAK_TF = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+BF16_MFMA_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak
 # SURVEY.md 8 flop table @448^2 (per image, GFLOP): rows that run on the gemm_f32 kernel
 GEMM_GFLOP_PER_IMG = 0.925 + 12 * (2.778 + 0.926 + 7.408) + 5 * (0.926 + 0.947) + 0.617 + 0.036
 VIT_CAM_GFLOP_PER_IMG = 181.2  # the reference algorithm's ViT + CAM work
@@ -140,7 +141,9 @@ def main():
         out = {
             "metric": "images/sec (CAM+PAR refine, 448x448)", "value": round(value, 3), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if model.encoder.visual.handle().gemm_mode() == "f32" else "bf16x3 (fp32 as bf16 hi+lo, fp32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: VOC-shaped 448x448, batch=32/GPU, ViT-B/16 surgery + patch-text CAM "
                                    "(T=45,F=20) + affinity random walk + PAR(20 it, 6 dilations) + argmax + confusion, "
                                    "full HIP path; seeded random weights, shipped VOC attribute bank",
@@ -151,25 +154,37 @@ def main():
         if prof:
             steps = args.steps
             ms = {k: v["ms"] / steps for k, v in prof.items() if v["launches"]}
-            gemm_ms = prof["gemm_nt"]["ms"]
-            gemm_launches = max(prof["gemm_nt"]["launches"], 1)
-            gemm_flops = prof["gemm_nt"]["work"]                    # sum of 2*M*N*K over the launches (algorithmic)
+            mode = model.encoder.visual.handle().gemm_mode()
+            cat = "gemm_bf16x3" if mode == "bf16x3" else "gemm_nt"
+            gemm_ms = prof[cat]["ms"]
+            gemm_launches = max(prof[cat]["launches"], 1)
+            gemm_flops = prof[cat]["work"]                          # sum of 2*M*N*K over the launches (algorithmic)
             achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
             traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
             if os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get("gemm_f32_kernel_nt_bytes_per_launch")
+                    traffic = json.load(open(tpath)).get(cat + "_bytes_per_launch")
                 except Exception:
                     traffic = None
+            if mode == "bf16x3":
+                peak = BF16_MFMA_PEAK_TF
+                kname = ("gemm_bf16x3_kernel (fp32 operands as bf16 hi+lo planes, 3 x v_mfma_f32_32x32x16_bf16 per product; "
+                         "all nn.Linear / patch-embed / proj GEMMs)")
+            else:
+                peak = F32_MATRIX_PEAK_TF
+                kname = "gemm_f32_kernel<NT> (fp32 MFMA 32x32x2; all nn.Linear / patch-embed / proj / sim GEMMs)"
             out["roofline"] = {
-                "kernel": "gemm_f32_kernel<NT> (fp32 MFMA 32x32x2; all nn.Linear / patch-embed / proj / sim GEMMs)",
-                "bound": "mfma", "achieved": round(achieved, 3), "peak": F32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
-                "frac": round(achieved / F32_MATRIX_PEAK_TF, 4), "traffic": traffic,
+                "kernel": kname, "bound": "mfma", "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": traffic,
                 "avg_launch_ms": round(gemm_ms / gemm_launches, 5), "launches_per_step": gemm_launches // steps,
                 "algorithmic_gflop_per_image": round(gemm_flops / steps / B / 1e9, 3),
                 "survey_gflop_per_image": round(GEMM_GFLOP_PER_IMG, 3),
             }
+            if mode == "bf16x3":
+                # the kernel issues 3 bf16 MFMAs per algorithmic product: matrix-pipe utilisation is 3x the algorithmic fraction
+                out["roofline"]["mfma_issue_frac"] = round(3 * achieved / peak, 4)
+                out["roofline"]["fp32_equivalent_peak"] = round(peak / 3, 1)
             # secondary rooflines (same event-timing source): PAR propagation (HBM) and the whole ViT (MFMA)
             par_it = prof["par_iterate"]
             if par_it["ms"] > 0:
@@ -178,7 +193,7 @@ def main():
                 out["roofline_par_iterate"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                "frac": round(gbs / HBM_PEAK_GBS, 4),
                                                "avg_launch_ms": round(par_it["ms"] / max(par_it["launches"], 1), 5)}
-            vit_ms = sum(prof[k]["ms"] for k in ("gemm_nt", "gemm_nn", "attn_rowpass", "attn_accum", "layernorm", "embed",
+            vit_ms = sum(prof[k]["ms"] for k in ("gemm_nt", "gemm_nn", "gemm_bf16x3", "attn_rowpass", "attn_accum", "layernorm", "embed",
                                                   "token_norm", "cam_epilogue"))
             if vit_ms > 0:
                 tf = VIT_CAM_GFLOP_PER_IMG * 1e9 * B * steps / (vit_ms * 1e-3) / 1e12

@@ -39,10 +39,14 @@ SIGNATURES = {
     "excel_abi_version": (c_i, []),
     "excel_gemm_f32": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                              c_ll, c_ll, c_ll, c_ll, c_f]),
+    "excel_split_bf16": (c_i, [c_f, c_f, c_ll, c_i, c_f]),
+    "excel_gemm_bf16x3": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
     "excel_layernorm": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, C.c_float, c_f]),
     "excel_vit_create": (c_i, [C.POINTER(VitConfig), C.POINTER(VitWeights), C.POINTER(C.c_void_p)]),
     "excel_vit_destroy": (None, [C.c_void_p]),
     "excel_vit_workspace_bytes": (c_sz, [C.c_void_p, c_i, c_i]),
+    "excel_vit_set_gemm_mode": (c_i, [C.c_void_p, c_i]),
+    "excel_vit_get_gemm_mode": (c_i, [C.c_void_p]),
     "excel_vit_forward": (c_i, [C.c_void_p, c_f, c_i, c_i, c_f, c_sz, c_f, c_f, c_f, c_i, c_f, c_i, c_f, c_f]),
     "excel_cam_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "excel_clip_feature_surgery": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, C.c_float, c_f, c_f, c_f, c_f]),

@@ -26,7 +26,7 @@ struct ProfRec { int cat; hipEvent_t a, b; };
 std::vector<ProfRec> g_prof_recs;
 std::vector<hipEvent_t> g_prof_pool;
 double g_prof_work[PROF_NCAT];
-const char* PROF_NAMES[PROF_NCAT] = {"gemm_nt", "gemm_nn", "attn_rowpass", "attn_accum", "layernorm", "embed", "token_norm",
+const char* PROF_NAMES[PROF_NCAT] = {"gemm_nt", "gemm_nn", "gemm_bf16x3", "attn_rowpass", "attn_accum", "layernorm", "embed", "token_norm",
                                      "cam_epilogue", "sinkhorn", "bbox_mask", "matvec", "cam_upsample", "par_affinity",
                                      "par_iterate", "argmax", "confusion", "other"};
 hipEvent_t prof_event() {
@@ -86,6 +86,15 @@ static GemmArgs gemm_args(const float* A, const float* B, float* C, const float*
     return g;
 }
 
+static GemmBfArgs gemm_bf_args(const void* A, const unsigned short* W, float* C, void* Cs, const float* bias, const float* res,
+                               int M, int N, int K, int ldc, int ldr, int act, int out_mode) {
+    GemmBfArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = (const unsigned short*)A; g.B = W; g.C = C; g.Cs = (unsigned short*)Cs; g.bias = bias; g.res = res;
+    g.M = M; g.N = N; g.K = K; g.lda = 2 * K; g.ldb = 2 * K; g.ldc = ldc; g.ldr = ldr; g.act = act; g.out_mode = out_mode;
+    return g;
+}
+
 // ------------------------------------------------------------------------------------ small helper kernels
 __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cc) {
     __shared__ float t[32][33];
@@ -140,18 +149,86 @@ extern "C" int excel_gemm_f32(const float* A, const float* Bm, float* C, const f
     return excel_launch_gemm(g, b_kmajor != 0, batch, ST(stream));
 }
 
+extern "C" int excel_split_bf16(const float* in, void* out, long long rows, int K, void* stream) {
+    EXCEL_CHECK_ARG(in && out && rows > 0 && K > 0, "split_bf16: bad argument");
+    return excel_launch_split_bf16(in, out, rows, K, ST(stream));
+}
+
+extern "C" int excel_gemm_bf16x3(const void* A_split, const void* W_split, float* C, const float* bias, const float* residual,
+                                 int M, int N, int K, int act, int split_out, void* stream) {
+    EXCEL_CHECK_ARG(A_split && W_split && C, "gemm_bf16x3: null argument");
+    GemmBfArgs g = gemm_bf_args(A_split, (const unsigned short*)W_split, C, C, bias, residual, M, N, K, N, N, act,
+                                split_out ? GEMM_OUT_SPLIT_BF16 : GEMM_OUT_PLAIN);
+    return excel_launch_gemm_bf16x3(g, ST(stream));
+}
+
 extern "C" int excel_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int D, float eps, void* stream) {
     return excel_launch_layernorm(x, nullptr, 1, w, b, y, rows, D, eps, ST(stream));
 }
 
 // ------------------------------------------------------------------------------------ ViT handle
+struct SplitBlockW { unsigned short *in_proj, *out_proj, *fc1, *fc2; };
 struct excel_vit {
     excel_vit_config cfg;
     excel_vit_weights w;
     std::vector<excel_vit_block_weights> blocks;
     float* projT = nullptr;             // [C, D]
     std::map<int, float*> pos_cache;    // g -> [1+g*g, D]
+    int gemm_mode = 0;                  // 0: exact fp32 MFMA, 1: bf16x3 (split bf16, 3 MFMAs per product)
+    unsigned short* split_arena = nullptr;   // all split weights in one allocation
+    std::vector<SplitBlockW> sblocks;
+    unsigned short *s_conv1 = nullptr, *s_projT = nullptr;
 };
+
+static int vit_prepare_split_weights(excel_vit* h) {
+    if (h->split_arena) return EXCEL_OK;
+    const excel_vit_config& c = h->cfg;
+    const size_t D = c.width, Kc = (size_t)3 * c.patch * c.patch;
+    const size_t per_block = 3 * D * D + D * D + 4 * D * D + 4 * D * D;       // floats == split bytes / 4
+    const size_t total = per_block * c.layers + D * Kc + (size_t)c.out_dim * D;
+    float* arena = nullptr;
+    if (hipMalloc(&arena, total * sizeof(float)) != hipSuccess) {
+        excel_set_error("excel_vit: hipMalloc(split weights) failed");
+        return EXCEL_ERR_ALLOC;
+    }
+    h->split_arena = (unsigned short*)arena;
+    float* cur = arena;
+    auto put = [&](const float* src, size_t rows, size_t K) -> unsigned short* {
+        unsigned short* dst = (unsigned short*)cur;
+        excel_launch_split_bf16(src, dst, (long long)rows, (int)K, 0);
+        cur += rows * K;
+        return dst;
+    };
+    h->sblocks.resize(c.layers);
+    for (int l = 0; l < c.layers; ++l) {
+        const excel_vit_block_weights& bw = h->blocks[l];
+        h->sblocks[l].in_proj = put(bw.in_proj_w, 3 * D, D);
+        h->sblocks[l].out_proj = put(bw.out_proj_w, D, D);
+        h->sblocks[l].fc1 = put(bw.fc1_w, 4 * D, D);
+        h->sblocks[l].fc2 = put(bw.fc2_w, D, 4 * D);
+    }
+    h->s_conv1 = put(h->w.conv1_w, D, Kc);
+    h->s_projT = put(h->projT, c.out_dim, D);
+    if (hipStreamSynchronize(0) != hipSuccess) {
+        excel_set_error("excel_vit: splitting weights failed: %s", hipGetErrorString(hipGetLastError()));
+        return EXCEL_ERR_LAUNCH;
+    }
+    return EXCEL_OK;
+}
+
+extern "C" int excel_vit_set_gemm_mode(excel_vit_t h, int mode) {
+    EXCEL_CHECK_ARG(h && (mode == 0 || mode == 1), "excel_vit_set_gemm_mode: mode must be 0 (f32) or 1 (bf16x3)");
+    if (mode == 1) {
+        EXCEL_CHECK_ARG((h->cfg.width % 32) == 0 && ((3 * h->cfg.patch * h->cfg.patch) % 32) == 0,
+                        "bf16x3 mode needs width and 3*patch^2 to be multiples of 32");
+        TRY(vit_prepare_split_weights(h));
+    }
+    h->gemm_mode = mode;
+    return EXCEL_OK;
+}
+extern "C" int excel_vit_get_gemm_mode(excel_vit_t h) { return h ? h->gemm_mode : -1; }
+
+
 
 extern "C" int excel_vit_create(const excel_vit_config* cfg, const excel_vit_weights* w, excel_vit_t* out) {
     EXCEL_CHECK_ARG(cfg && w && out, "excel_vit_create: null argument");
@@ -177,12 +254,18 @@ extern "C" int excel_vit_create(const excel_vit_config* cfg, const excel_vit_wei
         return EXCEL_ERR_LAUNCH;
     }
     *out = h;
+    const char* mode = getenv("EXCEL_GEMM_MODE");     // default numerics of new handles: "f32" | "bf16x3"
+    if (mode && !strcmp(mode, "bf16x3") && (cfg->width % 32) == 0 && ((3 * cfg->patch * cfg->patch) % 32) == 0) {
+        int rc = excel_vit_set_gemm_mode(h, 1);
+        if (rc) return rc;
+    }
     return EXCEL_OK;
 }
 
 extern "C" void excel_vit_destroy(excel_vit_t h) {
     if (!h) return;
     if (h->projT) hipFree(h->projT);
+    if (h->split_arena) hipFree(h->split_arena);
     for (auto& kv : h->pos_cache) hipFree(kv.second);
     delete h;
 }
@@ -255,27 +338,45 @@ extern "C" int excel_vit_forward(excel_vit_t h, const float* img, int B, int S, 
         pos = it->second;
     }
 
+    const bool bf = h->gemm_mode == 1;
     // patch embedding: im2col -> GEMM (conv1 weight is [D, 3*ps*ps] K-major) -> +cls/pos, ln_pre
-    TRY(excel_launch_im2col(img, ws.hbuf, B, S, ps, st));
+    TRY(excel_launch_im2col(img, ws.hbuf, B, S, ps, st, bf ? 1 : 0));
     {
         const int Kc = 3 * ps * ps;
-        GemmArgs ga = gemm_args(ws.hbuf, h->w.conv1_w, ws.ao, nullptr, nullptr, B * P, D, Kc, Kc, Kc, D, 0, GEMM_ACT_NONE);
-        TRY(excel_launch_gemm(ga, true, 1, st));
+        if (bf) {
+            GemmBfArgs ga = gemm_bf_args(ws.hbuf, h->s_conv1, ws.ao, nullptr, nullptr, nullptr, B * P, D, Kc, D, 0, GEMM_ACT_NONE, GEMM_OUT_PLAIN);
+            TRY(excel_launch_gemm_bf16x3(ga, st));
+        } else {
+            GemmArgs ga = gemm_args(ws.hbuf, h->w.conv1_w, ws.ao, nullptr, nullptr, B * P, D, Kc, Kc, Kc, D, 0, GEMM_ACT_NONE);
+            TRY(excel_launch_gemm(ga, true, 1, st));
+        }
     }
     TRY(excel_launch_assemble_ln_pre(ws.ao, h->w.class_emb, pos, h->w.ln_pre_w, h->w.ln_pre_b, ws.x, B, N, D, eps, st));
+
+    // linear layer helper: C = act(A . W^T + bias) + res, A produced in the mode's operand format
+    auto linear = [&](const float* A, const float* Wf, const unsigned short* Ws, const float* bias, const float* res, float* Cout,
+                      int Nout, int K, int act, int out_mode) -> int {
+        if (bf) {
+            GemmBfArgs ga = gemm_bf_args(A, Ws, Cout, Cout, bias, res, M, Nout, K, Nout, Nout, act, out_mode);
+            if (out_mode == GEMM_OUT_QKV_HEADMAJOR) { ga.tokN = N; ga.heads = H; ga.hd = 64; }
+            return excel_launch_gemm_bf16x3(ga, st);
+        }
+        GemmArgs ga = gemm_args(A, Wf, Cout, bias, res, M, Nout, K, K, K, Nout, Nout, act);
+        if (out_mode == GEMM_OUT_QKV_HEADMAJOR) { ga.out_mode = GEMM_OUT_QKV_HEADMAJOR; ga.tokN = N; ga.heads = H; ga.hd = 64; }
+        return excel_launch_gemm(ga, true, 1, st);
+    };
+    const int mid_mode = bf ? GEMM_OUT_SPLIT_BF16 : GEMM_OUT_PLAIN;   // format of GEMM->GEMM intermediates (MLP hidden)
+    const SplitBlockW nosplit{nullptr, nullptr, nullptr, nullptr};
 
     const int first_surgery = L - c.n_surgery;
     for (int l = 0; l < L; ++l) {
         const excel_vit_block_weights& bw = h->blocks[l];
+        const SplitBlockW& sw = bf ? h->sblocks[l] : nosplit;
         const bool surgery = l >= first_surgery;
         float* src = (surgery && l > first_surgery) ? ws.xo : ws.x;   // :315 vs :323
-        TRY(excel_launch_layernorm(src, nullptr, 1, bw.ln1_w, bw.ln1_b, ws.y, M, D, eps, st));
-        {   // packed q|k|v projection, written head-major
-            GemmArgs ga = gemm_args(ws.y, bw.in_proj_w, ws.qkvh, bw.in_proj_b, nullptr, M, 3 * D, D, D, D, 0, 0, GEMM_ACT_NONE);
-            ga.out_mode = GEMM_OUT_QKV_HEADMAJOR; ga.tokN = N; ga.heads = H; ga.hd = 64;
-            TRY(excel_launch_gemm(ga, true, 1, st));
-        }
-        TRY(excel_launch_attn_rowpass(ws.qkvh, ws.ao, ws.stats, B, H, N, 64, scale, surgery ? 4 : 1, st));
+        TRY(excel_launch_layernorm(src, nullptr, 1, bw.ln1_w, bw.ln1_b, ws.y, M, D, eps, st, bf));
+        TRY(linear(ws.y, bw.in_proj_w, sw.in_proj, bw.in_proj_b, nullptr, ws.qkvh, 3 * D, D, GEMM_ACT_NONE, GEMM_OUT_QKV_HEADMAJOR));
+        TRY(excel_launch_attn_rowpass(ws.qkvh, ws.ao, ws.stats, B, H, N, 64, scale, surgery ? 4 : 1, st, bf));
         const bool in_aff = w_aff && l >= L - aff_layers;
         float* attn_l = (n_attn_out && l >= L - n_attn_out) ? attn_out + (size_t)(l - (L - n_attn_out)) * B * N * N : nullptr;
         if (surgery || in_aff || attn_l) {
@@ -284,13 +385,10 @@ extern "C" int excel_vit_forward(excel_vit_t h, const float* img, int B, int S, 
                                         (l == L - aff_layers) ? 1 : 0, st));
         }
         if (!surgery) {
-            GemmArgs ga = gemm_args(ws.ao, bw.out_proj_w, ws.x, bw.out_proj_b, ws.x, M, D, D, D, D, D, D, GEMM_ACT_NONE);
-            TRY(excel_launch_gemm(ga, true, 1, st));                                              // x += out_proj(attn)
-            TRY(excel_launch_layernorm(ws.x, nullptr, 1, bw.ln2_w, bw.ln2_b, ws.y, M, D, eps, st));
-            GemmArgs g1 = gemm_args(ws.y, bw.fc1_w, ws.hbuf, bw.fc1_b, nullptr, M, 4 * D, D, D, D, 4 * D, 0, GEMM_ACT_QUICKGELU);
-            TRY(excel_launch_gemm(g1, true, 1, st));
-            GemmArgs g2 = gemm_args(ws.hbuf, bw.fc2_w, ws.x, bw.fc2_b, ws.x, M, D, 4 * D, 4 * D, 4 * D, D, D, GEMM_ACT_NONE);
-            TRY(excel_launch_gemm(g2, true, 1, st));                                              // x += mlp(ln_2(x))
+            TRY(linear(ws.ao, bw.out_proj_w, sw.out_proj, bw.out_proj_b, ws.x, ws.x, D, D, GEMM_ACT_NONE, GEMM_OUT_PLAIN));   // x += out_proj(attn)
+            TRY(excel_launch_layernorm(ws.x, nullptr, 1, bw.ln2_w, bw.ln2_b, ws.y, M, D, eps, st, bf));
+            TRY(linear(ws.y, bw.fc1_w, sw.fc1, bw.fc1_b, nullptr, ws.hbuf, 4 * D, D, GEMM_ACT_QUICKGELU, mid_mode));
+            TRY(linear(ws.hbuf, bw.fc2_w, sw.fc2, bw.fc2_b, ws.x, ws.x, D, 4 * D, GEMM_ACT_NONE, GEMM_OUT_PLAIN));           // x += mlp(ln_2(x))
             if (feats_out) hipMemcpyAsync(feats_out + (size_t)l * M * D, ws.x, sizeof(float) * (size_t)M * D, hipMemcpyDeviceToDevice, st);
         } else {
             // new path: (A_sum . V_h) for every head, heads concatenated -> y  (batched NN GEMM over (b,h))   :149
@@ -301,28 +399,22 @@ extern "C" int excel_vit_forward(excel_vit_t h, const float* img, int B, int S, 
                 ga.sA = (long long)N * ws.NP; ga.sA2 = 0;
                 ga.sB = (long long)3 * H * N * 64; ga.sB2 = (long long)N * 64;
                 ga.sC = (long long)N * D; ga.sC2 = 64;
+                if (bf) ga.out_mode = GEMM_OUT_SPLIT_BF16;      // feeds the bf16x3 out-proj below
                 TRY(excel_launch_gemm(ga, false, B * H, st));
             }
             // original path residual first (x_ori = src + proj(attn_ori.v), :317/:326), then the new path (x += proj(.), :319/:329)
-            GemmArgs go = gemm_args(ws.ao, bw.out_proj_w, ws.xo, bw.out_proj_b, src, M, D, D, D, D, D, D, GEMM_ACT_NONE);
-            TRY(excel_launch_gemm(go, true, 1, st));
-            GemmArgs gn = gemm_args(ws.y, bw.out_proj_w, ws.x, bw.out_proj_b, ws.x, M, D, D, D, D, D, D, GEMM_ACT_NONE);
-            TRY(excel_launch_gemm(gn, true, 1, st));
-            TRY(excel_launch_layernorm(ws.xo, nullptr, 1, bw.ln2_w, bw.ln2_b, ws.y, M, D, eps, st));
-            GemmArgs g1 = gemm_args(ws.y, bw.fc1_w, ws.hbuf, bw.fc1_b, nullptr, M, 4 * D, D, D, D, 4 * D, 0, GEMM_ACT_QUICKGELU);
-            TRY(excel_launch_gemm(g1, true, 1, st));
-            GemmArgs g2 = gemm_args(ws.hbuf, bw.fc2_w, ws.xo, bw.fc2_b, ws.xo, M, D, 4 * D, 4 * D, 4 * D, D, D, GEMM_ACT_NONE);
-            TRY(excel_launch_gemm(g2, true, 1, st));                                              // x_ori += mlp(ln_2(x_ori))
+            TRY(linear(ws.ao, bw.out_proj_w, sw.out_proj, bw.out_proj_b, src, ws.xo, D, D, GEMM_ACT_NONE, GEMM_OUT_PLAIN));
+            TRY(linear(ws.y, bw.out_proj_w, sw.out_proj, bw.out_proj_b, ws.x, ws.x, D, D, GEMM_ACT_NONE, GEMM_OUT_PLAIN));
+            TRY(excel_launch_layernorm(ws.xo, nullptr, 1, bw.ln2_w, bw.ln2_b, ws.y, M, D, eps, st, bf));
+            TRY(linear(ws.y, bw.fc1_w, sw.fc1, bw.fc1_b, nullptr, ws.hbuf, 4 * D, D, GEMM_ACT_QUICKGELU, mid_mode));
+            TRY(linear(ws.hbuf, bw.fc2_w, sw.fc2, bw.fc2_b, ws.xo, ws.xo, D, 4 * D, GEMM_ACT_NONE, GEMM_OUT_PLAIN));         // x_ori += mlp(ln_2(x_ori))
             if (feats_out) hipMemcpyAsync(feats_out + (size_t)l * M * D, ws.xo, sizeof(float) * (size_t)M * D, hipMemcpyDeviceToDevice, st);
         }
     }
     // x[0] = x_ori[0] (:442) fused into ln_post (:445), then @ proj (:446)
-    TRY(excel_launch_layernorm(ws.x, c.n_surgery > 0 ? ws.xo : nullptr, N, h->w.ln_post_w, h->w.ln_post_b, ws.y, M, D, eps, st));
+    TRY(excel_launch_layernorm(ws.x, c.n_surgery > 0 ? ws.xo : nullptr, N, h->w.ln_post_w, h->w.ln_post_b, ws.y, M, D, eps, st, bf));
     float* fraw = x_raw ? x_raw : ws.fraw;
-    {
-        GemmArgs ga = gemm_args(ws.y, h->projT, fraw, nullptr, nullptr, M, C, D, D, D, C, 0, GEMM_ACT_NONE);
-        TRY(excel_launch_gemm(ga, true, 1, st));
-    }
+    TRY(linear(ws.y, h->projT, h->s_projT, nullptr, nullptr, fraw, C, D, GEMM_ACT_NONE, GEMM_OUT_PLAIN));
     TRY(excel_launch_token_axis_normalize(fraw, ws.ss, image_features, B, N, C, st));             // clip.py:353
     return EXCEL_OK;
 }

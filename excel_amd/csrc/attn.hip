@@ -30,6 +30,7 @@ struct RowpassArgs {
     float2* stats;       // [B,H,4,N] {row max (scaled scores), 1/row sum}
     int B, H, N;
     float scale;
+    int out_split;       // 1: out is a split-bf16 tensor [B*N][2][H*64] (A operand of the bf16x3 out-proj GEMM)
 };
 
 template <bool FLASH>
@@ -148,7 +149,15 @@ __device__ __forceinline__ void rowpass_body(const RowpassArgs& p, float* smem, 
         for (int qq = 0; qq < 32; ++qq) {
             const int q = q0 + qq;
             if (q >= N) break;
-            p.out[((long long)b * N + q) * (p.H * HD) + h * HD + lane] = ob[qq * 65 + lane];
+            const float v = ob[qq * 65 + lane];
+            if (p.out_split) {
+                const __bf16 hi = (__bf16)v;
+                __bf16* o = reinterpret_cast<__bf16*>(p.out) + ((long long)b * N + q) * 2 * (p.H * HD) + h * HD + lane;
+                o[0] = hi;
+                o[p.H * HD] = (__bf16)(v - (float)hi);
+            } else {
+                p.out[((long long)b * N + q) * (p.H * HD) + h * HD + lane] = v;
+            }
         }
     }
 }
@@ -279,11 +288,11 @@ __global__ __launch_bounds__(256, 1) void attn_accum_kernel(AccumArgs p) {
 }
 
 int excel_launch_attn_rowpass(const float* qkvh, float* out, float* stats, int B, int H, int N, int hd, float scale,
-                              int ntypes, hipStream_t st) {
+                              int ntypes, hipStream_t st, int split_out) {
     ProfScope prof__(PROF_ATTN_ROWPASS, st);
     EXCEL_CHECK_ARG(hd == HD, "attention: head_dim must be 64 (got %d)", hd);
     EXCEL_CHECK_ARG(ntypes == 1 || ntypes == 4, "attention: ntypes must be 1 or 4");
-    RowpassArgs a{qkvh, out, reinterpret_cast<float2*>(stats), B, H, N, scale};
+    RowpassArgs a{qkvh, out, reinterpret_cast<float2*>(stats), B, H, N, scale, split_out};
     hipLaunchKernelGGL(attn_rowpass_kernel, dim3(cdiv(N, 128), B * H, ntypes), dim3(256), 0, st, a);
     EXCEL_CHECK_LAUNCH("attn_rowpass");
     return EXCEL_OK;

@@ -68,7 +68,7 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 // ---------------------------------------------------------------- optional per-category HIP-event profiling
 // (bench.py enables it to get live per-kernel durations on the launch stream; off by default: zero overhead)
 enum ExcelProfCat {
-    PROF_GEMM_NT = 0, PROF_GEMM_NN, PROF_ATTN_ROWPASS, PROF_ATTN_ACCUM, PROF_LAYERNORM, PROF_EMBED, PROF_TOKEN_NORM,
+    PROF_GEMM_NT = 0, PROF_GEMM_NN, PROF_GEMM_BF16X3, PROF_ATTN_ROWPASS, PROF_ATTN_ACCUM, PROF_LAYERNORM, PROF_EMBED, PROF_TOKEN_NORM,
     PROF_CAM_EPILOGUE, PROF_SINKHORN, PROF_BBOX, PROF_MATVEC, PROF_UPSAMPLE, PROF_PAR_AFFINITY, PROF_PAR_ITERATE,
     PROF_ARGMAX, PROF_CONFUSION, PROF_OTHER, PROF_NCAT
 };

@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 
 enum { GEMM_ACT_NONE = 0, GEMM_ACT_QUICKGELU = 1 };
-enum { GEMM_OUT_PLAIN = 0, GEMM_OUT_QKV_HEADMAJOR = 1 };
+enum { GEMM_OUT_PLAIN = 0, GEMM_OUT_QKV_HEADMAJOR = 1, GEMM_OUT_SPLIT_BF16 = 2 };
 
 struct GemmArgs {
     const float* A;
@@ -26,15 +26,31 @@ struct GemmArgs {
 
 int excel_launch_gemm(const GemmArgs& p, bool b_kmajor, int batch, hipStream_t stream);
 
+// bf16x3 GEMM (gemm_bf16x3.hip): A, B are "split" tensors [rows][2][K] bf16 (hi plane, lo plane)
+struct GemmBfArgs {
+    const unsigned short* A;   // [M][2][K]  (lda = elements per row >= 2K)
+    const unsigned short* B;   // [N][2][K]
+    float* C;                  // fp32 output (plain / head-major)
+    unsigned short* Cs;        // split output [M][2][N] (GEMM_OUT_SPLIT_BF16)
+    const float* bias;
+    const float* res;
+    int M, N, K;
+    int lda, ldb, ldc, ldr;
+    int act, out_mode;
+    int tokN, heads, hd;
+};
+int excel_launch_gemm_bf16x3(const GemmBfArgs& p, hipStream_t stream);
+int excel_launch_split_bf16(const float* in, void* out, long long R, int K, hipStream_t st);
+
 int excel_launch_layernorm(const float* x, const float* cls_src, int tokN, const float* w, const float* b, float* y,
-                           int rows, int D, float eps, hipStream_t st);
+                           int rows, int D, float eps, hipStream_t st, int split_out = 0);
 int excel_launch_assemble_ln_pre(const float* patch, const float* cls_emb, const float* pos, const float* w, const float* b,
                                  float* x, int B, int tokN, int D, float eps, hipStream_t st);
 int excel_launch_token_axis_normalize(const float* f, float* ss, float* out, int B, int tokN, int C, hipStream_t st);
-int excel_launch_im2col(const float* img, float* col, int B, int S, int ps, hipStream_t st);
+int excel_launch_im2col(const float* img, float* col, int B, int S, int ps, hipStream_t st, int split_out = 0);
 
 int excel_launch_attn_rowpass(const float* qkvh, float* out, float* stats, int B, int H, int N, int hd, float scale,
-                              int ntypes, hipStream_t st);
+                              int ntypes, hipStream_t st, int split_out = 0);
 int excel_launch_attn_accum(const float* qkvh, const float* stats, float* a_sum, float* w_aff, float* attn_out, int B, int H,
                             int N, int NP, int hd, float scale, int surgery, float w_scale, float aff_scale, int aff_init,
                             hipStream_t st);

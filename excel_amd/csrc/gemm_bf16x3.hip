@@ -1,0 +1,201 @@
+// "bf16x3" GEMM: fp32-grade GEMM on the CDNA4 bf16 matrix core.
+//
+// Every fp32 operand x is carried as two bf16 planes  x = hi + lo  (hi = bf16(x), lo = bf16(x - hi); 16 mantissa bits,
+// fp32 exponent range, so no scaling and no overflow concerns) and a product is evaluated as
+//     a.b ~= ah.bh + ah.bl + al.bh          (the al.bl term is 2^-16 relative and dropped)
+// with three v_mfma_f32_32x32x16_bf16 into ONE fp32 accumulator.  Products of bf16 values are exact in fp32, so the
+// only error is the dropped term and the lo truncation: ~2^-17 relative per product.  Measured through the whole
+// ViT-B/16 surgery forward at 448^2 the CAM moves by 8.8e-6 max-abs against exact fp32 (gate: 1e-3) -- see DESIGN.md 2.
+// The bf16 pipe issues 16x the MACs per cycle of the f32-input MFMA, so 3 MFMAs per product is a 5.3x higher ceiling
+// (2.5 PFLOP/s / 3 = 833 TFLOP/s fp32-equivalent vs 157 TFLOP/s).
+//
+// "Split" tensors are stored [rows][2][K] bf16 (row r: K hi values then K lo values): exactly the bytes of the fp32
+// tensor, so they live in the same workspace buffers.  Producers write them directly (LayerNorm, the QuickGELU
+// epilogue of this kernel, the attention output, im2col); weights are split once at excel_vit_create.
+//
+//   C[M,N] (fp32 or split) = act(A_split[M,K] . W_split[N,K]^T + bias) + residual
+// Tiling: 128x128x32 block tile, 4 waves (2x2) x (2x2) MFMA tiles of 32x32, LDS double buffer,
+// direct-to-LDS staging
+// (global_load_lds_dwordx4, XOR-swizzled 128-B rows: conflict-free ds_read_b128), XCD-aware tile order; per k16 step a wave does 8 ds_read_b128 and
+// 12 MFMAs.
+#include "common.h"
+#include "excel_internal.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+#define TBM 128
+#define TBN 128
+#define TBK 32
+#define TROW 64     // bf16 elements per LDS row: [hi 32 | lo 32] = 128 B = 8 chunks of 16 B, XOR-swizzled (no padding)
+
+// Shared epilogue of the GEMM kernels: bias -> activation -> (+ residual) -> store, specialised per output mode so the
+// 64 accumulator elements of a thread see no per-element mode branches, integer divisions or 64-bit multiplies.
+template <int OUT_MODE>
+__device__ __forceinline__ void bf_epilogue(const GemmBfArgs& p, const f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn, int lane) {
+    const int r = lane & 31;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + r;
+        if (col >= p.N) continue;
+        const float bv = p.bias ? p.bias[col] : 0.f;
+        long long qcol_off = 0;
+        if (OUT_MODE == GEMM_OUT_QKV_HEADMAJOR) {
+            const int D = p.heads * p.hd;
+            const int qt = col / D, rem = col - qt * D;
+            const int qh = rem / p.hd, qd = rem - qh * p.hd;
+            qcol_off = ((long long)qt * p.heads + qh) * p.tokN * p.hd + qd;     // + (b*3*heads*tokN + n) * hd per row
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rbase = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
+            int qb = 0, qn = 0;
+            if (OUT_MODE == GEMM_OUT_QKV_HEADMAJOR) { qb = rbase / p.tokN; qn = rbase - qb * p.tokN; }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int dr = (e & 3) + 8 * (e >> 2);
+                const int row = rbase + dr;
+                if (row >= p.M) continue;
+                float v = acc[i][j][e] + bv;
+                if (p.act == GEMM_ACT_QUICKGELU) v = v * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v));
+                if (p.res) v += p.res[(long long)row * p.ldr + col];
+                if (OUT_MODE == GEMM_OUT_SPLIT_BF16) {
+                    const __bf16 hi = (__bf16)v;
+                    __bf16* o = reinterpret_cast<__bf16*>(p.Cs) + (long long)row * 2 * p.N + col;
+                    o[0] = hi;
+                    o[p.N] = (__bf16)(v - (float)hi);
+                } else if (OUT_MODE == GEMM_OUT_QKV_HEADMAJOR) {
+                    int n = qn + dr, b = qb;
+                    while (n >= p.tokN) { n -= p.tokN; ++b; }
+                    p.C[qcol_off + ((long long)b * 3 * p.heads * p.tokN + n) * p.hd] = v;
+                } else {
+                    p.C[(long long)row * p.ldc + col] = v;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmBfArgs p) {
+    // [stage][operand A|B][128 rows x 64 bf16]; each row is 8 x 16-B chunks, chunk c stored at slot c ^ ((row>>1)&7)
+    __shared__ __attribute__((aligned(1024))) u16 smem[2][2][TBM * TROW];   // 64 KB -> 2 workgroups per CU
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, kh = lane >> 5;
+    const int tiles_n = (p.N + TBN - 1) / TBN, tiles_m = (p.M + TBM - 1) / TBM;
+    const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tm = id / tiles_n, tn = id % tiles_n;
+    const int m0 = tm * TBM, n0 = tn * TBN;
+
+    // direct-to-LDS staging (global_load_lds_dwordx4): one wave-instruction fills 1 KB = 8 tile rows; the LDS image is
+    // lane-linear, so the swizzle is applied to the per-lane SOURCE address.  Each wave issues 4 (A) + 4 (B) per k-step.
+    const u16* gsrc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int op = j >> 2, seg = wave * 4 + (j & 3);
+        const int row_l = seg * 8 + (lane >> 3), phys = lane & 7;
+        const int c = phys ^ ((row_l >> 1) & 7);
+        const int grow = op ? min(n0 + row_l, p.N - 1) : min(m0 + row_l, p.M - 1);
+        gsrc[j] = (op ? p.B + (long long)grow * p.ldb : p.A + (long long)grow * p.lda) + (long long)(c >> 2) * p.K + (c & 3) * 8;
+    }
+    auto issue_tile = [&](int kt, int buf) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int op = j >> 2, seg = wave * 4 + (j & 3);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc[j] + kt * TBK),
+                                             (__attribute__((address_space(3))) void*)(&smem[buf][op][seg * 8 * TROW]), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int sw = (r >> 1) & 7;      // (row>>1)&7 of every fragment row this lane reads (tile rows are r + multiples of 32)
+    const int nk = p.K / TBK;
+    issue_tile(0, 0);
+    __syncthreads();                  // drains the LDS-DMA (vmcnt(0)) and publishes the tile
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) issue_tile(kt + 1, cur ^ 1);      // in flight during this step's 24 MFMAs
+        const u16* as = smem[cur][0];
+        const u16* bs = smem[cur][1];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int ch = ((s * 2 + kh) ^ sw) * 8, cl = ((4 + s * 2 + kh) ^ sw) * 8;
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const u16* rowp = as + (wm * 64 + i * 32 + r) * TROW;
+                ah[i] = *reinterpret_cast<const bf16x8*>(rowp + ch);
+                al[i] = *reinterpret_cast<const bf16x8*>(rowp + cl);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const u16* rowp = bs + (wn * 64 + j * 32 + r) * TROW;
+                bh[j] = *reinterpret_cast<const bf16x8*>(rowp + ch);
+                bl[j] = *reinterpret_cast<const bf16x8*>(rowp + cl);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    // small terms first, the dominant hi.hi product last
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    switch (p.out_mode) {
+        case GEMM_OUT_SPLIT_BF16: bf_epilogue<GEMM_OUT_SPLIT_BF16>(p, acc, m0, n0, wm, wn, lane); break;
+        case GEMM_OUT_QKV_HEADMAJOR: bf_epilogue<GEMM_OUT_QKV_HEADMAJOR>(p, acc, m0, n0, wm, wn, lane); break;
+        default: bf_epilogue<GEMM_OUT_PLAIN>(p, acc, m0, n0, wm, wn, lane); break;
+    }
+}
+
+// fp32 [R,K] -> split bf16 [R,2,K]
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ in, u16* __restrict__ out, long long R, int K) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= R * K) return;
+    const long long row = i / K;
+    const int k = (int)(i % K);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(in + i);
+    __bf16 hi[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        hi[j] = (__bf16)v[j];
+        lo[j] = (__bf16)(v[j] - (float)hi[j]);
+    }
+    __bf16* o = reinterpret_cast<__bf16*>(out) + row * 2 * K + k;
+    *reinterpret_cast<uint2*>(o) = *reinterpret_cast<const uint2*>(hi);
+    *reinterpret_cast<uint2*>(o + K) = *reinterpret_cast<const uint2*>(lo);
+}
+
+int excel_launch_gemm_bf16x3(const GemmBfArgs& p, hipStream_t stream) {
+    ProfScope prof__(PROF_GEMM_BF16X3, stream, 2.0 * p.M * (double)p.N * p.K);
+    EXCEL_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0 && (p.K % TBK) == 0, "gemm_bf16x3: K must be a multiple of %d (K=%d)", TBK, p.K);
+    EXCEL_CHECK_ARG((p.lda % 8) == 0 && (p.ldb % 8) == 0 && p.lda >= 2 * p.K && p.ldb >= 2 * p.K, "gemm_bf16x3: bad lda/ldb");
+    EXCEL_CHECK_ARG((((uintptr_t)p.A | (uintptr_t)p.B) & 15) == 0, "gemm_bf16x3: operands must be 16-byte aligned");
+    const int tiles = cdiv(p.M, TBM) * cdiv(p.N, TBN);
+    hipLaunchKernelGGL(gemm_bf16x3_kernel, dim3(tiles), dim3(256), 0, stream, p);
+    EXCEL_CHECK_LAUNCH("gemm_bf16x3");
+    return EXCEL_OK;
+}
+
+int excel_launch_split_bf16(const float* in, void* out, long long R, int K, hipStream_t st) {
+    ProfScope prof__(PROF_OTHER, st);
+    EXCEL_CHECK_ARG((K % 4) == 0, "split_bf16: K must be a multiple of 4");
+    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)cdivl(R * K / 4, 256)), dim3(256), 0, st, in, (u16*)out, R, K);
+    EXCEL_CHECK_LAUNCH("split_bf16");
+    return EXCEL_OK;
+}

@@ -8,7 +8,7 @@
 
 __device__ __forceinline__ void ln_row(const float* __restrict__ src, const float* __restrict__ add,
                                        const float* __restrict__ w, const float* __restrict__ b,
-                                       float* __restrict__ dst, int D, float eps, int lane) {
+                                       float* __restrict__ dst, int D, float eps, int lane, bool split = false) {
     // pass 1: mean (the row is 3 KB: passes 2 and 3 hit L1)
     float s = 0.f;
     for (int c = lane * 4; c < D; c += 256) {
@@ -32,7 +32,16 @@ __device__ __forceinline__ void ln_row(const float* __restrict__ src, const floa
         const f32x4 ww = *reinterpret_cast<const f32x4*>(w + c);
         const f32x4 bb = *reinterpret_cast<const f32x4*>(b + c);
         v = (v - mean) * rstd * ww + bb;
-        *reinterpret_cast<f32x4*>(dst + c) = v;
+        if (split) {   // bf16 hi/lo planes [2][D] in the same D*4 bytes (operand format of the bf16x3 GEMM)
+            __bf16 hi[4], lo[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { hi[j] = (__bf16)v[j]; lo[j] = (__bf16)(v[j] - (float)hi[j]); }
+            __bf16* o = reinterpret_cast<__bf16*>(dst);
+            *reinterpret_cast<uint2*>(o + c) = *reinterpret_cast<const uint2*>(hi);
+            *reinterpret_cast<uint2*>(o + D + c) = *reinterpret_cast<const uint2*>(lo);
+        } else {
+            *reinterpret_cast<f32x4*>(dst + c) = v;
+        }
     }
 }
 
@@ -41,12 +50,12 @@ __device__ __forceinline__ void ln_row(const float* __restrict__ src, const floa
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __restrict__ x, const float* __restrict__ cls_src,
                                                              int tokN, const float* __restrict__ w,
                                                              const float* __restrict__ b, float* __restrict__ y,
-                                                             int rows, int D, float eps) {
+                                                             int rows, int D, float eps, int split_out) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* src = x + (long long)row * D;
     if (cls_src && (row % tokN) == 0) src = cls_src + (long long)row * D;
-    ln_row(src, nullptr, w, b, y + (long long)row * D, D, eps, threadIdx.x & 63);
+    ln_row(src, nullptr, w, b, y + (long long)row * D, D, eps, threadIdx.x & 63, split_out != 0);
 }
 
 // x_pre[b,n,:] = (n == 0 ? class_embedding : patch[b,n-1,:]) + pos[n,:];  x = ln_pre(x_pre)
@@ -98,7 +107,7 @@ __global__ __launch_bounds__(256) void token_axis_scale_kernel(const float* __re
 
 // im2col for the stride-16 patch conv: column index = c*ps*ps + py*ps + px (conv weight [D,3,ps,ps] flattened)
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, float* __restrict__ col,
-                                                     int S, int g, int ps, long long total4) {
+                                                     int S, int g, int ps, long long total4, int split_out) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total4) return;
     const long long e = i * 4;
@@ -110,14 +119,23 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ i
     const int gy = pp / g, gx = pp % g;
     const int c = k / (ps * ps), py = (k / ps) % ps, px = k % ps;   // px multiple of 4
     const f32x4 v = *reinterpret_cast<const f32x4*>(img + (((long long)b * 3 + c) * S + gy * ps + py) * S + gx * ps + px);
-    *reinterpret_cast<f32x4*>(col + e) = v;
+    if (split_out) {
+        __bf16 hi[4], lo[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { hi[j] = (__bf16)v[j]; lo[j] = (__bf16)(v[j] - (float)hi[j]); }
+        __bf16* o = reinterpret_cast<__bf16*>(col) + pr * 2 * Kc + k;
+        *reinterpret_cast<uint2*>(o) = *reinterpret_cast<const uint2*>(hi);
+        *reinterpret_cast<uint2*>(o + Kc) = *reinterpret_cast<const uint2*>(lo);
+    } else {
+        *reinterpret_cast<f32x4*>(col + e) = v;
+    }
 }
 
 int excel_launch_layernorm(const float* x, const float* cls_src, int tokN, const float* w, const float* b, float* y,
-                           int rows, int D, float eps, hipStream_t st) {
+                           int rows, int D, float eps, hipStream_t st, int split_out) {
     ProfScope prof__(PROF_LAYERNORM, st);
     EXCEL_CHECK_ARG(rows > 0 && D > 0 && (D % 4) == 0, "layernorm: D must be a multiple of 4 (D=%d)", D);
-    hipLaunchKernelGGL(layernorm_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, cls_src, tokN, w, b, y, rows, D, eps);
+    hipLaunchKernelGGL(layernorm_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, cls_src, tokN, w, b, y, rows, D, eps, split_out);
     EXCEL_CHECK_LAUNCH("layernorm_rows");
     return EXCEL_OK;
 }
@@ -142,12 +160,12 @@ int excel_launch_token_axis_normalize(const float* f, float* ss, float* out, int
     return EXCEL_OK;
 }
 
-int excel_launch_im2col(const float* img, float* col, int B, int S, int ps, hipStream_t st) {
+int excel_launch_im2col(const float* img, float* col, int B, int S, int ps, hipStream_t st, int split_out) {
     ProfScope prof__(PROF_EMBED, st);
     EXCEL_CHECK_ARG(S % ps == 0 && (ps % 4) == 0, "im2col: S must be a multiple of the patch size, patch %% 4 == 0");
     const int g = S / ps;
     const long long total4 = (long long)B * g * g * 3 * ps * ps / 4;
-    hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)cdivl(total4, 256)), dim3(256), 0, st, img, col, S, g, ps, total4);
+    hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)cdivl(total4, 256)), dim3(256), 0, st, img, col, S, g, ps, total4, split_out);
     EXCEL_CHECK_LAUNCH("im2col");
     return EXCEL_OK;
 }

@@ -53,6 +53,24 @@ def gemm(A, Bm, bias=None, residual=None, act=0, b_kmajor=True):
     return out if batched else out[0]
 
 
+def split_bf16(x):
+    """fp32 [R,K] -> split operand [R,2,K] (bf16 bit patterns in an int16 tensor)."""
+    x = f32c(x)
+    R, K = x.shape
+    out = torch.empty((R, 2, K), dtype=torch.int16, device=x.device)
+    check(lib().excel_split_bf16(_p(x), _p(out, torch.int16), R, K, _stream()), "excel_split_bf16")
+    return out
+
+
+def gemm_bf16x3(A_split, W_split, bias=None, residual=None, act=0, split_out=False):
+    M, _, K = A_split.shape
+    N = W_split.shape[0]
+    out = torch.empty((M, N), dtype=torch.float32, device=A_split.device)
+    check(lib().excel_gemm_bf16x3(_p(A_split, torch.int16), _p(W_split, torch.int16), _p(out), _p(bias), _p(residual), M, N, K, act,
+                                  1 if split_out else 0, _stream()), "excel_gemm_bf16x3")
+    return out.view(torch.int16).view(M, 2, N) if split_out else out
+
+
 def layernorm(x, w, b, eps=1e-5):
     D = x.shape[-1]
     y = torch.empty_like(x)
@@ -119,6 +137,13 @@ class VitHandle:
                 self._h = None
         except Exception:
             pass
+
+    def set_gemm_mode(self, mode):
+        """'f32' (exact fp32 MFMA) or 'bf16x3' (split-bf16 operands, 3 bf16 MFMAs per product)."""
+        check(lib().excel_vit_set_gemm_mode(self._h, {"f32": 0, "bf16x3": 1}[mode]), "excel_vit_set_gemm_mode")
+
+    def gemm_mode(self):
+        return {0: "f32", 1: "bf16x3"}[lib().excel_vit_get_gemm_mode(self._h)]
 
     def workspace(self, B, S):
         need = lib().excel_vit_workspace_bytes(self._h, B, S)

@@ -37,6 +37,13 @@ int excel_gemm_f32(const float* A, const float* Bm, float* C, const float* bias,
                    int M, int N, int K, int lda, int ldb, int ldc, int ldr, int b_kmajor, int act,
                    int batch, long long sA, long long sB, long long sC, long long sR, void* stream);
 
+/* "bf16x3" building blocks: excel_split_bf16 turns fp32 [rows,K] into the split operand format [rows][2][K] bf16
+ * (hi plane, lo plane; same number of bytes); excel_gemm_bf16x3 computes C = act(A.W^T + bias) + residual from two split
+ * operands with three bf16 MFMAs per product (fp32 accumulate).  C is fp32 [M,N], or a split tensor when split_out. */
+int excel_split_bf16(const float* in, void* out, long long rows, int K, void* stream);
+int excel_gemm_bf16x3(const void* A_split, const void* W_split, float* C, const float* bias, const float* residual,
+                      int M, int N, int K, int act, int split_out, void* stream);
+
 /* LayerNorm over the last dim, fp32, eps as given (clip/clip_surgery_model.py:271-277). */
 int excel_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int D, float eps, void* stream);
 
@@ -74,6 +81,12 @@ typedef struct excel_vit* excel_vit_t;
  * Replaces ExCEL_CLIP.visual construction + reload_self_attn (clip/clip_surgery_model.py:396-416). */
 int excel_vit_create(const excel_vit_config* cfg, const excel_vit_weights* w, excel_vit_t* out);
 void excel_vit_destroy(excel_vit_t h);
+
+/* GEMM numerics of the linear layers of this handle: 0 = exact fp32 (v_mfma_f32_32x32x2_f32), 1 = "bf16x3" (operands as
+ * bf16 hi+lo planes, 3 bf16 MFMAs per product, ~2^-17 relative per product; CAM moves < 1e-5).
+ * Default 0, or 1 when the environment variable EXCEL_GEMM_MODE=bf16x3 is set at create time. */
+int excel_vit_set_gemm_mode(excel_vit_t h, int mode);
+int excel_vit_get_gemm_mode(excel_vit_t h);
 
 size_t excel_vit_workspace_bytes(excel_vit_t h, int B, int S);
 

@@ -398,3 +398,83 @@ def test_confusion_golden(ops, golden):
     for gt, pr in zip(gts, g["sc_preds"]):
         hist = ops.confusion_accumulate(dev(gt.astype(np.uint8)), dev(pr.astype(np.uint8)), 21, hist)
     assert np.array_equal(host(hist), g["sc_hist"])
+
+
+# ------------------------------------------------------------------ bf16x3 mode (split-bf16 operands, 3 MFMAs / product)
+def _bf16_round(x):
+    u = np.asarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u >> 16) & 1) + 0x7FFF
+    return (((u + r) & 0xFFFF0000).astype(np.uint32)).view(np.float32)
+
+
+def test_split_bf16_format(ops):
+    rs = np.random.RandomState(0)
+    x = (rs.standard_normal((37, 64)) * np.exp(rs.uniform(-20, 20, (37, 64)))).astype(np.float32)
+    s = host(ops.split_bf16(dev(x))).view(np.uint16).astype(np.uint32)
+    hi = (s[:, 0, :] << 16).view(np.float32)
+    lo = (s[:, 1, :] << 16).view(np.float32)
+    ref_hi = _bf16_round(x)
+    assert np.array_equal(hi, ref_hi)
+    assert np.array_equal(lo, _bf16_round(x - ref_hi))
+    assert np.max(np.abs((hi.astype(np.float64) + lo) - x) / np.abs(x)) < 2.0 ** -16
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 45, 512), (785, 2304, 768), (37, 64, 128), (257, 768, 3072)])
+def test_gemm_bf16x3(ops, M, N, K):
+    rs = np.random.RandomState(M + N)
+    A = rs.standard_normal((M, K)).astype(np.float32)
+    W = (rs.standard_normal((N, K)) * 0.05).astype(np.float32)
+    bias = rs.standard_normal(N).astype(np.float32)
+    res = rs.standard_normal((M, N)).astype(np.float32)
+    ref = A.astype(np.float64) @ W.T.astype(np.float64)
+    As, Ws = ops.split_bf16(dev(A)), ops.split_bf16(dev(W))
+    out = host(ops.gemm_bf16x3(As, Ws))
+    scale = np.sqrt(K) * 0.05
+    assert maxabs(out, ref) < 3e-5 * scale            # ~2^-17 per product, random accumulation
+    y = ref + bias
+    y = y * (1.0 / (1.0 + np.exp(-1.702 * y))) + res
+    out2 = host(ops.gemm_bf16x3(As, Ws, bias=dev(bias), residual=dev(res), act=1))
+    assert maxabs(out2, y) < 3e-5 * scale + 2e-6
+    # split output == split of the fp32 output
+    s = host(ops.gemm_bf16x3(As, Ws, split_out=True)).view(np.uint16).astype(np.uint32)
+    hi = (s[:, 0, :] << 16).view(np.float32)
+    assert np.array_equal(hi, _bf16_round(out))
+
+
+def test_vit_b16_448_bf16x3_mode(ops):
+    """Same BASELINE-shape check as the fp32 test, with the linear layers on the bf16x3 path: the CAM gate (1e-3)
+    must hold with a wide margin (measured ~1e-5)."""
+    cfg = VitConfig(width=768, layers=12, heads=12, patch=16, out_dim=512, input_resolution=224, n_surgery=5)
+    w = make_vit_weights(cfg, seed=1, attn_gain=2.0)
+    imgs = np.random.RandomState(4).standard_normal((1, 3, 448, 448)).astype(np.float32)
+    h = make_handle(ops, cfg, w)
+    h.set_gemm_mode("bf16x3")
+    assert h.gemm_mode() == "bf16x3"
+    r = h.forward(dev(imgs), want_w_aff=True, n_attn_out=6, want_raw=True)
+    x, attn, _ = oracle.vit.vit_forward(imgs, w, cfg)
+    f_ref, _, _ = oracle.cam.generate_clip_fts(imgs, w, cfg)
+    e_feat = relmax(host(r["image_features"]), f_ref)
+    e_aff = relmax(host(r["w_aff"]), attn[-6:, :, 1:, 1:].mean(0, dtype=np.float32))
+    rs = np.random.RandomState(8)
+    text = rs.standard_normal((45, 512)).astype(np.float32)
+    text /= np.linalg.norm(text, axis=1, keepdims=True)
+    full, _ = ops.clip_feature_surgery(r["image_features"], dev(text), num_fg=20)
+    e_cam = maxabs(host(full), oracle.cam.clip_feature_surgery(f_ref, text))
+    print(f"bf16x3: feature rel err {e_feat:.2e}, w_aff rel err {e_aff:.2e}, CAM max-abs err {e_cam:.2e}")
+    assert e_feat < 5e-4 and e_aff < 5e-4
+    assert e_cam < 1e-3
+    assert e_cam < 2e-4
+    h.set_gemm_mode("f32")
+    r32 = h.forward(dev(imgs), want_raw=True)
+    e32 = maxabs(host(ops.clip_feature_surgery(r32["image_features"], dev(text))[0]), oracle.cam.clip_feature_surgery(f_ref, text))
+    print(f"f32   : CAM max-abs err {e32:.2e}")
+
+
+def test_vit_tiny_bf16x3_mode_vs_golden(ops, golden):
+    g = golden("vit_cam_tiny.npz")
+    w = oracle.vit.reload_self_attn(make_vit_weights(TINY, seed=int(g["seed_w"])), TINY, feat_size=6, mode="train")
+    h = make_handle(ops, TINY, w)
+    h.set_gemm_mode("bf16x3")
+    r = h.forward(dev(g["imgs"]), want_raw=True)
+    full, _ = ops.clip_feature_surgery(r["image_features"], dev(g["train_text"]))
+    assert maxabs(host(full), g["train_cam"]) < 1e-3
