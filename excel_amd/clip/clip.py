@@ -60,7 +60,7 @@ def clip_feature_surgery(image_features, text_features, redundant_feats=None, t=
 
 
 def load(name, device="cuda", state_dict=None, width=768, layers=12, heads=12, patch=16, output_dim=512,
-         input_resolution=224):
+         input_resolution=224, gemm_mode=None):
     """clip.load("ExCEL_ViT-B/16") counterpart: builds the visual tower from a state_dict whose keys follow the
     reference ("visual.conv1.weight" ... or without the "visual." prefix).  Returns (model, None)."""
     if state_dict is None:
@@ -68,5 +68,6 @@ def load(name, device="cuda", state_dict=None, width=768, layers=12, heads=12, p
     sd = {}
     for k, v in state_dict.items():
         sd[k[len("visual."):] if k.startswith("visual.") else k] = v
-    vis = VisionTransformer(input_resolution, patch, width, layers, heads, output_dim, state_dict=sd, device=device)
+    vis = VisionTransformer(input_resolution, patch, width, layers, heads, output_dim, state_dict=sd, device=device,
+                            gemm_mode=gemm_mode)
     return ExCEL_CLIP(vis), None

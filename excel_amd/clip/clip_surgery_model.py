@@ -12,7 +12,8 @@ from .. import ops
 class VisionTransformer:
     """VisionTransformer(input_resolution, patch_size, width, layers, heads, output_dim)  (:375)"""
 
-    def __init__(self, input_resolution, patch_size, width, layers, heads, output_dim, state_dict=None, device="cuda"):
+    def __init__(self, input_resolution, patch_size, width, layers, heads, output_dim, state_dict=None, device="cuda",
+                 gemm_mode=None):
         self.input_resolution = input_resolution
         self.patch_size = patch_size
         self.embed_dim = width
@@ -21,6 +22,7 @@ class VisionTransformer:
         self.output_dim = output_dim
         self.device = device
         self.n_surgery = 0
+        self.gemm_mode = gemm_mode
         self._sd = dict(state_dict) if state_dict is not None else None
         self._handle = None
         self.attn = None
@@ -51,7 +53,7 @@ class VisionTransformer:
             if self._sd is None:
                 raise RuntimeError("VisionTransformer has no weights (load_state_dict first)")
             self._handle = ops.VitHandle(self._sd, self.embed_dim, self.layers, self.num_heads, self.patch_size,
-                                         self.output_dim, n_surgery=self.n_surgery, device=self.device)
+                                         self.output_dim, n_surgery=self.n_surgery, device=self.device, gemm_mode=self.gemm_mode)
         return self._handle
 
     @torch.no_grad()

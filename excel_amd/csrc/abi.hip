@@ -271,7 +271,7 @@ extern "C" void excel_vit_destroy(excel_vit_t h) {
 }
 
 struct VitWs {
-    float *x, *xo, *y, *ao, *qkvh, *hbuf, *stats, *a_sum, *fraw, *ss;
+    float *x, *xo, *y, *ao, *qkvh, *qkvs, *hbuf, *stats, *a_sum, *fraw, *ss;
     int NP;
     size_t total;
 };
@@ -288,6 +288,7 @@ static VitWs vit_ws_layout(const excel_vit_config& c, int B, int S, char* base) 
     w.y = take(M * D);
     w.ao = take(M * D);                   // also the patch-embed GEMM output [B*P, D]
     w.qkvh = take(M * 3 * D);
+    w.qkvs = take(M * 3 * D);             // split-bf16 copy of q|k|v for the bf16x3 attention scores (bf16x3 mode)
     {   // MLP hidden [M,4D]; also holds the im2col matrix [B*P, 3*ps*ps]
         const size_t col = (size_t)B * (N - 1) * 3 * c.patch * c.patch;
         w.hbuf = take(M * 4 * D > col ? M * 4 * D : col);
@@ -358,7 +359,7 @@ extern "C" int excel_vit_forward(excel_vit_t h, const float* img, int B, int S, 
                       int Nout, int K, int act, int out_mode) -> int {
         if (bf) {
             GemmBfArgs ga = gemm_bf_args(A, Ws, Cout, Cout, bias, res, M, Nout, K, Nout, Nout, act, out_mode);
-            if (out_mode == GEMM_OUT_QKV_HEADMAJOR) { ga.tokN = N; ga.heads = H; ga.hd = 64; }
+            if (out_mode == GEMM_OUT_QKV_HEADMAJOR) { ga.tokN = N; ga.heads = H; ga.hd = 64; ga.qkv_split = (unsigned short*)ws.qkvs; }
             return excel_launch_gemm_bf16x3(ga, st);
         }
         GemmArgs ga = gemm_args(A, Wf, Cout, bias, res, M, Nout, K, K, K, Nout, Nout, act);
@@ -376,13 +377,14 @@ extern "C" int excel_vit_forward(excel_vit_t h, const float* img, int B, int S, 
         float* src = (surgery && l > first_surgery) ? ws.xo : ws.x;   // :315 vs :323
         TRY(excel_launch_layernorm(src, nullptr, 1, bw.ln1_w, bw.ln1_b, ws.y, M, D, eps, st, bf));
         TRY(linear(ws.y, bw.in_proj_w, sw.in_proj, bw.in_proj_b, nullptr, ws.qkvh, 3 * D, D, GEMM_ACT_NONE, GEMM_OUT_QKV_HEADMAJOR));
-        TRY(excel_launch_attn_rowpass(ws.qkvh, ws.ao, ws.stats, B, H, N, 64, scale, surgery ? 4 : 1, st, bf));
+        const unsigned short* qkvs = bf ? (const unsigned short*)ws.qkvs : nullptr;
+        TRY(excel_launch_attn_rowpass(ws.qkvh, ws.ao, ws.stats, B, H, N, 64, scale, surgery ? 4 : 1, st, bf, qkvs));
         const bool in_aff = w_aff && l >= L - aff_layers;
         float* attn_l = (n_attn_out && l >= L - n_attn_out) ? attn_out + (size_t)(l - (L - n_attn_out)) * B * N * N : nullptr;
         if (surgery || in_aff || attn_l) {
             TRY(excel_launch_attn_accum(ws.qkvh, ws.stats, surgery ? ws.a_sum : nullptr, in_aff ? w_aff : nullptr, attn_l, B, H, N,
                                         ws.NP, 64, scale, surgery ? 1 : 0, surgery ? 1.f : 1.f / (float)H, 1.f / (float)aff_layers,
-                                        (l == L - aff_layers) ? 1 : 0, st));
+                                        (l == L - aff_layers) ? 1 : 0, st, qkvs));
         }
         if (!surgery) {
             TRY(linear(ws.ao, bw.out_proj_w, sw.out_proj, bw.out_proj_b, ws.x, ws.x, D, D, GEMM_ACT_NONE, GEMM_OUT_PLAIN));   // x += out_proj(attn)

@@ -31,9 +31,16 @@ struct RowpassArgs {
     int B, H, N;
     float scale;
     int out_split;       // 1: out is a split-bf16 tensor [B*N][2][H*64] (A operand of the bf16x3 out-proj GEMM)
+    const unsigned short* qkvs;   // bf16x3 scores: q|k|v head-major in split format [B,3,H,N][2][64] (null = exact fp32 scores)
 };
 
-template <bool FLASH>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+// BF = true: the score products run as bf16x3 (3 x v_mfma_f32_32x32x16_bf16 on split-bf16 q/k/v, see gemm_bf16x3.hip);
+// the softmax and the P.V product stay fp32.  Score tiles keep the same accumulator layout, so everything downstream
+// of the MFMAs is shared with the exact-fp32 path.
+template <bool FLASH, bool BF>
 __device__ __forceinline__ void rowpass_body(const RowpassArgs& p, float* smem, int b, int h, int type, int qblk) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, kh = lane >> 5;
@@ -51,8 +58,20 @@ __device__ __forceinline__ void rowpass_body(const RowpassArgs& p, float* smem, 
     const int q0 = qblk * 128 + wave * 32;
     const int qrow = min(q0 + r, N - 1);
     f32x4 xf[8];
+    bf16x8 xh[4], xl[4];
+    const u16* Ysp = nullptr;
+    if (BF) {
+        const u16* Xsp = p.qkvs + (((long long)b * 3 + tx) * p.H + h) * (long long)N * 128;
+        Ysp = p.qkvs + (((long long)b * 3 + ty) * p.H + h) * (long long)N * 128;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) xf[c] = *reinterpret_cast<const f32x4*>(X + (long long)qrow * HD + c * 8 + kh * 4);
+        for (int s4 = 0; s4 < 4; ++s4) {
+            xh[s4] = *reinterpret_cast<const bf16x8*>(Xsp + (long long)qrow * 128 + s4 * 16 + kh * 8);
+            xl[s4] = *reinterpret_cast<const bf16x8*>(Xsp + (long long)qrow * 128 + 64 + s4 * 16 + kh * 8);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) xf[c] = *reinterpret_cast<const f32x4*>(X + (long long)qrow * HD + c * 8 + kh * 4);
+    }
 
     float m = -INFINITY, l = 0.f;
     f32x16 oT[2];
@@ -66,7 +85,8 @@ __device__ __forceinline__ void rowpass_body(const RowpassArgs& p, float* smem, 
         for (int i = 0; i < 2; ++i) {
             const int idx = tid + 256 * i;
             const int row = min(kt * 32 + (idx >> 4), N - 1), c4 = idx & 15;
-            rk[i] = *reinterpret_cast<const f32x4*>(Y + (long long)row * HD + c4 * 4);
+            if (BF) rk[i] = *reinterpret_cast<const f32x4*>(Ysp + (long long)row * 128 + c4 * 8);   // 16-B chunk c4 of [hi 64 | lo 64]
+            else rk[i] = *reinterpret_cast<const f32x4*>(Y + (long long)row * HD + c4 * 4);
             if (FLASH) rv[i] = *reinterpret_cast<const f32x4*>(V + (long long)row * HD + c4 * 4);
         }
     };
@@ -75,7 +95,10 @@ __device__ __forceinline__ void rowpass_body(const RowpassArgs& p, float* smem, 
         for (int i = 0; i < 2; ++i) {
             const int idx = tid + 256 * i;
             const int row = idx >> 4, c4 = idx & 15;
-            *reinterpret_cast<f32x4*>(&Ks[buf * 32 * KP + row * KP + c4 * 4]) = rk[i];
+            if (BF)   // 256-B rows of 16 chunks, chunk c at slot c ^ (row & 15): conflict-free ds_read_b128 without padding
+                *reinterpret_cast<f32x4*>(reinterpret_cast<u16*>(Ks) + buf * 32 * 128 + row * 128 + ((c4 ^ (row & 15)) * 8)) = rk[i];
+            else
+                *reinterpret_cast<f32x4*>(&Ks[buf * 32 * KP + row * KP + c4 * 4]) = rk[i];
             if (FLASH) *reinterpret_cast<f32x4*>(&Vs[buf * 32 * 64 + row * 64 + c4 * 4]) = rv[i];
         }
     };
@@ -91,11 +114,23 @@ __device__ __forceinline__ void rowpass_body(const RowpassArgs& p, float* smem, 
         f32x16 s;
 #pragma unroll
         for (int e = 0; e < 16; ++e) s[e] = 0.f;
+        if (BF) {
+            const u16* kr = reinterpret_cast<const u16*>(Ks) + cur * 32 * 128 + r * 128;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const f32x4 yf = *reinterpret_cast<const f32x4*>(&ks[r * KP + c * 8 + kh * 4]);
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const bf16x8 yh = *reinterpret_cast<const bf16x8*>(kr + (((s4 * 2 + kh) ^ (r & 15)) * 8));
+                const bf16x8 yl = *reinterpret_cast<const bf16x8*>(kr + (((8 + s4 * 2 + kh) ^ (r & 15)) * 8));
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl, xh[s4], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh, xl[s4], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh, xh[s4], s, 0, 0, 0);
+            }
+        } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(yf[e], xf[c][e], s, 0, 0, 0);
+            for (int c = 0; c < 8; ++c) {
+                const f32x4 yf = *reinterpret_cast<const f32x4*>(&ks[r * KP + c * 8 + kh * 4]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(yf[e], xf[c][e], s, 0, 0, 0);
+            }
         }
         float mx = -INFINITY;
 #pragma unroll
@@ -167,10 +202,13 @@ __global__ __launch_bounds__(256, 2) void attn_rowpass_kernel(RowpassArgs p) {
     const int bh = blockIdx.y;
     const int b = bh / p.H, h = bh % p.H;
     const int type = blockIdx.z;
-    if (type == 0)
-        rowpass_body<true>(p, smem, b, h, 0, blockIdx.x);
-    else
-        rowpass_body<false>(p, smem, b, h, type, blockIdx.x);
+    if (p.qkvs) {
+        if (type == 0) rowpass_body<true, true>(p, smem, b, h, 0, blockIdx.x);
+        else rowpass_body<false, true>(p, smem, b, h, type, blockIdx.x);
+    } else {
+        if (type == 0) rowpass_body<true, false>(p, smem, b, h, 0, blockIdx.x);
+        else rowpass_body<false, false>(p, smem, b, h, type, blockIdx.x);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ accum
@@ -185,12 +223,13 @@ struct AccumArgs {
     float w_scale;        // 1/H for nn.MultiheadAttention blocks (head-mean), 1 for surgery blocks (head-sum)
     float aff_scale;      // 1/attn_layers
     int aff_init;         // 1: w_aff = ..., 0: w_aff += ...
+    const unsigned short* qkvs;   // split-bf16 q|k|v for bf16x3 scores (null = exact fp32)
 };
 
-template <bool SURGERY>
+template <bool SURGERY, bool BF>
 __global__ __launch_bounds__(256, 1) void attn_accum_kernel(AccumArgs p) {
     constexpr int NT = SURGERY ? 6 : 2;
-    __shared__ __attribute__((aligned(16))) float tiles[NT * 64 * KP];   // 104,448 B / 34,816 B
+    __shared__ __attribute__((aligned(16))) float tiles[NT * 64 * KP];   // 104,448 B / 34,816 B (BF uses 64*64 floats per tile)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, kh = lane >> 5;
     const int wk = wave >> 1, wq = wave & 1;
@@ -213,12 +252,18 @@ __global__ __launch_bounds__(256, 1) void attn_accum_kernel(AccumArgs p) {
             if (SURGERY) { typ = t % 3; row0 = (t < 3) ? qt * 64 : kt * 64; }
             else { typ = t; row0 = (t == 0) ? qt * 64 : kt * 64; }
             const float* src = p.qkvh + (((long long)b * 3 + typ) * p.H + h) * (long long)N * HD;
+            const u16* srcs = BF ? p.qkvs + (((long long)b * 3 + typ) * p.H + h) * (long long)N * 128 : nullptr;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int idx = tid + 256 * i;
                 const int row = idx >> 4, c4 = idx & 15;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(src + (long long)min(row0 + row, N - 1) * HD + c4 * 4);
-                *reinterpret_cast<f32x4*>(&tiles[t * 64 * KP + row * KP + c4 * 4]) = v;
+                if (BF) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(srcs + (long long)min(row0 + row, N - 1) * 128 + c4 * 8);
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<u16*>(tiles) + t * 64 * 128 + row * 128 + ((c4 ^ (row & 15)) * 8)) = v;
+                } else {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(src + (long long)min(row0 + row, N - 1) * HD + c4 * 4);
+                    *reinterpret_cast<f32x4*>(&tiles[t * 64 * KP + row * KP + c4 * 4]) = v;
+                }
             }
         }
         __syncthreads();
@@ -231,12 +276,26 @@ __global__ __launch_bounds__(256, 1) void attn_accum_kernel(AccumArgs p) {
             f32x16 s;
 #pragma unroll
             for (int e = 0; e < 16; ++e) s[e] = 0.f;
+            if (BF) {
+                const u16* y16 = reinterpret_cast<const u16*>(tiles) + slotY * 64 * 128 + (wk * 32 + r) * 128;
+                const u16* x16 = reinterpret_cast<const u16*>(tiles) + slotX * 64 * 128 + (wq * 32 + r) * 128;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const f32x4 yf = *reinterpret_cast<const f32x4*>(ys + c * 8);
-                const f32x4 xf = *reinterpret_cast<const f32x4*>(xs + c * 8);
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int ch = ((s4 * 2 + kh) ^ (r & 15)) * 8, cl = ((8 + s4 * 2 + kh) ^ (r & 15)) * 8;
+                    const bf16x8 yh = *reinterpret_cast<const bf16x8*>(y16 + ch), yl = *reinterpret_cast<const bf16x8*>(y16 + cl);
+                    const bf16x8 xh = *reinterpret_cast<const bf16x8*>(x16 + ch), xl = *reinterpret_cast<const bf16x8*>(x16 + cl);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl, xh, s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh, xl, s, 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh, xh, s, 0, 0, 0);
+                }
+            } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(yf[e], xf[e], s, 0, 0, 0);
+                for (int c = 0; c < 8; ++c) {
+                    const f32x4 yf = *reinterpret_cast<const f32x4*>(ys + c * 8);
+                    const f32x4 xf = *reinterpret_cast<const f32x4*>(xs + c * 8);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(yf[e], xf[e], s, 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -288,11 +347,11 @@ __global__ __launch_bounds__(256, 1) void attn_accum_kernel(AccumArgs p) {
 }
 
 int excel_launch_attn_rowpass(const float* qkvh, float* out, float* stats, int B, int H, int N, int hd, float scale,
-                              int ntypes, hipStream_t st, int split_out) {
+                              int ntypes, hipStream_t st, int split_out, const unsigned short* qkvs) {
     ProfScope prof__(PROF_ATTN_ROWPASS, st);
     EXCEL_CHECK_ARG(hd == HD, "attention: head_dim must be 64 (got %d)", hd);
     EXCEL_CHECK_ARG(ntypes == 1 || ntypes == 4, "attention: ntypes must be 1 or 4");
-    RowpassArgs a{qkvh, out, reinterpret_cast<float2*>(stats), B, H, N, scale, split_out};
+    RowpassArgs a{qkvh, out, reinterpret_cast<float2*>(stats), B, H, N, scale, split_out, qkvs};
     hipLaunchKernelGGL(attn_rowpass_kernel, dim3(cdiv(N, 128), B * H, ntypes), dim3(256), 0, st, a);
     EXCEL_CHECK_LAUNCH("attn_rowpass");
     return EXCEL_OK;
@@ -300,16 +359,20 @@ int excel_launch_attn_rowpass(const float* qkvh, float* out, float* stats, int B
 
 int excel_launch_attn_accum(const float* qkvh, const float* stats, float* a_sum, float* w_aff, float* attn_out, int B, int H,
                             int N, int NP, int hd, float scale, int surgery, float w_scale, float aff_scale, int aff_init,
-                            hipStream_t st) {
+                            hipStream_t st, const unsigned short* qkvs) {
     ProfScope prof__(PROF_ATTN_ACCUM, st);
     EXCEL_CHECK_ARG(hd == HD, "attention: head_dim must be 64 (got %d)", hd);
     EXCEL_CHECK_ARG(!surgery || (a_sum && NP >= N && NP <= cdiv(N, 64) * 64), "attn_accum: bad a_sum/NP");
-    AccumArgs a{qkvh, reinterpret_cast<const float2*>(stats), a_sum, w_aff, attn_out, B, H, N, NP, scale, w_scale, aff_scale, aff_init};
+    AccumArgs a{qkvh, reinterpret_cast<const float2*>(stats), a_sum, w_aff, attn_out, B, H, N, NP, scale, w_scale, aff_scale, aff_init, qkvs};
     dim3 grid(cdiv(N, 64), cdiv(N, 64), B);
-    if (surgery)
-        hipLaunchKernelGGL(attn_accum_kernel<true>, grid, dim3(256), 0, st, a);
+    if (surgery && qkvs)
+        hipLaunchKernelGGL((attn_accum_kernel<true, true>), grid, dim3(256), 0, st, a);
+    else if (surgery)
+        hipLaunchKernelGGL((attn_accum_kernel<true, false>), grid, dim3(256), 0, st, a);
+    else if (qkvs)
+        hipLaunchKernelGGL((attn_accum_kernel<false, true>), grid, dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL(attn_accum_kernel<false>, grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((attn_accum_kernel<false, false>), grid, dim3(256), 0, st, a);
     EXCEL_CHECK_LAUNCH("attn_accum");
     return EXCEL_OK;
 }

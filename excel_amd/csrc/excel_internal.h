@@ -38,6 +38,7 @@ struct GemmBfArgs {
     int lda, ldb, ldc, ldr;
     int act, out_mode;
     int tokN, heads, hd;
+    unsigned short* qkv_split;   // GEMM_OUT_QKV_HEADMAJOR: also write q|k|v head-major in split format [B,3,H,N][2][hd] (may be null)
 };
 int excel_launch_gemm_bf16x3(const GemmBfArgs& p, hipStream_t stream);
 int excel_launch_split_bf16(const float* in, void* out, long long R, int K, hipStream_t st);
@@ -50,10 +51,10 @@ int excel_launch_token_axis_normalize(const float* f, float* ss, float* out, int
 int excel_launch_im2col(const float* img, float* col, int B, int S, int ps, hipStream_t st, int split_out = 0);
 
 int excel_launch_attn_rowpass(const float* qkvh, float* out, float* stats, int B, int H, int N, int hd, float scale,
-                              int ntypes, hipStream_t st, int split_out = 0);
+                              int ntypes, hipStream_t st, int split_out = 0, const unsigned short* qkvs = nullptr);
 int excel_launch_attn_accum(const float* qkvh, const float* stats, float* a_sum, float* w_aff, float* attn_out, int B, int H,
                             int N, int NP, int hd, float scale, int surgery, float w_scale, float aff_scale, int aff_init,
-                            hipStream_t st);
+                            hipStream_t st, const unsigned short* qkvs = nullptr);
 int excel_launch_cam_epilogue(float* S, float* out_full, float* out_slice, int B, int N, int T, int ldS, int F, float temp,
                               hipStream_t st);
 int excel_launch_trans_mat_sym(const float* W, float* T, float* Tsym, float* cs, int B, int P, hipStream_t st);

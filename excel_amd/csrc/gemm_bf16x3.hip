@@ -40,10 +40,12 @@ __device__ __forceinline__ void bf_epilogue(const GemmBfArgs& p, const f32x16 (&
         if (col >= p.N) continue;
         const float bv = p.bias ? p.bias[col] : 0.f;
         long long qcol_off = 0;
+        int qd = 0;
         if (OUT_MODE == GEMM_OUT_QKV_HEADMAJOR) {
             const int D = p.heads * p.hd;
             const int qt = col / D, rem = col - qt * D;
-            const int qh = rem / p.hd, qd = rem - qh * p.hd;
+            const int qh = rem / p.hd;
+            qd = rem - qh * p.hd;
             qcol_off = ((long long)qt * p.heads + qh) * p.tokN * p.hd + qd;     // + (b*3*heads*tokN + n) * hd per row
         }
 #pragma unroll
@@ -67,7 +69,14 @@ __device__ __forceinline__ void bf_epilogue(const GemmBfArgs& p, const f32x16 (&
                 } else if (OUT_MODE == GEMM_OUT_QKV_HEADMAJOR) {
                     int n = qn + dr, b = qb;
                     while (n >= p.tokN) { n -= p.tokN; ++b; }
-                    p.C[qcol_off + ((long long)b * 3 * p.heads * p.tokN + n) * p.hd] = v;
+                    const long long off = qcol_off + ((long long)b * 3 * p.heads * p.tokN + n) * p.hd;
+                    p.C[off] = v;
+                    if (p.qkv_split) {     // same (b,type,head,n) row, [hi hd | lo hd] bf16: operand of the bf16x3 attention scores
+                        __bf16* o = reinterpret_cast<__bf16*>(p.qkv_split) + (off - qd) * 2 + qd;
+                        const __bf16 hi = (__bf16)v;
+                        o[0] = hi;
+                        o[p.hd] = (__bf16)(v - (float)hi);
+                    }
                 } else {
                     p.C[(long long)row * p.ldc + col] = v;
                 }

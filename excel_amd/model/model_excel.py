@@ -13,17 +13,18 @@ from .load_attr import attr_aggregate
 class ExCEL_model:
     def __init__(self, clip_model=None, embedding_dim=256, in_channels=512, dataset_name="pascal_voc",
                  num_classes=21, num_atrr_clusters=112, json_file=None, img_size=320, mode="train", device="cuda",
-                 state_dict=None, text_features=None, attr_bank=None, vit_cfg=None, text_attr=None):
+                 state_dict=None, text_features=None, attr_bank=None, vit_cfg=None, text_attr=None, gemm_mode=None):
         """Extra keyword arguments (no network here): `state_dict` = CLIP visual weights, `text_features` [T,512] =
         output of encode_text_with_prompt_ensemble (clip/clip.py:252-269, one-time, out of scope),
-        `attr_bank` [512,K] overrides the bank file, `vit_cfg` overrides the ViT-B/16 shape."""
+        `attr_bank` [512,K] overrides the bank file, `vit_cfg` overrides the ViT-B/16 shape, `gemm_mode` = "bf16x3"
+        (default) | "f32" selects the matrix-core numerics."""
         self.num_classes = num_classes
         self.embedding_dim = embedding_dim
         self.in_channels = in_channels
         self.device = device
         cfg = dict(width=768, layers=12, heads=12, patch=16, output_dim=512, input_resolution=224)
         cfg.update(vit_cfg or {})
-        self.encoder, _ = clip.load(clip_model, device=device, state_dict=state_dict, **cfg)          # :25
+        self.encoder, _ = clip.load(clip_model, device=device, state_dict=state_dict, gemm_mode=gemm_mode, **cfg)   # :25
         self.encoder.visual.reload_self_attn(layers=6, feat_size=img_size // cfg["patch"], mode=mode)   # :26
         if text_attr is not None:          # a pre-aggregated [C,T] bank (tests / cached banks)
             self.integral_text_features, self.attr_flag = None, None

@@ -5,6 +5,7 @@ libexcel_hip; nothing is computed with torch ops.  Tensors must be fp32,
 contiguous and on the GPU; outputs are fresh tensors.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -83,7 +84,7 @@ class VitHandle:
     """Owns device copies of the ViT weights (state_dict naming of the reference's VisionTransformer,
     clip/clip_surgery_model.py:374-394) and the C handle bound to them."""
 
-    def __init__(self, state_dict, width, layers, heads, patch, out_dim, n_surgery=5, device="cuda", prefix=""):
+    def __init__(self, state_dict, width, layers, heads, patch, out_dim, n_surgery=5, device="cuda", prefix="", gemm_mode=None):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("excel_amd.VitHandle needs a GPU device: the HIP library is the only compute path")
@@ -128,6 +129,12 @@ class VitHandle:
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             check(lib().excel_vit_create(C.byref(cfg), C.byref(w), C.byref(self._h)), "excel_vit_create")
+            # numerics of the linear layers and attention scores: "bf16x3" (default; fp32 operands as bf16 hi+lo, 3 bf16
+            # MFMAs per product, CAM error ~1e-5 against exact fp32) or "f32" (exact fp32 MFMA).  EXCEL_GEMM_MODE overrides.
+            mode = gemm_mode or os.environ.get("EXCEL_GEMM_MODE", "bf16x3")
+            if mode == "bf16x3" and (width % 32 or (3 * patch * patch) % 32):
+                mode = "f32"
+            self.set_gemm_mode(mode)
         self._ws = None
 
     def __del__(self):

@@ -33,21 +33,24 @@ def gpu():
     return True
 
 
-def tiny_model(text_attr, seed=11, img_size=96, mode="train", num_classes=5):
+def tiny_model(text_attr, seed=11, img_size=96, mode="train", num_classes=5, gemm_mode=None):
     from excel_amd.model import ExCEL_model
     w = make_vit_weights(TINY, seed=seed)
     return ExCEL_model(clip_model="tiny", num_classes=num_classes, img_size=img_size, mode=mode, state_dict=w,
-                       vit_cfg=TINY_KW, text_attr=text_attr), w
+                       vit_cfg=TINY_KW, text_attr=text_attr, gemm_mode=gemm_mode), w
 
 
-def test_api_path_matches_golden_trace(gpu, golden):
-    """The reference's own per-image call sequence (tools/infer_lam.py:79-94) through the mirrored API."""
+@pytest.mark.parametrize("gemm_mode,tol", [("f32", 2e-4), ("bf16x3", 1e-3)])
+def test_api_path_matches_golden_trace(gpu, golden, gemm_mode, tol):
+    """The reference's own per-image call sequence (tools/infer_lam.py:79-94) through the mirrored API, in both
+    matrix-core modes: exact fp32 (tight) and the default bf16x3 (north-star gates)."""
     from excel_amd.utils.affutils import refine_cams_with_aff, refine_cams_with_bkg_weclip
     from excel_amd.utils.PAR import PAR
     from excel_amd.utils import evaluate
     from excel_amd import ops
     g = golden("pipeline_tiny.npz")
-    model, _ = tiny_model(g["text"].T.copy())
+    model, _ = tiny_model(g["text"].T.copy(), gemm_mode=gemm_mode)
+    assert model.encoder.visual.handle().gemm_mode() == gemm_mode
     par = PAR(num_iter=20, dilations=[1, 2, 4, 8, 12, 24])
     gts, preds = [], []
     for i in range(4):
@@ -56,26 +59,26 @@ def test_api_path_matches_golden_trace(gpu, golden):
         assert maxabs(host(inputs), g[f"s{i}_inputs"]) < 1e-5
         _, _, attr_maps_raw, attn_weights, _ = model(inputs)
         assert maxabs(host(attr_maps_raw), g[f"s{i}_maps"]) < 1e-3          # north-star gate
-        assert maxabs(host(attr_maps_raw), g[f"s{i}_maps"]) < 2e-4
+        assert maxabs(host(attr_maps_raw), g[f"s{i}_maps"]) < tol
         cls_label = dev(g[f"s{i}_cls"])
         refined, cls_lst = refine_cams_with_aff(attr_maps_raw[0], attn_weights[:, 0], cls_label, size=inputs.shape[2:],
                                                 caa_thre=0.79)
         assert np.array_equal(cls_lst.numpy(), g[f"s{i}_cls_lst"])
         ref_refined = g[f"s{i}_refined"]
         got = np.stack([host(r) for r in refined])
-        assert maxabs(got, ref_refined) < 1e-4 * max(1.0, float(np.abs(ref_refined).max()))
+        assert maxabs(got, ref_refined) < (1e-4 if gemm_mode == "f32" else 1e-3) * max(1.0, float(np.abs(ref_refined).max()))
         H, W = g[f"s{i}_gt"].shape
         labels, cams = refine_cams_with_bkg_weclip(refined, inputs[0], cls_lst, par, (H, W))
         assert tuple(labels.shape) == (1, H, W) and labels.dtype == torch.int64
         assert maxabs(host(cams), g[f"s{i}_cams"]) < 1e-3
         agree = float(np.mean(host(labels)[0] == g[f"s{i}_label"]))
-        assert agree >= 0.999, agree
+        assert agree >= (0.999 if gemm_mode == "f32" else 0.998), agree
         preds.append(host(labels)[0].astype(np.int16))
         gts.append(g[f"s{i}_gt"].astype(np.int16))
     sc = evaluate.scores(gts, preds, num_classes=5)
     hist = evaluate.hist_from_labels(gts, preds, 5)
-    assert np.abs(host(hist) - g["hist"]).sum() <= 8
-    assert abs(sc["miou"] - float(g["miou"])) < 2e-3
+    assert np.abs(host(hist) - g["hist"]).sum() <= (8 if gemm_mode == "f32" else 60)
+    assert abs(sc["miou"] - float(g["miou"])) < (2e-3 if gemm_mode == "f32" else 5e-3)
 
 
 def test_api_path_with_stacked_attention_tensor(gpu, golden):
@@ -105,7 +108,7 @@ def test_batched_pipeline_tiny_vs_oracle(gpu):
     rs = np.random.RandomState(77)
     text = rs.standard_normal((9, 64)).astype(np.float32)
     text /= np.linalg.norm(text, axis=1, keepdims=True)
-    model, w = tiny_model(text.T.copy())
+    model, w = tiny_model(text.T.copy(), gemm_mode="f32")
     wo = oracle.vit.reload_self_attn(w, TINY, 6, "train")
     B, S, F = 5, 96, 4
     imgs = rs.standard_normal((B, 3, S, S)).astype(np.float32)
