@@ -187,9 +187,9 @@ __device__ __forceinline__ void rowpass_body(const RowpassArgs& p, float* smem, 
             const float v = ob[qq * 65 + lane];
             if (p.out_split) {
                 const __bf16 hi = (__bf16)v;
-                __bf16* o = reinterpret_cast<__bf16*>(p.out) + ((long long)b * N + q) * 2 * (p.H * HD) + h * HD + lane;
+                __bf16* o = reinterpret_cast<__bf16*>(p.out) + ((long long)b * N + q) * 2 * (p.H * HD) + split_off(h * HD + lane, 0);
                 o[0] = hi;
-                o[p.H * HD] = (__bf16)(v - (float)hi);
+                o[32] = (__bf16)(v - (float)hi);
             } else {
                 p.out[((long long)b * N + q) * (p.H * HD) + h * HD + lane] = v;
             }

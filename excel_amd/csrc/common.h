@@ -80,3 +80,8 @@ struct ProfScope {
     ProfScope(int c, hipStream_t s, double work = 0.0) : cat(c), st(s), on(g_excel_prof_on) { if (on) excel_prof_begin(cat, st, work); }
     ~ProfScope() { if (on) excel_prof_end(cat, st); }
 };
+
+// ---------------------------------------------------------------- split-bf16 operand layout
+// A "split" row of K fp32 values is 2K bf16: for every block of 32 k the 32 hi values then the 32 lo values, so that the
+// 128 bytes a bf16x3 GEMM k-step (BK = 32) needs from a row are ONE contiguous, 128-B aligned cache line.
+__host__ __device__ __forceinline__ long long split_off(int k, int plane) { return (long long)(k >> 5) * 64 + plane * 32 + (k & 31); }

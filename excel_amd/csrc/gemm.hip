@@ -173,11 +173,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
                 if (res) v += res[(long long)row * p.ldr + col];
                 if (p.out_mode == GEMM_OUT_SPLIT_BF16) {
                     // split-bf16 output [rows][2][ldc]: plane width ldc, z2 offsets columns (in bf16 elements)
-                    __bf16* o = reinterpret_cast<__bf16*>(p.C + (long long)z1 * p.sC) + (long long)z2 * p.sC2 +
-                                (long long)row * 2 * p.ldc + col;
+                    // (z2 offsets columns by sC2 elements of the logical row; blocked hi/lo layout, see split_off)
+                    __bf16* o = reinterpret_cast<__bf16*>(p.C + (long long)z1 * p.sC) + (long long)row * 2 * p.ldc +
+                                split_off((int)(z2 * p.sC2) + col, 0);
                     const __bf16 hi = (__bf16)v;
                     o[0] = hi;
-                    o[p.ldc] = (__bf16)(v - (float)hi);
+                    o[32] = (__bf16)(v - (float)hi);
                 } else if (p.out_mode == GEMM_OUT_QKV_HEADMAJOR) {
                     const int b = row / p.tokN, n = row % p.tokN;
                     C[((((long long)b * 3 + qt) * p.heads + qh) * p.tokN + n) * p.hd + qd] = v;

@@ -9,7 +9,9 @@
 // The bf16 pipe issues 16x the MACs per cycle of the f32-input MFMA, so 3 MFMAs per product is a 5.3x higher ceiling
 // (2.5 PFLOP/s / 3 = 833 TFLOP/s fp32-equivalent vs 157 TFLOP/s).
 //
-// "Split" tensors are stored [rows][2][K] bf16 (row r: K hi values then K lo values): exactly the bytes of the fp32
+// "Split" tensors hold 2K bf16 per row, per block of 32 k: 32 hi values then 32 lo values (split_off, common.h), so one
+// GEMM k-step reads ONE full 128-B line per row (fetching hi and lo planes separately halves the useful bytes per L2
+// line and measured ~2x the L2 traffic): exactly the bytes of the fp32
 // tensor, so they live in the same workspace buffers.  Producers write them directly (LayerNorm, the QuickGELU
 // epilogue of this kernel, the attention output, im2col); weights are split once at excel_vit_create.
 //
@@ -18,6 +20,7 @@
 // direct-to-LDS staging
 // (global_load_lds_dwordx4, XOR-swizzled 128-B rows: conflict-free ds_read_b128), XCD-aware tile order; per k16 step a wave does 8 ds_read_b128 and
 // 12 MFMAs.
+#include <stdlib.h>
 #include "common.h"
 #include "excel_internal.h"
 
@@ -63,9 +66,9 @@ __device__ __forceinline__ void bf_epilogue(const GemmBfArgs& p, const f32x16 (&
                 if (p.res) v += p.res[(long long)row * p.ldr + col];
                 if (OUT_MODE == GEMM_OUT_SPLIT_BF16) {
                     const __bf16 hi = (__bf16)v;
-                    __bf16* o = reinterpret_cast<__bf16*>(p.Cs) + (long long)row * 2 * p.N + col;
+                    __bf16* o = reinterpret_cast<__bf16*>(p.Cs) + (long long)row * 2 * p.N + split_off(col, 0);
                     o[0] = hi;
-                    o[p.N] = (__bf16)(v - (float)hi);
+                    o[32] = (__bf16)(v - (float)hi);
                 } else if (OUT_MODE == GEMM_OUT_QKV_HEADMAJOR) {
                     int n = qn + dr, b = qb;
                     while (n >= p.tokN) { n -= p.tokN; ++b; }
@@ -85,36 +88,117 @@ __device__ __forceinline__ void bf_epilogue(const GemmBfArgs& p, const f32x16 (&
     }
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmBfArgs p) {
-    // [stage][operand A|B][128 rows x 64 bf16]; each row is 8 x 16-B chunks, chunk c stored at slot c ^ ((row>>1)&7)
-    __shared__ __attribute__((aligned(1024))) u16 smem[2][2][TBM * TROW];   // 64 KB -> 2 workgroups per CU
+// LDS-staged epilogue: the accumulator layout (one column per lane, rows spread over registers) makes direct stores
+// 4-byte scatters (two 128-B segments per instruction; measured 28 % of the fc1 GEMM).  Each wave instead transposes its
+// 64x64 tile through 2 x (32 x 68-float) LDS rounds and stores row-contiguous 16-byte vectors: bias / residual become
+// float4 loads, fp32 rows are written as full 256-B segments, split-bf16 rows as 8-byte hi/lo groups.
+template <int OUT_MODE>
+__device__ __forceinline__ void bf_epilogue_lds(const GemmBfArgs& p, const f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn,
+                                                int lane, float* scratch) {
+    const int r = lane & 31;
+    const int c4 = (lane & 15) * 4;
+    const int col = n0 + wn * 64 + c4;
+    const bool col_ok = col < p.N;                       // N % 4 == 0: the whole float4 is inside or outside
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && col_ok) bias4 = *reinterpret_cast<const f32x4*>(p.bias + col);
+    int qt = 0, qh = 0, qd = 0;
+    if (OUT_MODE == GEMM_OUT_QKV_HEADMAJOR) {
+        const int D = p.heads * p.hd;
+        qt = col / D;
+        const int rem = col - qt * D;
+        qh = rem / p.hd;
+        qd = rem - qh * p.hd;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) scratch[c32_row(e, lane) * 68 + j * 32 + r] = acc[i][j][e];
+        __builtin_amdgcn_s_waitcnt(0xc07f);               // this wave's LDS writes landed (same-wave read back)
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row_l = it * 4 + (lane >> 4);
+            const int row = m0 + wm * 64 + i * 32 + row_l;
+            f32x4 v = *reinterpret_cast<const f32x4*>(&scratch[row_l * 68 + c4]);
+            if (row >= p.M || !col_ok) continue;
+            v += bias4;
+            if (p.act == GEMM_ACT_QUICKGELU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = v[q] * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v[q]));
+            }
+            if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (long long)row * p.ldr + col);
+            if (OUT_MODE == GEMM_OUT_PLAIN) {
+                *reinterpret_cast<f32x4*>(p.C + (long long)row * p.ldc + col) = v;
+            } else {
+                __bf16 hi[4], lo[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { hi[q] = (__bf16)v[q]; lo[q] = (__bf16)(v[q] - (float)hi[q]); }
+                if (OUT_MODE == GEMM_OUT_SPLIT_BF16) {
+                    __bf16* o = reinterpret_cast<__bf16*>(p.Cs) + (long long)row * 2 * p.N + split_off(col, 0);
+                    *reinterpret_cast<uint2*>(o) = *reinterpret_cast<const uint2*>(hi);
+                    *reinterpret_cast<uint2*>(o + 32) = *reinterpret_cast<const uint2*>(lo);
+                } else {   // q|k|v head-major: fp32 for P.V / A.V, and [hi hd | lo hd] bf16 for the bf16x3 scores
+                    const int b = row / p.tokN, n = row - b * p.tokN;
+                    const long long rowidx = (((long long)b * 3 + qt) * p.heads + qh) * p.tokN + n;
+                    *reinterpret_cast<f32x4*>(p.C + rowidx * p.hd + qd) = v;
+                    if (p.qkv_split) {
+                        __bf16* o = reinterpret_cast<__bf16*>(p.qkv_split) + rowidx * 2 * p.hd + qd;
+                        *reinterpret_cast<uint2*>(o) = *reinterpret_cast<const uint2*>(hi);
+                        *reinterpret_cast<uint2*>(o + p.hd) = *reinterpret_cast<const uint2*>(lo);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);               // reads done before the next round overwrites the scratch
+    }
+}
+
+// WM waves along M (block tile = WM*64 x 128), 2 along N; NSTAGE-deep LDS ring filled by global_load_lds.
+//   <2, 2>: 128x128 tile, 64 KB LDS, 2 workgroups/CU, one __syncthreads per k-step (small problems / tails)
+//   <4, 3>: 256x128 tile, 144 KB LDS, 1 workgroup (8 waves)/CU, two k-steps of loads in flight behind a COUNTED
+//           s_waitcnt vmcnt + raw s_barrier (a miss to MALL/HBM no longer stalls the step that issued it), 25 % fewer
+//           L2->LDS bytes per flop.
+template <int WM, int NSTAGE>
+__global__ __launch_bounds__(WM * 128, (WM == 2) ? 2 : 2) void gemm_bf16x3_kernel(GemmBfArgs p) {
+    constexpr int BM = WM * 64;
+    constexpr int STAGE = (BM + TBN) * TROW;                 // u16 elements per stage: A rows then B rows
+    constexpr int NWAVE = WM * 2;
+    constexpr int A_PER_WAVE = (BM / 8) / NWAVE;             // 1-KB row groups (8 rows) each wave stages per k-step
+    constexpr int B_PER_WAVE = (TBN / 8) / NWAVE;
+    constexpr int PER_WAVE = A_PER_WAVE + B_PER_WAVE;
+    // each row is 8 x 16-B chunks [hi 32 | lo 32], chunk c stored at slot c ^ ((row>>1)&7)
+    __shared__ __attribute__((aligned(1024))) u16 smem[NSTAGE * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, kh = lane >> 5;
-    const int tiles_n = (p.N + TBN - 1) / TBN, tiles_m = (p.M + TBM - 1) / TBM;
+    const int tiles_n = (p.N + TBN - 1) / TBN, tiles_m = (p.M + BM - 1) / BM;
     const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     const int tm = id / tiles_n, tn = id % tiles_n;
-    const int m0 = tm * TBM, n0 = tn * TBN;
+    const int m0 = tm * BM, n0 = tn * TBN;
 
     // direct-to-LDS staging (global_load_lds_dwordx4): one wave-instruction fills 1 KB = 8 tile rows; the LDS image is
-    // lane-linear, so the swizzle is applied to the per-lane SOURCE address.  Each wave issues 4 (A) + 4 (B) per k-step.
-    const u16* gsrc[8];
+    // lane-linear, so the swizzle is applied to the per-lane SOURCE address.
+    const u16* gsrc[PER_WAVE];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int op = j >> 2, seg = wave * 4 + (j & 3);
+    for (int j = 0; j < PER_WAVE; ++j) {
+        const bool isB = j >= A_PER_WAVE;
+        const int seg = isB ? wave * B_PER_WAVE + (j - A_PER_WAVE) : wave * A_PER_WAVE + j;
         const int row_l = seg * 8 + (lane >> 3), phys = lane & 7;
         const int c = phys ^ ((row_l >> 1) & 7);
-        const int grow = op ? min(n0 + row_l, p.N - 1) : min(m0 + row_l, p.M - 1);
-        gsrc[j] = (op ? p.B + (long long)grow * p.ldb : p.A + (long long)grow * p.lda) + (long long)(c >> 2) * p.K + (c & 3) * 8;
+        const int grow = isB ? min(n0 + row_l, p.N - 1) : min(m0 + row_l, p.M - 1);
+        gsrc[j] = (isB ? p.B + (long long)grow * p.ldb : p.A + (long long)grow * p.lda) + c * 8;   // chunk c of the row's 128-B k-block
     }
-    auto issue_tile = [&](int kt, int buf) {
+    auto issue_tile = [&](int kt, int stage) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int op = j >> 2, seg = wave * 4 + (j & 3);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc[j] + kt * TBK),
-                                             (__attribute__((address_space(3))) void*)(&smem[buf][op][seg * 8 * TROW]), 16, 0, 0);
+        for (int j = 0; j < PER_WAVE; ++j) {
+            const bool isB = j >= A_PER_WAVE;
+            const int seg = isB ? wave * B_PER_WAVE + (j - A_PER_WAVE) : wave * A_PER_WAVE + j;
+            u16* dst = smem + stage * STAGE + (isB ? BM * TROW : 0) + seg * 8 * TROW;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc[j] + kt * 64),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
     };
 
@@ -128,16 +212,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmBfArgs p) {
 
     const int sw = (r >> 1) & 7;      // (row>>1)&7 of every fragment row this lane reads (tile rows are r + multiples of 32)
     const int nk = p.K / TBK;
-    issue_tile(0, 0);
-    __syncthreads();                  // drains the LDS-DMA (vmcnt(0)) and publishes the tile
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) issue_tile(kt + 1, cur ^ 1);      // in flight during this step's 24 MFMAs
-        const u16* as = smem[cur][0];
-        const u16* bs = smem[cur][1];
+
+    auto compute = [&](int stage) {
+        const u16* as = smem + stage * STAGE;
+        const u16* bs = as + BM * TROW;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int ch = ((s * 2 + kh) ^ sw) * 8, cl = ((4 + s * 2 + kh) ^ sw) * 8;
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int ch = ((s2 * 2 + kh) ^ sw) * 8, cl = ((4 + s2 * 2 + kh) ^ sw) * 8;
             bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -161,14 +242,58 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmBfArgs p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
-        __syncthreads();
-        cur ^= 1;
+    };
+
+    if (NSTAGE == 2) {
+        issue_tile(0, 0);
+        __syncthreads();                  // drains the LDS-DMA (vmcnt(0)) and publishes the tile
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) issue_tile(kt + 1, (kt + 1) & 1);      // in flight during this step's MFMAs
+            compute(kt & 1);
+            __syncthreads();
+        }
+    } else {
+        // ring of NSTAGE (3) stages, two k-steps of loads in flight.  Step kt: wait until only the NEWER stage's loads
+        // may still be outstanding (counted vmcnt: PER_WAVE per stage), raw barrier (publishes stage kt to all waves AND
+        // proves everyone finished reading stage kt-1), refill stage kt-1's slot with tile kt+2, compute stage kt.
+        issue_tile(0, 0);
+        if (nk > 1) issue_tile(1, 1);
+        int stage = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) {
+                if (PER_WAVE == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < nk) issue_tile(kt + 2, stage == 0 ? NSTAGE - 1 : stage - 1);
+            compute(stage);
+            stage = (stage + 1 == NSTAGE) ? 0 : stage + 1;
+        }
     }
 
     switch (p.out_mode) {
-        case GEMM_OUT_SPLIT_BF16: bf_epilogue<GEMM_OUT_SPLIT_BF16>(p, acc, m0, n0, wm, wn, lane); break;
-        case GEMM_OUT_QKV_HEADMAJOR: bf_epilogue<GEMM_OUT_QKV_HEADMAJOR>(p, acc, m0, n0, wm, wn, lane); break;
-        default: bf_epilogue<GEMM_OUT_PLAIN>(p, acc, m0, n0, wm, wn, lane); break;
+        case 99:   // dev: no epilogue (k-loop timing); keeps the accumulators live
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+            break;
+        default: {
+            const bool vec = (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 && (p.hd & 3) == 0;
+            if (vec) {
+                __syncthreads();   // every wave is done with the staging ring: reuse it as per-wave transpose scratch
+                float* scratch = reinterpret_cast<float*>(smem) + wave * (32 * 68);
+                if (p.out_mode == GEMM_OUT_SPLIT_BF16) bf_epilogue_lds<GEMM_OUT_SPLIT_BF16>(p, acc, m0, n0, wm, wn, lane, scratch);
+                else if (p.out_mode == GEMM_OUT_QKV_HEADMAJOR) bf_epilogue_lds<GEMM_OUT_QKV_HEADMAJOR>(p, acc, m0, n0, wm, wn, lane, scratch);
+                else bf_epilogue_lds<GEMM_OUT_PLAIN>(p, acc, m0, n0, wm, wn, lane, scratch);
+            } else {
+                if (p.out_mode == GEMM_OUT_SPLIT_BF16) bf_epilogue<GEMM_OUT_SPLIT_BF16>(p, acc, m0, n0, wm, wn, lane);
+                else if (p.out_mode == GEMM_OUT_QKV_HEADMAJOR) bf_epilogue<GEMM_OUT_QKV_HEADMAJOR>(p, acc, m0, n0, wm, wn, lane);
+                else bf_epilogue<GEMM_OUT_PLAIN>(p, acc, m0, n0, wm, wn, lane);
+            }
+        }
     }
 }
 
@@ -185,25 +310,33 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
         hi[j] = (__bf16)v[j];
         lo[j] = (__bf16)(v[j] - (float)hi[j]);
     }
-    __bf16* o = reinterpret_cast<__bf16*>(out) + row * 2 * K + k;
+    __bf16* o = reinterpret_cast<__bf16*>(out) + row * 2 * K + split_off(k, 0);
     *reinterpret_cast<uint2*>(o) = *reinterpret_cast<const uint2*>(hi);
-    *reinterpret_cast<uint2*>(o + K) = *reinterpret_cast<const uint2*>(lo);
+    *reinterpret_cast<uint2*>(o + 32) = *reinterpret_cast<const uint2*>(lo);
 }
 
 int excel_launch_gemm_bf16x3(const GemmBfArgs& p, hipStream_t stream) {
     ProfScope prof__(PROF_GEMM_BF16X3, stream, 2.0 * p.M * (double)p.N * p.K);
     EXCEL_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0 && (p.K % TBK) == 0, "gemm_bf16x3: K must be a multiple of %d (K=%d)", TBK, p.K);
+    EXCEL_CHECK_ARG(p.out_mode != GEMM_OUT_SPLIT_BF16 || (p.N % 32) == 0, "gemm_bf16x3: split output needs N %% 32 == 0");
     EXCEL_CHECK_ARG((p.lda % 8) == 0 && (p.ldb % 8) == 0 && p.lda >= 2 * p.K && p.ldb >= 2 * p.K, "gemm_bf16x3: bad lda/ldb");
     EXCEL_CHECK_ARG((((uintptr_t)p.A | (uintptr_t)p.B) & 15) == 0, "gemm_bf16x3: operands must be 16-byte aligned");
-    const int tiles = cdiv(p.M, TBM) * cdiv(p.N, TBN);
-    hipLaunchKernelGGL(gemm_bf16x3_kernel, dim3(tiles), dim3(256), 0, stream, p);
+    static const char* force = getenv("EXCEL_BF_TILE");      // dev knob: "128" | "256"
+    const bool big = force ? !strcmp(force, "256") : (p.M >= 2048);
+    if (big) {
+        const int tiles = cdiv(p.M, 256) * cdiv(p.N, TBN);
+        hipLaunchKernelGGL((gemm_bf16x3_kernel<4, 3>), dim3(tiles), dim3(512), 0, stream, p);
+    } else {
+        const int tiles = cdiv(p.M, TBM) * cdiv(p.N, TBN);
+        hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 2>), dim3(tiles), dim3(256), 0, stream, p);
+    }
     EXCEL_CHECK_LAUNCH("gemm_bf16x3");
     return EXCEL_OK;
 }
 
 int excel_launch_split_bf16(const float* in, void* out, long long R, int K, hipStream_t st) {
     ProfScope prof__(PROF_OTHER, st);
-    EXCEL_CHECK_ARG((K % 4) == 0, "split_bf16: K must be a multiple of 4");
+    EXCEL_CHECK_ARG((K % 32) == 0, "split_bf16: K must be a multiple of 32 (blocked hi/lo layout)");
     hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)cdivl(R * K / 4, 256)), dim3(256), 0, st, in, (u16*)out, R, K);
     EXCEL_CHECK_LAUNCH("split_bf16");
     return EXCEL_OK;

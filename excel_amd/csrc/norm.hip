@@ -37,8 +37,8 @@ __device__ __forceinline__ void ln_row(const float* __restrict__ src, const floa
 #pragma unroll
             for (int j = 0; j < 4; ++j) { hi[j] = (__bf16)v[j]; lo[j] = (__bf16)(v[j] - (float)hi[j]); }
             __bf16* o = reinterpret_cast<__bf16*>(dst);
-            *reinterpret_cast<uint2*>(o + c) = *reinterpret_cast<const uint2*>(hi);
-            *reinterpret_cast<uint2*>(o + D + c) = *reinterpret_cast<const uint2*>(lo);
+            *reinterpret_cast<uint2*>(o + split_off(c, 0)) = *reinterpret_cast<const uint2*>(hi);
+            *reinterpret_cast<uint2*>(o + split_off(c, 1)) = *reinterpret_cast<const uint2*>(lo);
         } else {
             *reinterpret_cast<f32x4*>(dst + c) = v;
         }
@@ -123,9 +123,9 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ i
         __bf16 hi[4], lo[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { hi[j] = (__bf16)v[j]; lo[j] = (__bf16)(v[j] - (float)hi[j]); }
-        __bf16* o = reinterpret_cast<__bf16*>(col) + pr * 2 * Kc + k;
+        __bf16* o = reinterpret_cast<__bf16*>(col) + pr * 2 * Kc + split_off(k, 0);
         *reinterpret_cast<uint2*>(o) = *reinterpret_cast<const uint2*>(hi);
-        *reinterpret_cast<uint2*>(o + Kc) = *reinterpret_cast<const uint2*>(lo);
+        *reinterpret_cast<uint2*>(o + 32) = *reinterpret_cast<const uint2*>(lo);
     } else {
         *reinterpret_cast<f32x4*>(col + e) = v;
     }

@@ -409,19 +409,26 @@ def _bf16_round(x):
     return (((u + r) & 0xFFFF0000).astype(np.uint32)).view(np.float32)
 
 
+def _unsplit(t):
+    """split tensor [R,2,K] (int16 view) -> (hi, lo) fp32 [R,K]; layout: per block of 32 k, 32 hi then 32 lo."""
+    R = t.shape[0]
+    K = t.shape[2]
+    u = t.reshape(R, K // 32, 2, 32).view(np.uint16).astype(np.uint32) << 16
+    f = u.view(np.float32)
+    return f[:, :, 0, :].reshape(R, K), f[:, :, 1, :].reshape(R, K)
+
+
 def test_split_bf16_format(ops):
     rs = np.random.RandomState(0)
-    x = (rs.standard_normal((37, 64)) * np.exp(rs.uniform(-20, 20, (37, 64)))).astype(np.float32)
-    s = host(ops.split_bf16(dev(x))).view(np.uint16).astype(np.uint32)
-    hi = (s[:, 0, :] << 16).view(np.float32)
-    lo = (s[:, 1, :] << 16).view(np.float32)
+    x = (rs.standard_normal((37, 96)) * np.exp(rs.uniform(-20, 20, (37, 96)))).astype(np.float32)
+    hi, lo = _unsplit(host(ops.split_bf16(dev(x))))
     ref_hi = _bf16_round(x)
     assert np.array_equal(hi, ref_hi)
     assert np.array_equal(lo, _bf16_round(x - ref_hi))
     assert np.max(np.abs((hi.astype(np.float64) + lo) - x) / np.abs(x)) < 2.0 ** -16
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 45, 512), (785, 2304, 768), (37, 64, 128), (257, 768, 3072)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 64, 512), (785, 2304, 768), (37, 64, 128), (257, 768, 3072), (2100, 384, 96)])
 def test_gemm_bf16x3(ops, M, N, K):
     rs = np.random.RandomState(M + N)
     A = rs.standard_normal((M, K)).astype(np.float32)
@@ -438,8 +445,7 @@ def test_gemm_bf16x3(ops, M, N, K):
     out2 = host(ops.gemm_bf16x3(As, Ws, bias=dev(bias), residual=dev(res), act=1))
     assert maxabs(out2, y) < 3e-5 * scale + 2e-6
     # split output == split of the fp32 output
-    s = host(ops.gemm_bf16x3(As, Ws, split_out=True)).view(np.uint16).astype(np.uint32)
-    hi = (s[:, 0, :] << 16).view(np.float32)
+    hi, _ = _unsplit(host(ops.gemm_bf16x3(As, Ws, split_out=True)))
     assert np.array_equal(hi, _bf16_round(out))
 
 

@@ -1,0 +1,29 @@
+"""Standalone GEMM micro-benchmark (dev tool): python tools_dev/gemm_bench.py [M N K] [reps] [mode]"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from excel_amd import ops
+M, N, K = (int(x) for x in sys.argv[1:4]) if len(sys.argv) > 3 else (25120, 3072, 768)
+reps = int(sys.argv[4]) if len(sys.argv) > 4 else 20
+mode = sys.argv[5] if len(sys.argv) > 5 else "bf16x3"
+g = torch.Generator(device="cuda").manual_seed(0)
+A = torch.randn(M, K, device="cuda", generator=g)
+W = torch.randn(N, K, device="cuda", generator=g) * 0.05
+if mode.startswith("bf16x3"):
+    import ctypes as C
+    from excel_amd._lib import lib
+    As, Ws = ops.split_bf16(A), ops.split_bf16(W)
+    out = torch.empty((M, 2 * N if mode.endswith("split") else N), dtype=torch.float32, device="cuda")
+    so = {"bf16x3": 0, "bf16x3_split": 1, "bf16x3_noepi": 99}[mode]
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    f = lambda: lib().excel_gemm_bf16x3(As.data_ptr(), Ws.data_ptr(), out.data_ptr(), None, None, M, N, K, 0, so, st)
+else:
+    f = lambda: ops.gemm(A, W)
+for _ in range(3): f()
+torch.cuda.synchronize()
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+ev0.record()
+for _ in range(reps): f()
+ev1.record(); torch.cuda.synchronize()
+ms = ev0.elapsed_time(ev1) / reps
+print(f"{mode} M={M} N={N} K={K}: {ms*1e3:.1f} us  {2.0*M*N*K/ms/1e9:.1f} TFLOP/s (fp32-equivalent)")
