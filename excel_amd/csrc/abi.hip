@@ -271,8 +271,8 @@ extern "C" void excel_vit_destroy(excel_vit_t h) {
 }
 
 struct VitWs {
-    float *x, *xo, *y, *ao, *qkvh, *qkvs, *hbuf, *stats, *a_sum, *fraw, *ss;
-    int NP;
+    float *x, *xo, *y, *ao, *qkvh, *qkvs, *hbuf, *stats, *a_sum, *vt, *fraw, *ss;
+    int NP, KP;
     size_t total;
 };
 
@@ -281,6 +281,7 @@ static VitWs vit_ws_layout(const excel_vit_config& c, int B, int S, char* base) 
     const size_t M = (size_t)B * N, D = c.width;
     VitWs w;
     w.NP = (N + 3) / 4 * 4;
+    w.KP = (N + 31) / 32 * 32;            // K of the bf16x3 A_sum.V GEMM (zero padded)
     size_t off = 0;
     auto take = [&](size_t floats) { float* p = (float*)(base + off); off += align_up(floats * sizeof(float), 256); return p; };
     w.x = take(M * D);
@@ -294,7 +295,8 @@ static VitWs vit_ws_layout(const excel_vit_config& c, int B, int S, char* base) 
         w.hbuf = take(M * 4 * D > col ? M * 4 * D : col);
     }
     w.stats = take((size_t)B * c.heads * 4 * N * 2);
-    w.a_sum = take((size_t)B * N * w.NP);
+    w.a_sum = take((size_t)B * N * w.KP);              // fp32 [B,N,NP] or split bf16 [B,N][2*KP]
+    w.vt = take((size_t)B * D * w.KP);                 // V^T split [B][D][2*KP] (bf16x3 mode)
     w.fraw = take(M * c.out_dim);
     w.ss = take((size_t)B * c.out_dim);
     w.total = off;
@@ -383,8 +385,8 @@ extern "C" int excel_vit_forward(excel_vit_t h, const float* img, int B, int S, 
         float* attn_l = (n_attn_out && l >= L - n_attn_out) ? attn_out + (size_t)(l - (L - n_attn_out)) * B * N * N : nullptr;
         if (surgery || in_aff || attn_l) {
             TRY(excel_launch_attn_accum(ws.qkvh, ws.stats, surgery ? ws.a_sum : nullptr, in_aff ? w_aff : nullptr, attn_l, B, H, N,
-                                        ws.NP, 64, scale, surgery ? 1 : 0, surgery ? 1.f : 1.f / (float)H, 1.f / (float)aff_layers,
-                                        (l == L - aff_layers) ? 1 : 0, st, qkvs));
+                                        bf ? ws.KP : ws.NP, 64, scale, surgery ? 1 : 0, surgery ? 1.f : 1.f / (float)H,
+                                        1.f / (float)aff_layers, (l == L - aff_layers) ? 1 : 0, st, qkvs, bf ? 1 : 0));
         }
         if (!surgery) {
             TRY(linear(ws.ao, bw.out_proj_w, sw.out_proj, bw.out_proj_b, ws.x, ws.x, D, D, GEMM_ACT_NONE, GEMM_OUT_PLAIN));   // x += out_proj(attn)
@@ -393,15 +395,23 @@ extern "C" int excel_vit_forward(excel_vit_t h, const float* img, int B, int S, 
             TRY(linear(ws.hbuf, bw.fc2_w, sw.fc2, bw.fc2_b, ws.x, ws.x, D, 4 * D, GEMM_ACT_NONE, GEMM_OUT_PLAIN));           // x += mlp(ln_2(x))
             if (feats_out) hipMemcpyAsync(feats_out + (size_t)l * M * D, ws.x, sizeof(float) * (size_t)M * D, hipMemcpyDeviceToDevice, st);
         } else {
-            // new path: (A_sum . V_h) for every head, heads concatenated -> y  (batched NN GEMM over (b,h))   :149
-            {
+            // new path: (A_sum . V_h) for every head, heads concatenated -> y   (:149)
+            if (bf) {
+                // one bf16x3 NT GEMM per image: y[b] (split) = A_sum[b] [N x KP] . (V^T[b] [D x KP])^T
+                TRY(excel_launch_vt_split(ws.qkvh + (size_t)2 * H * N * 64, (unsigned short*)ws.vt, B, H, N, ws.KP,
+                                          (long long)3 * H * N * 64, st));
+                GemmBfArgs ga = gemm_bf_args(ws.a_sum, (const unsigned short*)ws.vt, ws.y, ws.y, nullptr, nullptr, N, D, ws.KP, D, 0,
+                                             GEMM_ACT_NONE, GEMM_OUT_SPLIT_BF16);
+                ga.batch = B;
+                ga.sA = (long long)N * 2 * ws.KP; ga.sB = (long long)D * 2 * ws.KP; ga.sC = 0; ga.sCs = (long long)N * 2 * D;
+                TRY(excel_launch_gemm_bf16x3(ga, st));
+            } else {   // exact fp32: batched NN GEMM over (b,h)
                 GemmArgs ga = gemm_args(ws.a_sum, ws.qkvh + (size_t)2 * H * N * 64, ws.y, nullptr, nullptr, N, 64, N, ws.NP, 64, D, 0, GEMM_ACT_NONE);
                 ga.Kld = ws.NP;
                 ga.zdiv = H;
                 ga.sA = (long long)N * ws.NP; ga.sA2 = 0;
                 ga.sB = (long long)3 * H * N * 64; ga.sB2 = (long long)N * 64;
                 ga.sC = (long long)N * D; ga.sC2 = 64;
-                if (bf) ga.out_mode = GEMM_OUT_SPLIT_BF16;      // feeds the bf16x3 out-proj below
                 TRY(excel_launch_gemm(ga, false, B * H, st));
             }
             // original path residual first (x_ori = src + proj(attn_ori.v), :317/:326), then the new path (x += proj(.), :319/:329)

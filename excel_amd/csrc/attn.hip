@@ -224,6 +224,7 @@ struct AccumArgs {
     float aff_scale;      // 1/attn_layers
     int aff_init;         // 1: w_aff = ..., 0: w_aff += ...
     const unsigned short* qkvs;   // split-bf16 q|k|v for bf16x3 scores (null = exact fp32)
+    int a_sum_split;      // 1: a_sum is written in split-bf16 format [B,N][2*NP] (NP % 32 == 0): A operand of the bf16x3 A_sum.V GEMM
 };
 
 template <bool SURGERY, bool BF>
@@ -328,7 +329,17 @@ __global__ __launch_bounds__(256, 1) void attn_accum_kernel(AccumArgs p) {
             const float v = tb[qq * 33 + r];
             if (qg >= N) continue;
             if (which == 0) {
-                if (kg < p.NP) p.a_sum[((long long)b * N + qg) * p.NP + kg] = v * (1.f / 3.f);
+                if (kg < p.NP) {
+                    const float av = v * (1.f / 3.f);
+                    if (p.a_sum_split) {
+                        __bf16* o = reinterpret_cast<__bf16*>(p.a_sum) + ((long long)b * N + qg) * 2 * p.NP + split_off(kg, 0);
+                        const __bf16 hi = (__bf16)av;
+                        o[0] = hi;
+                        o[32] = (__bf16)(av - (float)hi);
+                    } else {
+                        p.a_sum[((long long)b * N + qg) * p.NP + kg] = av;
+                    }
+                }
             } else {
                 const float pw = v * p.w_scale;
                 if (p.attn_out && kg < N) p.attn_out[((long long)b * N + qg) * N + kg] = pw;
@@ -359,11 +370,11 @@ int excel_launch_attn_rowpass(const float* qkvh, float* out, float* stats, int B
 
 int excel_launch_attn_accum(const float* qkvh, const float* stats, float* a_sum, float* w_aff, float* attn_out, int B, int H,
                             int N, int NP, int hd, float scale, int surgery, float w_scale, float aff_scale, int aff_init,
-                            hipStream_t st, const unsigned short* qkvs) {
+                            hipStream_t st, const unsigned short* qkvs, int a_sum_split) {
     ProfScope prof__(PROF_ATTN_ACCUM, st);
     EXCEL_CHECK_ARG(hd == HD, "attention: head_dim must be 64 (got %d)", hd);
     EXCEL_CHECK_ARG(!surgery || (a_sum && NP >= N && NP <= cdiv(N, 64) * 64), "attn_accum: bad a_sum/NP");
-    AccumArgs a{qkvh, reinterpret_cast<const float2*>(stats), a_sum, w_aff, attn_out, B, H, N, NP, scale, w_scale, aff_scale, aff_init, qkvs};
+    AccumArgs a{qkvh, reinterpret_cast<const float2*>(stats), a_sum, w_aff, attn_out, B, H, N, NP, scale, w_scale, aff_scale, aff_init, qkvs, a_sum_split};
     dim3 grid(cdiv(N, 64), cdiv(N, 64), B);
     if (surgery && qkvs)
         hipLaunchKernelGGL((attn_accum_kernel<true, true>), grid, dim3(256), 0, st, a);

@@ -39,9 +39,12 @@ struct GemmBfArgs {
     int act, out_mode;
     int tokN, heads, hd;
     unsigned short* qkv_split;   // GEMM_OUT_QKV_HEADMAJOR: also write q|k|v head-major in split format [B,3,H,N][2][hd] (may be null)
+    int batch;                   // >= 1: blockIdx.y; operands advance by sA / sB bf16 elements, C by sC floats, Cs by sCs bf16 elements
+    long long sA, sB, sC, sCs;
 };
 int excel_launch_gemm_bf16x3(const GemmBfArgs& p, hipStream_t stream);
 int excel_launch_split_bf16(const float* in, void* out, long long R, int K, hipStream_t st);
+int excel_launch_vt_split(const float* v, unsigned short* vt, int B, int H, int N, int KP, long long v_batch_stride, hipStream_t st);
 
 int excel_launch_layernorm(const float* x, const float* cls_src, int tokN, const float* w, const float* b, float* y,
                            int rows, int D, float eps, hipStream_t st, int split_out = 0);
@@ -54,7 +57,7 @@ int excel_launch_attn_rowpass(const float* qkvh, float* out, float* stats, int B
                               int ntypes, hipStream_t st, int split_out = 0, const unsigned short* qkvs = nullptr);
 int excel_launch_attn_accum(const float* qkvh, const float* stats, float* a_sum, float* w_aff, float* attn_out, int B, int H,
                             int N, int NP, int hd, float scale, int surgery, float w_scale, float aff_scale, int aff_init,
-                            hipStream_t st, const unsigned short* qkvs = nullptr);
+                            hipStream_t st, const unsigned short* qkvs = nullptr, int a_sum_split = 0);
 int excel_launch_cam_epilogue(float* S, float* out_full, float* out_slice, int B, int N, int T, int ldS, int F, float temp,
                               hipStream_t st);
 int excel_launch_trans_mat_sym(const float* W, float* T, float* Tsym, float* cs, int B, int P, hipStream_t st);

@@ -178,6 +178,10 @@ __global__ __launch_bounds__(WM * 128, (WM == 2) ? 2 : 2) void gemm_bf16x3_kerne
     const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     const int tm = id / tiles_n, tn = id % tiles_n;
     const int m0 = tm * BM, n0 = tn * TBN;
+    if (p.batch > 1) {      // batched problems (blockIdx.y): advance the operand / output bases (block-uniform)
+        const long long z = blockIdx.y;
+        p.A += z * p.sA; p.B += z * p.sB; p.C += z * p.sC; p.Cs += z * p.sCs;
+    }
 
     // direct-to-LDS staging (global_load_lds_dwordx4): one wave-instruction fills 1 KB = 8 tile rows; the LDS image is
     // lane-linear, so the swizzle is applied to the per-lane SOURCE address.
@@ -315,8 +319,51 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
     *reinterpret_cast<uint2*>(o + 32) = *reinterpret_cast<const uint2*>(lo);
 }
 
+// v [B][H][N][64] fp32 (head-major, image stride v_bstride) -> V^T in split format vt [B][H*64][2*KP] (row = one (head, d),
+// K axis = token m, zero-padded to KP): the K-major B operand of the bf16x3  A_sum . V  GEMM.  One workgroup per
+// (image, head, 64-token tile): coalesced 16-KB read, LDS transpose, 128-B contiguous hi|lo writes.
+__global__ __launch_bounds__(256) void vt_split_kernel(const float* __restrict__ v, u16* __restrict__ vt, int H, int N, int KP,
+                                                       long long v_bstride) {
+    __shared__ float t[64][65];
+    const int mt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const float* src = v + (long long)b * v_bstride + (long long)h * N * 64;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 64 * 16; i += 256) {
+        const int m = i >> 4, c4 = i & 15;
+        const int gm = mt * 64 + m;
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        if (gm < N) x = *reinterpret_cast<const f32x4*>(src + (long long)gm * 64 + c4 * 4);
+        t[m][c4 * 4 + 0] = x[0]; t[m][c4 * 4 + 1] = x[1]; t[m][c4 * 4 + 2] = x[2]; t[m][c4 * 4 + 3] = x[3];
+    }
+    __syncthreads();
+    // thread -> (d, 4 consecutive m): 64 d x 16 groups
+    for (int i = tid; i < 64 * 16; i += 256) {
+        const int d = i >> 4, g4 = i & 15;
+        const int m0 = mt * 64 + g4 * 4;
+        if (m0 >= KP) continue;
+        __bf16 hi[4], lo[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x = t[g4 * 4 + j][d];
+            hi[j] = (__bf16)x;
+            lo[j] = (__bf16)(x - (float)hi[j]);
+        }
+        __bf16* o = reinterpret_cast<__bf16*>(vt) + (((long long)b * H + h) * 64 + d) * 2 * KP + split_off(m0, 0);
+        *reinterpret_cast<uint2*>(o) = *reinterpret_cast<const uint2*>(hi);
+        *reinterpret_cast<uint2*>(o + 32) = *reinterpret_cast<const uint2*>(lo);
+    }
+}
+
+int excel_launch_vt_split(const float* v, unsigned short* vt, int B, int H, int N, int KP, long long v_batch_stride, hipStream_t st) {
+    ProfScope prof__(PROF_OTHER, st);
+    EXCEL_CHECK_ARG((KP % 32) == 0 && KP >= N, "vt_split: KP must be a multiple of 32 and >= N");
+    hipLaunchKernelGGL(vt_split_kernel, dim3(cdiv(KP, 64), H, B), dim3(256), 0, st, v, vt, H, N, KP, v_batch_stride);
+    EXCEL_CHECK_LAUNCH("vt_split");
+    return EXCEL_OK;
+}
+
 int excel_launch_gemm_bf16x3(const GemmBfArgs& p, hipStream_t stream) {
-    ProfScope prof__(PROF_GEMM_BF16X3, stream, 2.0 * p.M * (double)p.N * p.K);
+    ProfScope prof__(PROF_GEMM_BF16X3, stream, 2.0 * p.M * (double)p.N * p.K * (p.batch > 1 ? p.batch : 1));
     EXCEL_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0 && (p.K % TBK) == 0, "gemm_bf16x3: K must be a multiple of %d (K=%d)", TBK, p.K);
     EXCEL_CHECK_ARG(p.out_mode != GEMM_OUT_SPLIT_BF16 || (p.N % 32) == 0, "gemm_bf16x3: split output needs N %% 32 == 0");
     EXCEL_CHECK_ARG((p.lda % 8) == 0 && (p.ldb % 8) == 0 && p.lda >= 2 * p.K && p.ldb >= 2 * p.K, "gemm_bf16x3: bad lda/ldb");
@@ -325,10 +372,10 @@ int excel_launch_gemm_bf16x3(const GemmBfArgs& p, hipStream_t stream) {
     const bool big = force ? !strcmp(force, "256") : (p.M >= 2048);
     if (big) {
         const int tiles = cdiv(p.M, 256) * cdiv(p.N, TBN);
-        hipLaunchKernelGGL((gemm_bf16x3_kernel<4, 3>), dim3(tiles), dim3(512), 0, stream, p);
+        hipLaunchKernelGGL((gemm_bf16x3_kernel<4, 3>), dim3(tiles, p.batch > 1 ? p.batch : 1), dim3(512), 0, stream, p);
     } else {
         const int tiles = cdiv(p.M, TBM) * cdiv(p.N, TBN);
-        hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 2>), dim3(tiles), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 2>), dim3(tiles, p.batch > 1 ? p.batch : 1), dim3(256), 0, stream, p);
     }
     EXCEL_CHECK_LAUNCH("gemm_bf16x3");
     return EXCEL_OK;
