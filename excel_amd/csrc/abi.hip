@@ -356,17 +356,23 @@ extern "C" int excel_vit_forward(excel_vit_t h, const float* img, int B, int S, 
     }
     TRY(excel_launch_assemble_ln_pre(ws.ao, h->w.class_emb, pos, h->w.ln_pre_w, h->w.ln_pre_b, ws.x, B, N, D, eps, st));
 
-    // linear layer helper: C = act(A . W^T + bias) + res, A produced in the mode's operand format
-    auto linear = [&](const float* A, const float* Wf, const unsigned short* Ws, const float* bias, const float* res, float* Cout,
-                      int Nout, int K, int act, int out_mode) -> int {
+    // linear layer helper: C = act(A . W^T + bias) + res, A produced in the mode's operand format.
+    // rows/lda_f/ldc/ldr default to the dense [M, .] case; the last block uses them to touch only the cls rows.
+    auto linear_ex = [&](const float* A, const float* Wf, const unsigned short* Ws, const float* bias, const float* res, float* Cout,
+                         int rows, int Nout, int K, long long lda_f, int ldc, int ldr, int act, int out_mode) -> int {
         if (bf) {
-            GemmBfArgs ga = gemm_bf_args(A, Ws, Cout, Cout, bias, res, M, Nout, K, Nout, Nout, act, out_mode);
+            GemmBfArgs ga = gemm_bf_args(A, Ws, Cout, Cout, bias, res, rows, Nout, K, ldc, ldr, act, out_mode);
+            ga.lda = (int)(2 * lda_f);
             if (out_mode == GEMM_OUT_QKV_HEADMAJOR) { ga.tokN = N; ga.heads = H; ga.hd = 64; ga.qkv_split = (unsigned short*)ws.qkvs; }
             return excel_launch_gemm_bf16x3(ga, st);
         }
-        GemmArgs ga = gemm_args(A, Wf, Cout, bias, res, M, Nout, K, K, K, Nout, Nout, act);
+        GemmArgs ga = gemm_args(A, Wf, Cout, bias, res, rows, Nout, K, (int)lda_f, K, ldc, ldr, act);
         if (out_mode == GEMM_OUT_QKV_HEADMAJOR) { ga.out_mode = GEMM_OUT_QKV_HEADMAJOR; ga.tokN = N; ga.heads = H; ga.hd = 64; }
         return excel_launch_gemm(ga, true, 1, st);
+    };
+    auto linear = [&](const float* A, const float* Wf, const unsigned short* Ws, const float* bias, const float* res, float* Cout,
+                      int Nout, int K, int act, int out_mode) -> int {
+        return linear_ex(A, Wf, Ws, bias, res, Cout, M, Nout, K, K, Nout, Nout, act, out_mode);
     };
     const int mid_mode = bf ? GEMM_OUT_SPLIT_BF16 : GEMM_OUT_PLAIN;   // format of GEMM->GEMM intermediates (MLP hidden)
     const SplitBlockW nosplit{nullptr, nullptr, nullptr, nullptr};
@@ -380,7 +386,10 @@ extern "C" int excel_vit_forward(excel_vit_t h, const float* img, int B, int S, 
         TRY(excel_launch_layernorm(src, nullptr, 1, bw.ln1_w, bw.ln1_b, ws.y, M, D, eps, st, bf));
         TRY(linear(ws.y, bw.in_proj_w, sw.in_proj, bw.in_proj_b, nullptr, ws.qkvh, 3 * D, D, GEMM_ACT_NONE, GEMM_OUT_QKV_HEADMAJOR));
         const unsigned short* qkvs = bf ? (const unsigned short*)ws.qkvs : nullptr;
-        TRY(excel_launch_attn_rowpass(ws.qkvh, ws.ao, ws.stats, B, H, N, 64, scale, surgery ? 4 : 1, st, bf, qkvs));
+        // last block: its original-path output feeds only x[0] = x_ori[0] (:442) -> attention output, out-proj and MLP are
+        // needed for the cls rows alone (the reference computes all rows; all_feats consumers still get them on request)
+        const bool cls_only = surgery && l == L - 1 && !feats_out;
+        TRY(excel_launch_attn_rowpass(ws.qkvh, ws.ao, ws.stats, B, H, N, 64, scale, surgery ? 4 : 1, st, bf, qkvs, cls_only ? 1 : (1 << 30)));
         const bool in_aff = w_aff && l >= L - aff_layers;
         float* attn_l = (n_attn_out && l >= L - n_attn_out) ? attn_out + (size_t)(l - (L - n_attn_out)) * B * N * N : nullptr;
         if (surgery || in_aff || attn_l) {
@@ -415,11 +424,20 @@ extern "C" int excel_vit_forward(excel_vit_t h, const float* img, int B, int S, 
                 TRY(excel_launch_gemm(ga, false, B * H, st));
             }
             // original path residual first (x_ori = src + proj(attn_ori.v), :317/:326), then the new path (x += proj(.), :319/:329)
-            TRY(linear(ws.ao, bw.out_proj_w, sw.out_proj, bw.out_proj_b, src, ws.xo, D, D, GEMM_ACT_NONE, GEMM_OUT_PLAIN));
-            TRY(linear(ws.y, bw.out_proj_w, sw.out_proj, bw.out_proj_b, ws.x, ws.x, D, D, GEMM_ACT_NONE, GEMM_OUT_PLAIN));
-            TRY(excel_launch_layernorm(ws.xo, nullptr, 1, bw.ln2_w, bw.ln2_b, ws.y, M, D, eps, st, bf));
-            TRY(linear(ws.y, bw.fc1_w, sw.fc1, bw.fc1_b, nullptr, ws.hbuf, 4 * D, D, GEMM_ACT_QUICKGELU, mid_mode));
-            TRY(linear(ws.hbuf, bw.fc2_w, sw.fc2, bw.fc2_b, ws.xo, ws.xo, D, 4 * D, GEMM_ACT_NONE, GEMM_OUT_PLAIN));         // x_ori += mlp(ln_2(x_ori))
+            if (cls_only) {
+                const long long rs = (long long)N * D;       // row stride between consecutive cls tokens
+                TRY(linear_ex(ws.ao, bw.out_proj_w, sw.out_proj, bw.out_proj_b, src, ws.xo, B, D, D, rs, (int)rs, (int)rs, GEMM_ACT_NONE, GEMM_OUT_PLAIN));
+                TRY(linear(ws.y, bw.out_proj_w, sw.out_proj, bw.out_proj_b, ws.x, ws.x, D, D, GEMM_ACT_NONE, GEMM_OUT_PLAIN));
+                TRY(excel_launch_layernorm(ws.xo, nullptr, 1, bw.ln2_w, bw.ln2_b, ws.y, B, D, eps, st, bf, rs));        // compact [B, D]
+                TRY(linear_ex(ws.y, bw.fc1_w, sw.fc1, bw.fc1_b, nullptr, ws.hbuf, B, 4 * D, D, D, 4 * D, 0, GEMM_ACT_QUICKGELU, mid_mode));
+                TRY(linear_ex(ws.hbuf, bw.fc2_w, sw.fc2, bw.fc2_b, ws.xo, ws.xo, B, D, 4 * D, 4 * D, (int)rs, (int)rs, GEMM_ACT_NONE, GEMM_OUT_PLAIN));
+            } else {
+                TRY(linear(ws.ao, bw.out_proj_w, sw.out_proj, bw.out_proj_b, src, ws.xo, D, D, GEMM_ACT_NONE, GEMM_OUT_PLAIN));
+                TRY(linear(ws.y, bw.out_proj_w, sw.out_proj, bw.out_proj_b, ws.x, ws.x, D, D, GEMM_ACT_NONE, GEMM_OUT_PLAIN));
+                TRY(excel_launch_layernorm(ws.xo, nullptr, 1, bw.ln2_w, bw.ln2_b, ws.y, M, D, eps, st, bf));
+                TRY(linear(ws.y, bw.fc1_w, sw.fc1, bw.fc1_b, nullptr, ws.hbuf, 4 * D, D, GEMM_ACT_QUICKGELU, mid_mode));
+                TRY(linear(ws.hbuf, bw.fc2_w, sw.fc2, bw.fc2_b, ws.xo, ws.xo, D, 4 * D, GEMM_ACT_NONE, GEMM_OUT_PLAIN));         // x_ori += mlp(ln_2(x_ori))
+            }
             if (feats_out) hipMemcpyAsync(feats_out + (size_t)l * M * D, ws.xo, sizeof(float) * (size_t)M * D, hipMemcpyDeviceToDevice, st);
         }
     }

@@ -32,6 +32,7 @@ struct RowpassArgs {
     float scale;
     int out_split;       // 1: out is a split-bf16 tensor [B*N][2][H*64] (A operand of the bf16x3 out-proj GEMM)
     const unsigned short* qkvs;   // bf16x3 scores: q|k|v head-major in split format [B,3,H,N][2][64] (null = exact fp32 scores)
+    int flash_nq;        // q-blocks >= flash_nq of type 0 only produce row stats (last block: only the cls row's output is consumed)
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -202,11 +203,12 @@ __global__ __launch_bounds__(256, 2) void attn_rowpass_kernel(RowpassArgs p) {
     const int bh = blockIdx.y;
     const int b = bh / p.H, h = bh % p.H;
     const int type = blockIdx.z;
+    const bool flash = type == 0 && (int)blockIdx.x < p.flash_nq;
     if (p.qkvs) {
-        if (type == 0) rowpass_body<true, true>(p, smem, b, h, 0, blockIdx.x);
+        if (flash) rowpass_body<true, true>(p, smem, b, h, 0, blockIdx.x);
         else rowpass_body<false, true>(p, smem, b, h, type, blockIdx.x);
     } else {
-        if (type == 0) rowpass_body<true, false>(p, smem, b, h, 0, blockIdx.x);
+        if (flash) rowpass_body<true, false>(p, smem, b, h, 0, blockIdx.x);
         else rowpass_body<false, false>(p, smem, b, h, type, blockIdx.x);
     }
 }
@@ -358,11 +360,11 @@ __global__ __launch_bounds__(256, 1) void attn_accum_kernel(AccumArgs p) {
 }
 
 int excel_launch_attn_rowpass(const float* qkvh, float* out, float* stats, int B, int H, int N, int hd, float scale,
-                              int ntypes, hipStream_t st, int split_out, const unsigned short* qkvs) {
+                              int ntypes, hipStream_t st, int split_out, const unsigned short* qkvs, int flash_nq) {
     ProfScope prof__(PROF_ATTN_ROWPASS, st);
     EXCEL_CHECK_ARG(hd == HD, "attention: head_dim must be 64 (got %d)", hd);
     EXCEL_CHECK_ARG(ntypes == 1 || ntypes == 4, "attention: ntypes must be 1 or 4");
-    RowpassArgs a{qkvh, out, reinterpret_cast<float2*>(stats), B, H, N, scale, split_out, qkvs};
+    RowpassArgs a{qkvh, out, reinterpret_cast<float2*>(stats), B, H, N, scale, split_out, qkvs, flash_nq};
     hipLaunchKernelGGL(attn_rowpass_kernel, dim3(cdiv(N, 128), B * H, ntypes), dim3(256), 0, st, a);
     EXCEL_CHECK_LAUNCH("attn_rowpass");
     return EXCEL_OK;

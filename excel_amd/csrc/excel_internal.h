@@ -47,14 +47,14 @@ int excel_launch_split_bf16(const float* in, void* out, long long R, int K, hipS
 int excel_launch_vt_split(const float* v, unsigned short* vt, int B, int H, int N, int KP, long long v_batch_stride, hipStream_t st);
 
 int excel_launch_layernorm(const float* x, const float* cls_src, int tokN, const float* w, const float* b, float* y,
-                           int rows, int D, float eps, hipStream_t st, int split_out = 0);
+                           int rows, int D, float eps, hipStream_t st, int split_out = 0, long long in_stride = 0);
 int excel_launch_assemble_ln_pre(const float* patch, const float* cls_emb, const float* pos, const float* w, const float* b,
                                  float* x, int B, int tokN, int D, float eps, hipStream_t st);
 int excel_launch_token_axis_normalize(const float* f, float* ss, float* out, int B, int tokN, int C, hipStream_t st);
 int excel_launch_im2col(const float* img, float* col, int B, int S, int ps, hipStream_t st, int split_out = 0);
 
 int excel_launch_attn_rowpass(const float* qkvh, float* out, float* stats, int B, int H, int N, int hd, float scale,
-                              int ntypes, hipStream_t st, int split_out = 0, const unsigned short* qkvs = nullptr);
+                              int ntypes, hipStream_t st, int split_out = 0, const unsigned short* qkvs = nullptr, int flash_nq = 1 << 30);
 int excel_launch_attn_accum(const float* qkvh, const float* stats, float* a_sum, float* w_aff, float* attn_out, int B, int H,
                             int N, int NP, int hd, float scale, int surgery, float w_scale, float aff_scale, int aff_init,
                             hipStream_t st, const unsigned short* qkvs = nullptr, int a_sum_split = 0);

@@ -50,11 +50,11 @@ __device__ __forceinline__ void ln_row(const float* __restrict__ src, const floa
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __restrict__ x, const float* __restrict__ cls_src,
                                                              int tokN, const float* __restrict__ w,
                                                              const float* __restrict__ b, float* __restrict__ y,
-                                                             int rows, int D, float eps, int split_out) {
+                                                             int rows, int D, float eps, int split_out, long long in_stride) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float* src = x + (long long)row * D;
-    if (cls_src && (row % tokN) == 0) src = cls_src + (long long)row * D;
+    const float* src = x + (long long)row * in_stride;      // in_stride != D: gather every tokN-th row (cls tokens), compact output
+    if (cls_src && (row % tokN) == 0) src = cls_src + (long long)row * in_stride;
     ln_row(src, nullptr, w, b, y + (long long)row * D, D, eps, threadIdx.x & 63, split_out != 0);
 }
 
@@ -132,10 +132,10 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ i
 }
 
 int excel_launch_layernorm(const float* x, const float* cls_src, int tokN, const float* w, const float* b, float* y,
-                           int rows, int D, float eps, hipStream_t st, int split_out) {
+                           int rows, int D, float eps, hipStream_t st, int split_out, long long in_stride) {
     ProfScope prof__(PROF_LAYERNORM, st);
     EXCEL_CHECK_ARG(rows > 0 && D > 0 && (D % 4) == 0, "layernorm: D must be a multiple of 4 (D=%d)", D);
-    hipLaunchKernelGGL(layernorm_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, cls_src, tokN, w, b, y, rows, D, eps, split_out);
+    hipLaunchKernelGGL(layernorm_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, cls_src, tokN, w, b, y, rows, D, eps, split_out, in_stride > 0 ? in_stride : (long long)D);
     EXCEL_CHECK_LAUNCH("layernorm_rows");
     return EXCEL_OK;
 }
