@@ -389,7 +389,10 @@ extern "C" int excel_vit_forward(excel_vit_t h, const float* img, int B, int S, 
         // last block: its original-path output feeds only x[0] = x_ori[0] (:442) -> attention output, out-proj and MLP are
         // needed for the cls rows alone (the reference computes all rows; all_feats consumers still get them on request)
         const bool cls_only = surgery && l == L - 1 && !feats_out;
-        TRY(excel_launch_attn_rowpass(ws.qkvh, ws.ao, ws.stats, B, H, N, 64, scale, surgery ? 4 : 1, st, bf, qkvs, cls_only ? 1 : (1 << 30)));
+        if (bf)   // V^T in split format: B operand of the bf16x3 P.V (all blocks) and of A_sum.V (surgery blocks)
+            TRY(excel_launch_vt_split(ws.qkvh + (size_t)2 * H * N * 64, (unsigned short*)ws.vt, B, H, N, ws.KP, (long long)3 * H * N * 64, st));
+        TRY(excel_launch_attn_rowpass(ws.qkvh, ws.ao, ws.stats, B, H, N, 64, scale, surgery ? 4 : 1, st, bf, qkvs, cls_only ? 1 : (1 << 30),
+                                      bf ? (const unsigned short*)ws.vt : nullptr, ws.KP));
         const bool in_aff = w_aff && l >= L - aff_layers;
         float* attn_l = (n_attn_out && l >= L - n_attn_out) ? attn_out + (size_t)(l - (L - n_attn_out)) * B * N * N : nullptr;
         if (surgery || in_aff || attn_l) {
@@ -407,8 +410,6 @@ extern "C" int excel_vit_forward(excel_vit_t h, const float* img, int B, int S, 
             // new path: (A_sum . V_h) for every head, heads concatenated -> y   (:149)
             if (bf) {
                 // one bf16x3 NT GEMM per image: y[b] (split) = A_sum[b] [N x KP] . (V^T[b] [D x KP])^T
-                TRY(excel_launch_vt_split(ws.qkvh + (size_t)2 * H * N * 64, (unsigned short*)ws.vt, B, H, N, ws.KP,
-                                          (long long)3 * H * N * 64, st));
                 GemmBfArgs ga = gemm_bf_args(ws.a_sum, (const unsigned short*)ws.vt, ws.y, ws.y, nullptr, nullptr, N, D, ws.KP, D, 0,
                                              GEMM_ACT_NONE, GEMM_OUT_SPLIT_BF16);
                 ga.batch = B;

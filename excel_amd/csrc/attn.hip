@@ -33,6 +33,8 @@ struct RowpassArgs {
     int out_split;       // 1: out is a split-bf16 tensor [B*N][2][H*64] (A operand of the bf16x3 out-proj GEMM)
     const unsigned short* qkvs;   // bf16x3 scores: q|k|v head-major in split format [B,3,H,N][2][64] (null = exact fp32 scores)
     int flash_nq;        // q-blocks >= flash_nq of type 0 only produce row stats (last block: only the cls row's output is consumed)
+    const unsigned short* vt;     // V^T in split format [B][H*64][2*vt_kp] (gemm_bf16x3.hip: vt_split_kernel): P.V as bf16x3 (null = fp32 P.V)
+    int vt_kp;
 };
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -54,7 +56,11 @@ __device__ __forceinline__ void rowpass_body(const RowpassArgs& p, float* smem, 
     const float* V = p.qkvh + (((long long)b * 3 + 2) * p.H + h) * (long long)N * HD;
 
     float* Ks = smem;                    // [2][32*KP]
-    float* Vs = smem + 2 * 32 * KP;      // [2][32*64]
+    float* Vs = smem + 2 * 32 * KP;      // [2][32*64] fp32 V tile, or (PVBF) [2][64 d][32 hi | 32 lo] bf16 V^T tile
+    // PVBF: the P.V product also runs as bf16x3.  The V^T tile row d holds this key tile's 32 keys as [hi 32 | lo 32]
+    // bf16 = 16 eight-byte slots; slot (2c+half) is stored at (2c+half) ^ ((d>>1)&15): conflict-free ds_read_b64.
+    const bool PVBF = FLASH && BF && p.vt != nullptr;
+    const u16* VT = PVBF ? p.vt + (((long long)b * p.H + h) * 64) * 2 * p.vt_kp : nullptr;
 
     const int q0 = qblk * 128 + wave * 32;
     const int qrow = min(q0 + r, N - 1);
@@ -88,7 +94,14 @@ __device__ __forceinline__ void rowpass_body(const RowpassArgs& p, float* smem, 
             const int row = min(kt * 32 + (idx >> 4), N - 1), c4 = idx & 15;
             if (BF) rk[i] = *reinterpret_cast<const f32x4*>(Ysp + (long long)row * 128 + c4 * 8);   // 16-B chunk c4 of [hi 64 | lo 64]
             else rk[i] = *reinterpret_cast<const f32x4*>(Y + (long long)row * HD + c4 * 4);
-            if (FLASH) rv[i] = *reinterpret_cast<const f32x4*>(V + (long long)row * HD + c4 * 4);
+            if (FLASH) {
+                if (PVBF) {   // chunk (idx & 7) of d-row (idx >> 3): 16 B of [hi 32 | lo 32] of key block kt
+                    const int d = idx >> 3, c = idx & 7;
+                    rv[i] = *reinterpret_cast<const f32x4*>(VT + (long long)d * 2 * p.vt_kp + kt * 64 + c * 8);
+                } else {
+                    rv[i] = *reinterpret_cast<const f32x4*>(V + (long long)row * HD + c4 * 4);
+                }
+            }
         }
     };
     auto store_tile = [&](int buf) {
@@ -100,7 +113,16 @@ __device__ __forceinline__ void rowpass_body(const RowpassArgs& p, float* smem, 
                 *reinterpret_cast<f32x4*>(reinterpret_cast<u16*>(Ks) + buf * 32 * 128 + row * 128 + ((c4 ^ (row & 15)) * 8)) = rk[i];
             else
                 *reinterpret_cast<f32x4*>(&Ks[buf * 32 * KP + row * KP + c4 * 4]) = rk[i];
-            if (FLASH) *reinterpret_cast<f32x4*>(&Vs[buf * 32 * 64 + row * 64 + c4 * 4]) = rv[i];
+            if (FLASH) {
+                if (PVBF) {
+                    const int d = idx >> 3, c = idx & 7, msk = (d >> 1) & 15;
+                    f32x4 v = rv[i];
+                    if (msk & 1) v = f32x4{v[2], v[3], v[0], v[1]};      // the two 8-B halves of the chunk swap slots
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<u16*>(Vs) + buf * 64 * 64 + d * 64 + ((c ^ (msk >> 1)) * 8)) = v;
+                } else {
+                    *reinterpret_cast<f32x4*>(&Vs[buf * 32 * 64 + row * 64 + c4 * 4]) = rv[i];
+                }
+            }
         }
     };
 
@@ -156,13 +178,45 @@ __device__ __forceinline__ void rowpass_body(const RowpassArgs& p, float* smem, 
             const float* vs = Vs + cur * 32 * 64;
 #pragma unroll
             for (int e = 0; e < 16; ++e) { oT[0][e] *= alpha; oT[1][e] *= alpha; }
+            if (PVBF) {
+                // P (this lane: keys (e&3)+8(e>>2)+4kh of query r) -> bf16 hi/lo; MFMA k-step ks takes e = 8ks..8ks+7, i.e. keys
+                // {16ks+4kh+0..3, 16ks+8+4kh+0..3}: the V^T operand reads exactly those two 8-byte groups of row d.
+                bf16x8 ph[2], pl[2];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int krow = c32_row(e, lane);
-                const float v0 = vs[krow * 64 + r];
-                const float v1 = vs[krow * 64 + 32 + r];
-                oT[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s[e], oT[0], 0, 0, 0);
-                oT[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s[e], oT[1], 0, 0, 0);
+                for (int e = 0; e < 16; ++e) {
+                    const __bf16 hi = (__bf16)s[e];
+                    ph[e >> 3][e & 7] = hi;
+                    pl[e >> 3][e & 7] = (__bf16)(s[e] - (float)hi);
+                }
+                const u16* vt16 = reinterpret_cast<const u16*>(Vs) + cur * 64 * 64;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int d = dt * 32 + r, msk = (d >> 1) & 15;
+                    const u16* rowp = vt16 + d * 64;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                        // 8-byte slot index of (chunk c, half kh) = 2c + kh; hi chunks 0..3, lo chunks 4..7
+                        const bf16x4 h0 = *reinterpret_cast<const bf16x4*>(rowp + (((2 * (2 * ks) + kh) ^ msk) * 4));
+                        const bf16x4 h1 = *reinterpret_cast<const bf16x4*>(rowp + (((2 * (2 * ks + 1) + kh) ^ msk) * 4));
+                        const bf16x4 l0 = *reinterpret_cast<const bf16x4*>(rowp + (((2 * (4 + 2 * ks) + kh) ^ msk) * 4));
+                        const bf16x4 l1 = *reinterpret_cast<const bf16x4*>(rowp + (((2 * (5 + 2 * ks) + kh) ^ msk) * 4));
+                        const bf16x8 vh = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                        const bf16x8 vl = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                        oT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph[ks], oT[dt], 0, 0, 0);
+                        oT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl[ks], oT[dt], 0, 0, 0);
+                        oT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph[ks], oT[dt], 0, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int krow = c32_row(e, lane);
+                    const float v0 = vs[krow * 64 + r];
+                    const float v1 = vs[krow * 64 + 32 + r];
+                    oT[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, s[e], oT[0], 0, 0, 0);
+                    oT[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, s[e], oT[1], 0, 0, 0);
+                }
             }
         }
         if (kt + 1 < nkt) store_tile(cur ^ 1);
@@ -198,13 +252,190 @@ __device__ __forceinline__ void rowpass_body(const RowpassArgs& p, float* smem, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ rowpass, bf16x3 pipeline
+// Production variant of the row pass (bf16x3 scores AND bf16x3 P.V): K (split q|k|v rows) and V^T tiles stream through a
+// 3-stage LDS ring filled by global_load_lds (no VGPR round trip), two key tiles in flight behind a counted s_waitcnt
+// vmcnt + raw s_barrier, exactly like gemm_bf16x3_kernel<4,3>: the register-staged version waited for each tile's global
+// loads inside the step that issued them.  LDS images are lane-linear, so both swizzles are applied to the SOURCE address:
+//   K tile   [32 keys][16 chunks of 16 B = hi 64 | lo 64]   chunk c at slot c ^ (key & 15)      (conflict-free b128)
+//   V^T tile [64 d   ][ 8 chunks of 16 B = hi 32 | lo 32]   chunk c at slot c ^ ((d >> 1) & 7)  (2-way on the b64 reads)
+template <bool FLASH>
+__device__ __forceinline__ void rowpass_body_bf(const RowpassArgs& p, float* smem, int b, int h, int type, int qblk) {
+    constexpr int KT_EL = 32 * 128;                      // u16 elements of a K tile (8 KB)
+    constexpr int VT_EL = 64 * 64;                       // u16 elements of a V^T tile (8 KB)
+    constexpr int STAGE_EL = KT_EL + (FLASH ? VT_EL : 0);
+    constexpr int PER_WAVE = FLASH ? 4 : 2;              // 1-KB global_load_lds per wave per key tile
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, kh = lane >> 5;
+    const int N = p.N;
+    const int tx = (type == 0 || type == 1) ? 0 : (type == 2 ? 1 : 2);
+    const int ty = (type == 0) ? 1 : tx;
+    const u16* Xsp = p.qkvs + (((long long)b * 3 + tx) * p.H + h) * (long long)N * 128;
+    const u16* Ysp = p.qkvs + (((long long)b * 3 + ty) * p.H + h) * (long long)N * 128;
+    const u16* VT = FLASH ? p.vt + (((long long)b * p.H + h) * 64) * 2 * p.vt_kp : nullptr;
+    u16* ring = reinterpret_cast<u16*>(smem);            // [3][K tile | V^T tile]
+
+    const int q0 = qblk * 128 + wave * 32;
+    const int qrow = min(q0 + r, N - 1);
+    bf16x8 xh[4], xl[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        xh[s4] = *reinterpret_cast<const bf16x8*>(Xsp + (long long)qrow * 128 + s4 * 16 + kh * 8);
+        xl[s4] = *reinterpret_cast<const bf16x8*>(Xsp + (long long)qrow * 128 + 64 + s4 * 16 + kh * 8);
+    }
+
+    // per-lane source offsets of this wave's loads: K rows 8w..8w+7 (2 instr x 4 rows), V^T rows 16w..16w+15 (2 instr x 8 rows)
+    int koff[2], krow[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        krow[j] = wave * 8 + j * 4 + (lane >> 4);
+        koff[j] = ((lane & 15) ^ (krow[j] & 15)) * 8;
+    }
+    long long voff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int d = wave * 16 + j * 8 + (lane >> 3);
+        voff[j] = (long long)d * 2 * p.vt_kp + (((lane & 7) ^ ((d >> 1) & 7)) * 8);
+    }
+    auto issue = [&](int kt, int stage) {
+        u16* dstk = ring + stage * STAGE_EL;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int key = min(kt * 32 + krow[j], N - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ysp + (long long)key * 128 + koff[j]),
+                                             (__attribute__((address_space(3))) void*)(dstk + (wave * 8 + j * 4) * 128), 16, 0, 0);
+        }
+        if (FLASH) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(VT + voff[j] + kt * 64),
+                                                 (__attribute__((address_space(3))) void*)(dstk + KT_EL + (wave * 16 + j * 8) * 64), 16, 0, 0);
+        }
+    };
+
+    float m = -INFINITY, l = 0.f;
+    f32x16 oT[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { oT[0][e] = 0.f; oT[1][e] = 0.f; }
+
+    const int nkt = (N + 31) / 32;
+    issue(0, 0);
+    if (nkt > 1) issue(1, 1);
+    int stage = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) {
+            if (PER_WAVE == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nkt) issue(kt + 2, stage == 0 ? 2 : stage - 1);
+        const u16* kr = ring + stage * STAGE_EL + r * 128;
+        f32x16 s;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const bf16x8 yh = *reinterpret_cast<const bf16x8*>(kr + (((s4 * 2 + kh) ^ (r & 15)) * 8));
+            const bf16x8 yl = *reinterpret_cast<const bf16x8*>(kr + (((8 + s4 * 2 + kh) ^ (r & 15)) * 8));
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl, xh[s4], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh, xl[s4], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh, xh[s4], s, 0, 0, 0);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int key = kt * 32 + c32_row(e, lane);
+            s[e] = (key < N) ? s[e] * p.scale : -INFINITY;
+            mx = fmaxf(mx, s[e]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m, mx);
+        const float alpha = __expf(m - m_new);
+        float ps = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            s[e] = __expf(s[e] - m_new);
+            ps += s[e];
+        }
+        ps += __shfl_xor(ps, 32, 64);
+        l = l * alpha + ps;
+        m = m_new;
+        if (FLASH) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { oT[0][e] *= alpha; oT[1][e] *= alpha; }
+            // P (this lane: keys (e&3)+8(e>>2)+4kh of query r) -> bf16 hi/lo; MFMA k-step ks takes e = 8ks..8ks+7, i.e. keys
+            // {16ks+4kh+0..3, 16ks+8+4kh+0..3}: the V^T operand reads exactly those two 8-byte groups of row d.
+            bf16x8 ph[2], pl[2];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const __bf16 hi = (__bf16)s[e];
+                ph[e >> 3][e & 7] = hi;
+                pl[e >> 3][e & 7] = (__bf16)(s[e] - (float)hi);
+            }
+            const u16* vt16 = ring + stage * STAGE_EL + KT_EL;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const int d = dt * 32 + r, msk = (d >> 1) & 7;
+                const u16* rowp = vt16 + d * 64 + kh * 4;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                    const bf16x4 h0 = *reinterpret_cast<const bf16x4*>(rowp + (((2 * ks) ^ msk) * 8));
+                    const bf16x4 h1 = *reinterpret_cast<const bf16x4*>(rowp + (((2 * ks + 1) ^ msk) * 8));
+                    const bf16x4 l0 = *reinterpret_cast<const bf16x4*>(rowp + (((4 + 2 * ks) ^ msk) * 8));
+                    const bf16x4 l1 = *reinterpret_cast<const bf16x4*>(rowp + (((5 + 2 * ks) ^ msk) * 8));
+                    const bf16x8 vh = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                    const bf16x8 vl = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                    oT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph[ks], oT[dt], 0, 0, 0);
+                    oT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl[ks], oT[dt], 0, 0, 0);
+                    oT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph[ks], oT[dt], 0, 0, 0);
+                }
+            }
+        }
+        stage = (stage == 2) ? 0 : stage + 1;
+    }
+
+    const float linv = 1.f / l;
+    if (kh == 0 && q0 + r < N)
+        p.stats[(((long long)b * p.H + h) * 4 + type) * N + q0 + r] = make_float2(m, linv);
+
+    if (FLASH) {
+        __syncthreads();     // every wave has finished reading the ring: reuse it for the output transpose
+        float* ob = smem + wave * (32 * 65);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) ob[r * 65 + dt * 32 + c32_row(e, lane)] = oT[dt][e] * linv;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        for (int qq = 0; qq < 32; ++qq) {
+            const int q = q0 + qq;
+            if (q >= N) break;
+            const float v = ob[qq * 65 + lane];
+            if (p.out_split) {
+                const __bf16 hi = (__bf16)v;
+                __bf16* o = reinterpret_cast<__bf16*>(p.out) + ((long long)b * N + q) * 2 * (p.H * HD) + split_off(h * HD + lane, 0);
+                o[0] = hi;
+                o[32] = (__bf16)(v - (float)hi);
+            } else {
+                p.out[((long long)b * N + q) * (p.H * HD) + h * HD + lane] = v;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256, 2) void attn_rowpass_kernel(RowpassArgs p) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * 32 * KP + 2 * 32 * 64];   // 33.8 KB
+    __shared__ __attribute__((aligned(1024))) float smem[3 * 4096];   // 48 KB: 3-stage ring of (K tile 8 KB + V^T tile 8 KB); >= the 33.8 KB of the fp32 path
     const int bh = blockIdx.y;
     const int b = bh / p.H, h = bh % p.H;
     const int type = blockIdx.z;
     const bool flash = type == 0 && (int)blockIdx.x < p.flash_nq;
-    if (p.qkvs) {
+    if (p.qkvs && p.vt) {
+        if (flash) rowpass_body_bf<true>(p, smem, b, h, 0, blockIdx.x);
+        else rowpass_body_bf<false>(p, smem, b, h, type, blockIdx.x);
+    } else if (p.qkvs) {
         if (flash) rowpass_body<true, true>(p, smem, b, h, 0, blockIdx.x);
         else rowpass_body<false, true>(p, smem, b, h, type, blockIdx.x);
     } else {
@@ -360,11 +591,12 @@ __global__ __launch_bounds__(256, 1) void attn_accum_kernel(AccumArgs p) {
 }
 
 int excel_launch_attn_rowpass(const float* qkvh, float* out, float* stats, int B, int H, int N, int hd, float scale,
-                              int ntypes, hipStream_t st, int split_out, const unsigned short* qkvs, int flash_nq) {
+                              int ntypes, hipStream_t st, int split_out, const unsigned short* qkvs, int flash_nq,
+                              const unsigned short* vt, int vt_kp) {
     ProfScope prof__(PROF_ATTN_ROWPASS, st);
     EXCEL_CHECK_ARG(hd == HD, "attention: head_dim must be 64 (got %d)", hd);
     EXCEL_CHECK_ARG(ntypes == 1 || ntypes == 4, "attention: ntypes must be 1 or 4");
-    RowpassArgs a{qkvh, out, reinterpret_cast<float2*>(stats), B, H, N, scale, split_out, qkvs, flash_nq};
+    RowpassArgs a{qkvh, out, reinterpret_cast<float2*>(stats), B, H, N, scale, split_out, qkvs, flash_nq, vt, vt_kp};
     hipLaunchKernelGGL(attn_rowpass_kernel, dim3(cdiv(N, 128), B * H, ntypes), dim3(256), 0, st, a);
     EXCEL_CHECK_LAUNCH("attn_rowpass");
     return EXCEL_OK;

@@ -54,7 +54,8 @@ int excel_launch_token_axis_normalize(const float* f, float* ss, float* out, int
 int excel_launch_im2col(const float* img, float* col, int B, int S, int ps, hipStream_t st, int split_out = 0);
 
 int excel_launch_attn_rowpass(const float* qkvh, float* out, float* stats, int B, int H, int N, int hd, float scale,
-                              int ntypes, hipStream_t st, int split_out = 0, const unsigned short* qkvs = nullptr, int flash_nq = 1 << 30);
+                              int ntypes, hipStream_t st, int split_out = 0, const unsigned short* qkvs = nullptr, int flash_nq = 1 << 30,
+                              const unsigned short* vt = nullptr, int KP = 0);
 int excel_launch_attn_accum(const float* qkvh, const float* stats, float* a_sum, float* w_aff, float* attn_out, int B, int H,
                             int N, int NP, int hd, float scale, int surgery, float w_scale, float aff_scale, int aff_init,
                             hipStream_t st, const unsigned short* qkvs = nullptr, int a_sum_split = 0);
