@@ -314,7 +314,8 @@ __device__ __forceinline__ void rowpass_body_bf(const RowpassArgs& p, float* sme
         }
     };
 
-    float m = -INFINITY, l = 0.f;
+    const float c2 = p.scale * 1.4426950408889634f;     // scores enter the softmax in log2 units
+    float m = -INFINITY, l = 0.f;                         // m: running row max in log2 units
     f32x16 oT[2];
 #pragma unroll
     for (int e = 0; e < 16; ++e) { oT[0][e] = 0.f; oT[1][e] = 0.f; }
@@ -344,36 +345,43 @@ __device__ __forceinline__ void rowpass_body_bf(const RowpassArgs& p, float* sme
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh, xl[s4], s, 0, 0, 0);
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh, xh[s4], s, 0, 0, 0);
         }
-        float mx = -INFINITY;
+        // softmax bookkeeping in log2 units: p = exp2(s*c2 - m2), c2 = scale*log2(e)  (one fma + one v_exp per element);
+        // only the last key tile can contain keys >= N, so the mask lives in a uniform branch.
+        if (kt == nkt - 1) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int key = kt * 32 + c32_row(e, lane);
-            s[e] = (key < N) ? s[e] * p.scale : -INFINITY;
-            mx = fmaxf(mx, s[e]);
+            for (int e = 0; e < 16; ++e)
+                if (kt * 32 + c32_row(e, lane) >= N) s[e] = -INFINITY;
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float mx = s[0];
+#pragma unroll
+        for (int e = 1; e < 16; ++e) mx = fmaxf(mx, s[e]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c2;
         const float m_new = fmaxf(m, mx);
-        const float alpha = __expf(m - m_new);
+        const bool grew = m_new > m;
+        const float alpha = __builtin_amdgcn_exp2f(m - m_new);            // 1.0 exactly when the running max did not move
         float ps = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            s[e] = __expf(s[e] - m_new);
+            s[e] = __builtin_amdgcn_exp2f(fmaf(s[e], c2, -m_new));
             ps += s[e];
         }
         ps += __shfl_xor(ps, 32, 64);
         l = l * alpha + ps;
         m = m_new;
         if (FLASH) {
+            if (__any(grew)) {                           // wave-uniform: after the first few tiles the max rarely moves
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { oT[0][e] *= alpha; oT[1][e] *= alpha; }
+                for (int e = 0; e < 16; ++e) { oT[0][e] *= alpha; oT[1][e] *= alpha; }
+            }
             // P (this lane: keys (e&3)+8(e>>2)+4kh of query r) -> bf16 hi/lo; MFMA k-step ks takes e = 8ks..8ks+7, i.e. keys
             // {16ks+4kh+0..3, 16ks+8+4kh+0..3}: the V^T operand reads exactly those two 8-byte groups of row d.
+            // hi = p truncated to bf16 (bit mask), lo = bf16(p - hi): p - hi is exact, so hi + lo keeps 16 mantissa bits.
             bf16x8 ph[2], pl[2];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const __bf16 hi = (__bf16)s[e];
-                ph[e >> 3][e & 7] = hi;
-                pl[e >> 3][e & 7] = (__bf16)(s[e] - (float)hi);
+                const float hf = __uint_as_float(__float_as_uint(s[e]) & 0xFFFF0000u);
+                ph[e >> 3][e & 7] = (__bf16)hf;
+                pl[e >> 3][e & 7] = (__bf16)(s[e] - hf);
             }
             const u16* vt16 = ring + stage * STAGE_EL + KT_EL;
 #pragma unroll
@@ -400,7 +408,7 @@ __device__ __forceinline__ void rowpass_body_bf(const RowpassArgs& p, float* sme
 
     const float linv = 1.f / l;
     if (kh == 0 && q0 + r < N)
-        p.stats[(((long long)b * p.H + h) * 4 + type) * N + q0 + r] = make_float2(m, linv);
+        p.stats[(((long long)b * p.H + h) * 4 + type) * N + q0 + r] = make_float2(m, linv);   // m in LOG2 units (bf16x3 accum expects that)
 
     if (FLASH) {
         __syncthreads();     // every wave has finished reading the ring: reuse it for the output transpose
@@ -435,9 +443,6 @@ __global__ __launch_bounds__(256, 2) void attn_rowpass_kernel(RowpassArgs p) {
     if (p.qkvs && p.vt) {
         if (flash) rowpass_body_bf<true>(p, smem, b, h, 0, blockIdx.x);
         else rowpass_body_bf<false>(p, smem, b, h, type, blockIdx.x);
-    } else if (p.qkvs) {
-        if (flash) rowpass_body<true, true>(p, smem, b, h, 0, blockIdx.x);
-        else rowpass_body<false, true>(p, smem, b, h, type, blockIdx.x);
     } else {
         if (flash) rowpass_body<true, false>(p, smem, b, h, 0, blockIdx.x);
         else rowpass_body<false, false>(p, smem, b, h, type, blockIdx.x);
@@ -531,11 +536,27 @@ __global__ __launch_bounds__(256, 1) void attn_accum_kernel(AccumArgs p) {
                     for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(yf[e], xf[e], s, 0, 0, 0);
                 }
             }
+            if (BF) {
+                // bf16x3 path: row stats were written in log2 units by rowpass_body_bf
+                const float c2 = p.scale * 1.4426950408889634f;
+                if (kt * 64 + wk * 32 + 32 > N) {       // wave-uniform: only the last key tile holds keys >= N
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int key = kt * 64 + wk * 32 + c32_row(e, lane);
-                const float pr = __expf(s[e] * p.scale - ml.x) * ml.y;
-                acc[e] += (key < N) ? pr : 0.f;
+                    for (int e = 0; e < 16; ++e) {
+                        const int key = kt * 64 + wk * 32 + c32_row(e, lane);
+                        const float pr = __builtin_amdgcn_exp2f(fmaf(s[e], c2, -ml.x));
+                        acc[e] += (key < N) ? pr * ml.y : 0.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[e] = fmaf(__builtin_amdgcn_exp2f(fmaf(s[e], c2, -ml.x)), ml.y, acc[e]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = kt * 64 + wk * 32 + c32_row(e, lane);
+                    const float pr = __expf(s[e] * p.scale - ml.x) * ml.y;
+                    acc[e] += (key < N) ? pr : 0.f;
+                }
             }
         };
         if (SURGERY) {
@@ -596,6 +617,7 @@ int excel_launch_attn_rowpass(const float* qkvh, float* out, float* stats, int B
     ProfScope prof__(PROF_ATTN_ROWPASS, st);
     EXCEL_CHECK_ARG(hd == HD, "attention: head_dim must be 64 (got %d)", hd);
     EXCEL_CHECK_ARG(ntypes == 1 || ntypes == 4, "attention: ntypes must be 1 or 4");
+    EXCEL_CHECK_ARG(!qkvs || vt, "attention: the bf16x3 row pass needs V^T (vt) next to the split q|k|v");
     RowpassArgs a{qkvh, out, reinterpret_cast<float2*>(stats), B, H, N, scale, split_out, qkvs, flash_nq, vt, vt_kp};
     hipLaunchKernelGGL(attn_rowpass_kernel, dim3(cdiv(N, 128), B * H, ntypes), dim3(256), 0, st, a);
     EXCEL_CHECK_LAUNCH("attn_rowpass");
