@@ -158,7 +158,7 @@ extern "C" int excel_gemm_bf16x3(const void* A_split, const void* W_split, float
                                  int M, int N, int K, int act, int split_out, void* stream) {
     EXCEL_CHECK_ARG(A_split && W_split && C, "gemm_bf16x3: null argument");
     GemmBfArgs g = gemm_bf_args(A_split, (const unsigned short*)W_split, C, C, bias, residual, M, N, K, N, N, act,
-                                split_out == 99 ? 99 : (split_out ? GEMM_OUT_SPLIT_BF16 : GEMM_OUT_PLAIN));
+                                split_out ? GEMM_OUT_SPLIT_BF16 : GEMM_OUT_PLAIN);
     return excel_launch_gemm_bf16x3(g, ST(stream));
 }
 

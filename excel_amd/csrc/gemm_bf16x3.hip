@@ -34,8 +34,8 @@ typedef unsigned short u16;
 
 // Shared epilogue of the GEMM kernels: bias -> activation -> (+ residual) -> store, specialised per output mode so the
 // 64 accumulator elements of a thread see no per-element mode branches, integer divisions or 64-bit multiplies.
-template <int OUT_MODE>
-__device__ __forceinline__ void bf_epilogue(const GemmBfArgs& p, const f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn, int lane) {
+template <int OUT_MODE, int TI>
+__device__ __forceinline__ void bf_epilogue(const GemmBfArgs& p, const f32x16 (&acc)[TI][2], int m0, int n0, int wm, int wn, int lane) {
     const int r = lane & 31;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -52,8 +52,8 @@ __device__ __forceinline__ void bf_epilogue(const GemmBfArgs& p, const f32x16 (&
             qcol_off = ((long long)qt * p.heads + qh) * p.tokN * p.hd + qd;     // + (b*3*heads*tokN + n) * hd per row
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int rbase = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
+        for (int i = 0; i < TI; ++i) {
+            const int rbase = m0 + wm * (TI * 32) + i * 32 + 4 * (lane >> 5);
             int qb = 0, qn = 0;
             if (OUT_MODE == GEMM_OUT_QKV_HEADMAJOR) { qb = rbase / p.tokN; qn = rbase - qb * p.tokN; }
 #pragma unroll
@@ -92,8 +92,8 @@ __device__ __forceinline__ void bf_epilogue(const GemmBfArgs& p, const f32x16 (&
 // 4-byte scatters (two 128-B segments per instruction; measured 28 % of the fc1 GEMM).  Each wave instead transposes its
 // 64x64 tile through 2 x (32 x 68-float) LDS rounds and stores row-contiguous 16-byte vectors: bias / residual become
 // float4 loads, fp32 rows are written as full 256-B segments, split-bf16 rows as 8-byte hi/lo groups.
-template <int OUT_MODE>
-__device__ __forceinline__ void bf_epilogue_lds(const GemmBfArgs& p, const f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn,
+template <int OUT_MODE, int TI>
+__device__ __forceinline__ void bf_epilogue_lds(const GemmBfArgs& p, const f32x16 (&acc)[TI][2], int m0, int n0, int wm, int wn,
                                                 int lane, float* scratch) {
     const int r = lane & 31;
     const int c4 = (lane & 15) * 4;
@@ -110,7 +110,7 @@ __device__ __forceinline__ void bf_epilogue_lds(const GemmBfArgs& p, const f32x1
         qd = rem - qh * p.hd;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TI; ++i) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -119,7 +119,7 @@ __device__ __forceinline__ void bf_epilogue_lds(const GemmBfArgs& p, const f32x1
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int row_l = it * 4 + (lane >> 4);
-            const int row = m0 + wm * 64 + i * 32 + row_l;
+            const int row = m0 + wm * (TI * 32) + i * 32 + row_l;
             f32x4 v = *reinterpret_cast<const f32x4*>(&scratch[row_l * 68 + c4]);
             if (row >= p.M || !col_ok) continue;
             v += bias4;
@@ -154,30 +154,32 @@ __device__ __forceinline__ void bf_epilogue_lds(const GemmBfArgs& p, const f32x1
     }
 }
 
-// WM waves along M (block tile = WM*64 x 128), 2 along N; NSTAGE-deep LDS ring filled by global_load_lds.
-//   <2, 2>: 128x128 tile, 64 KB LDS, 2 workgroups/CU, one __syncthreads per k-step (small problems / tails)
-//   <4, 3>: 256x128 tile, 144 KB LDS, 1 workgroup (8 waves)/CU, two k-steps of loads in flight behind a COUNTED
-//           s_waitcnt vmcnt + raw s_barrier (a miss to MALL/HBM no longer stalls the step that issued it), 25 % fewer
-//           L2->LDS bytes per flop.
-template <int WM, int NSTAGE>
-__global__ __launch_bounds__(WM * 128, (WM == 2) ? 2 : 2) void gemm_bf16x3_kernel(GemmBfArgs p) {
-    constexpr int BM = WM * 64;
-    constexpr int STAGE = (BM + TBN) * TROW;                 // u16 elements per stage: A rows then B rows
-    constexpr int NWAVE = WM * 2;
+// WM x WN waves, each owning TI x 2 MFMA tiles (TI*32 rows x 64 columns): block tile = (WM*TI*32) x (WN*64);
+// NSTAGE-deep LDS ring filled by global_load_lds.  The staging path (L2 -> LDS) saturates near 27 GB/s per CU whatever
+// the tile, so the lever is bytes per flop:
+//   <2,2,2,2>: 128x128, 64 KB LDS, 2 workgroups/CU                      (small / batched problems)
+//   <4,2,2,3>: 256x128, 144 KB, 8 waves, counted vmcnt ring             (N = 768 GEMMs: keeps 594 tiles for 256 CUs)
+//   <2,4,4,2>: 256x256, 128 KB, 8 waves x (128x64), half the bytes/flop of 128x128   (QKV, fc1)
+template <int WM, int WN, int TI, int NSTAGE>
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16x3_kernel(GemmBfArgs p) {
+    constexpr int BM = WM * TI * 32, BN = WN * 64;
+    constexpr int STAGE = (BM + BN) * TROW;                  // u16 elements per stage: A rows then B rows
+    constexpr int NWAVE = WM * WN;
     constexpr int A_PER_WAVE = (BM / 8) / NWAVE;             // 1-KB row groups (8 rows) each wave stages per k-step
-    constexpr int B_PER_WAVE = (TBN / 8) / NWAVE;
+    constexpr int B_PER_WAVE = (BN / 8) / NWAVE;
     constexpr int PER_WAVE = A_PER_WAVE + B_PER_WAVE;
+    static_assert(A_PER_WAVE * NWAVE * 8 == BM && B_PER_WAVE * NWAVE * 8 == BN, "tile rows must split evenly over the waves");
     // each row is 8 x 16-B chunks [hi 32 | lo 32], chunk c stored at slot c ^ ((row>>1)&7)
     __shared__ __attribute__((aligned(1024))) u16 smem[NSTAGE * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, kh = lane >> 5;
-    const int tiles_n = (p.N + TBN - 1) / TBN, tiles_m = (p.M + BM - 1) / BM;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
     const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     const int tm = id / tiles_n, tn = id % tiles_n;
-    const int m0 = tm * BM, n0 = tn * TBN;
+    const int m0 = tm * BM, n0 = tn * BN;
     if (p.batch > 1) {      // batched problems (blockIdx.y): advance the operand / output bases (block-uniform)
         const long long z = blockIdx.y;
         p.A += z * p.sA; p.B += z * p.sB; p.C += z * p.sC; p.Cs += z * p.sCs;
@@ -206,9 +208,9 @@ __global__ __launch_bounds__(WM * 128, (WM == 2) ? 2 : 2) void gemm_bf16x3_kerne
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -223,10 +225,10 @@ __global__ __launch_bounds__(WM * 128, (WM == 2) ? 2 : 2) void gemm_bf16x3_kerne
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             const int ch = ((s2 * 2 + kh) ^ sw) * 8, cl = ((4 + s2 * 2 + kh) ^ sw) * 8;
-            bf16x8 ah[2], al[2], bh[2], bl[2];
+            bf16x8 ah[TI], al[TI], bh[2], bl[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const u16* rowp = as + (wm * 64 + i * 32 + r) * TROW;
+            for (int i = 0; i < TI; ++i) {
+                const u16* rowp = as + (wm * (TI * 32) + i * 32 + r) * TROW;
                 ah[i] = *reinterpret_cast<const bf16x8*>(rowp + ch);
                 al[i] = *reinterpret_cast<const bf16x8*>(rowp + cl);
             }
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(WM * 128, (WM == 2) ? 2 : 2) void gemm_bf16x3_kerne
                 bl[j] = *reinterpret_cast<const bf16x8*>(rowp + cl);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     // small terms first, the dominant hi.hi product last
@@ -265,6 +267,7 @@ __global__ __launch_bounds__(WM * 128, (WM == 2) ? 2 : 2) void gemm_bf16x3_kerne
         int stage = 0;
         for (int kt = 0; kt < nk; ++kt) {
             if (kt + 1 < nk) {
+                static_assert(NSTAGE == 2 || PER_WAVE == 6 || PER_WAVE == 8, "add the counted wait for this configuration");
                 if (PER_WAVE == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             } else {
@@ -275,29 +278,20 @@ __global__ __launch_bounds__(WM * 128, (WM == 2) ? 2 : 2) void gemm_bf16x3_kerne
             compute(stage);
             stage = (stage + 1 == NSTAGE) ? 0 : stage + 1;
         }
+        __syncthreads();
     }
 
-    switch (p.out_mode) {
-        case 99:   // dev: no epilogue (k-loop timing); keeps the accumulators live
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
-            break;
-        default: {
-            const bool vec = (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 && (p.hd & 3) == 0;
-            if (vec) {
-                __syncthreads();   // every wave is done with the staging ring: reuse it as per-wave transpose scratch
-                float* scratch = reinterpret_cast<float*>(smem) + wave * (32 * 68);
-                if (p.out_mode == GEMM_OUT_SPLIT_BF16) bf_epilogue_lds<GEMM_OUT_SPLIT_BF16>(p, acc, m0, n0, wm, wn, lane, scratch);
-                else if (p.out_mode == GEMM_OUT_QKV_HEADMAJOR) bf_epilogue_lds<GEMM_OUT_QKV_HEADMAJOR>(p, acc, m0, n0, wm, wn, lane, scratch);
-                else bf_epilogue_lds<GEMM_OUT_PLAIN>(p, acc, m0, n0, wm, wn, lane, scratch);
-            } else {
-                if (p.out_mode == GEMM_OUT_SPLIT_BF16) bf_epilogue<GEMM_OUT_SPLIT_BF16>(p, acc, m0, n0, wm, wn, lane);
-                else if (p.out_mode == GEMM_OUT_QKV_HEADMAJOR) bf_epilogue<GEMM_OUT_QKV_HEADMAJOR>(p, acc, m0, n0, wm, wn, lane);
-                else bf_epilogue<GEMM_OUT_PLAIN>(p, acc, m0, n0, wm, wn, lane);
-            }
-        }
+    const bool vec = (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 && (p.hd & 3) == 0;
+    if (vec) {
+        // every wave is past the last barrier of the k-loop: the staging ring is free -> per-wave transpose scratch
+        float* scratch = reinterpret_cast<float*>(smem) + wave * (32 * 68);
+        if (p.out_mode == GEMM_OUT_SPLIT_BF16) bf_epilogue_lds<GEMM_OUT_SPLIT_BF16, TI>(p, acc, m0, n0, wm, wn, lane, scratch);
+        else if (p.out_mode == GEMM_OUT_QKV_HEADMAJOR) bf_epilogue_lds<GEMM_OUT_QKV_HEADMAJOR, TI>(p, acc, m0, n0, wm, wn, lane, scratch);
+        else bf_epilogue_lds<GEMM_OUT_PLAIN, TI>(p, acc, m0, n0, wm, wn, lane, scratch);
+    } else {
+        if (p.out_mode == GEMM_OUT_SPLIT_BF16) bf_epilogue<GEMM_OUT_SPLIT_BF16, TI>(p, acc, m0, n0, wm, wn, lane);
+        else if (p.out_mode == GEMM_OUT_QKV_HEADMAJOR) bf_epilogue<GEMM_OUT_QKV_HEADMAJOR, TI>(p, acc, m0, n0, wm, wn, lane);
+        else bf_epilogue<GEMM_OUT_PLAIN, TI>(p, acc, m0, n0, wm, wn, lane);
     }
 }
 
@@ -368,14 +362,18 @@ int excel_launch_gemm_bf16x3(const GemmBfArgs& p, hipStream_t stream) {
     EXCEL_CHECK_ARG(p.out_mode != GEMM_OUT_SPLIT_BF16 || (p.N % 32) == 0, "gemm_bf16x3: split output needs N %% 32 == 0");
     EXCEL_CHECK_ARG((p.lda % 8) == 0 && (p.ldb % 8) == 0 && p.lda >= 2 * p.K && p.ldb >= 2 * p.K, "gemm_bf16x3: bad lda/ldb");
     EXCEL_CHECK_ARG((((uintptr_t)p.A | (uintptr_t)p.B) & 15) == 0, "gemm_bf16x3: operands must be 16-byte aligned");
-    static const char* force = getenv("EXCEL_BF_TILE");      // dev knob: "128" | "256"
-    const bool big = force ? !strcmp(force, "256") : (p.M >= 2048);
-    if (big) {
-        const int tiles = cdiv(p.M, 256) * cdiv(p.N, TBN);
-        hipLaunchKernelGGL((gemm_bf16x3_kernel<4, 3>), dim3(tiles, p.batch > 1 ? p.batch : 1), dim3(512), 0, stream, p);
+    static const char* force = getenv("EXCEL_BF_TILE");      // dev knob: "128" | "256x128" | "256"
+    int kind;   // 0: 128x128, 1: 256x128, 2: 256x256
+    if (force) kind = !strcmp(force, "256") ? 2 : (!strcmp(force, "256x128") ? 1 : 0);
+    else if (p.M < 2048 || (p.batch > 1)) kind = 0;
+    else kind = (p.N >= 1536) ? 2 : 1;
+    const int nb = p.batch > 1 ? p.batch : 1;
+    if (kind == 2) {
+        hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 4, 4, 2>), dim3(cdiv(p.M, 256) * cdiv(p.N, 256), nb), dim3(512), 0, stream, p);
+    } else if (kind == 1) {
+        hipLaunchKernelGGL((gemm_bf16x3_kernel<4, 2, 2, 3>), dim3(cdiv(p.M, 256) * cdiv(p.N, 128), nb), dim3(512), 0, stream, p);
     } else {
-        const int tiles = cdiv(p.M, TBM) * cdiv(p.N, TBN);
-        hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 2>), dim3(tiles, p.batch > 1 ? p.batch : 1), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 2, 2, 2>), dim3(cdiv(p.M, 128) * cdiv(p.N, 128), nb), dim3(256), 0, stream, p);
     }
     EXCEL_CHECK_LAUNCH("gemm_bf16x3");
     return EXCEL_OK;
