@@ -17,6 +17,7 @@
 //                 and folds W[1:,1:]/6 into the layer-mean affinity the random walk consumes (utils/affutils.py:180,197).
 //   The N x N x heads x 4 probability tensors the reference materialises (118 MB/image/layer) never exist;
 //   the price is one extra score GEMM per type, deterministic (no atomics).
+#include <stdlib.h>
 #include "common.h"
 #include "excel_internal.h"
 
@@ -462,6 +463,7 @@ struct AccumArgs {
     float aff_scale;      // 1/attn_layers
     int aff_init;         // 1: w_aff = ..., 0: w_aff += ...
     const unsigned short* qkvs;   // split-bf16 q|k|v for bf16x3 scores (null = exact fp32)
+    int dbg;              // dev: bit0 skip scoring, bit1 skip tile loads, bit2 skip the output epilogue
     int a_sum_split;      // 1: a_sum is written in split-bf16 format [B,N][2*NP] (NP % 32 == 0): A operand of the bf16x3 A_sum.V GEMM
 };
 
@@ -577,6 +579,21 @@ __global__ __launch_bounds__(256, 1) void attn_accum_kernel(AccumArgs p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) tb[r * 33 + c32_row(e, lane)] = acc[e];
         __builtin_amdgcn_s_waitcnt(0xc07f);
+        // unrolled: the 16 read-modify-write round trips on w_aff must be in flight together, not one after the other
+        // (a rolled loop serialised 16 dependent global loads per wave and dominated the kernel)
+        float oldw[16];
+        if (which == 1 && p.w_aff && !p.aff_init) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int qg = qbase + 2 * i + kh, kg = kbase + r;
+                const long long P = N - 1;
+                oldw[i] = (qg < N && qg >= 1 && kg >= 1 && kg < N) ? p.w_aff[((long long)b * P + (qg - 1)) * P + (kg - 1)] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oldw[i] = 0.f;
+        }
+#pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int qq = 2 * i + kh;
             const int qg = qbase + qq, kg = kbase + r;
@@ -600,8 +617,215 @@ __global__ __launch_bounds__(256, 1) void attn_accum_kernel(AccumArgs p) {
                 if (p.w_aff && qg >= 1 && kg >= 1 && kg < N) {
                     const long long P = N - 1;
                     float* dst = p.w_aff + ((long long)b * P + (qg - 1)) * P + (kg - 1);
-                    const float add = pw * p.aff_scale;
-                    *dst = p.aff_init ? add : (*dst + add);
+                    *dst = oldw[i] + pw * p.aff_scale;
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+    };
+    if (SURGERY) emit(accA, 0);
+    emit(accW, 1);
+}
+
+// ------------------------------------------------------------------------------------------------ accum, bf16x3 pipeline
+// Production variant of the accumulate pass.  Same maths as attn_accum_kernel<.,true>, restructured after measuring it:
+//   * workgroup = 128 queries x 64 keys, 8 waves (4 x 2, one 32x32 score tile each): two waves per SIMD, so one wave's
+//     exp/accumulate VALU work overlaps the other's MFMAs, and 25 % fewer operand bytes per score than 64 x 64;
+//   * the six operand tiles (q|k|v rows of the query tile X: 32 KB each, of the key tile Y: 16 KB each) and the row stats
+//     are streamed by global_load_lds on a ROLLING schedule, so the tiles of head h+1 land while head h is scored.
+// Per head, 4 steps, one raw s_barrier each (X tile = 4, Y tile = 2, stats = 2 wave-instructions per wave):
+//     step 0  qq (XQ,YQ)  issue XV,YV(h)                 wait XQ,YQ,stats(h): newest XK,YK(h)          -> vmcnt(6)
+//     step 1  qk (XQ,YK)  issue YQ,stats(h+1)            wait YK(h):          newest XV,YV(h)          -> vmcnt(6)
+//     step 2  kk (XK,YK)  issue XQ(h+1)                  (barrier only: frees XQ)
+//     step 3  vv (XV,YV)  issue XK,YK(h+1)               wait XV,YV(h):       newest YQ,stats,XQ(h+1)  -> vmcnt(8) / (0) last
+// A slot is refilled only after the barrier that follows its last reader; vmcnt retires loads in issue order.  There is
+// no ordinary global load inside the loop (it would force a vmcnt(0) drain of the LDS-DMA queue).
+template <bool SURGERY>
+__global__ __launch_bounds__(512, 2) void attn_accum_bf_kernel(AccumArgs p) {
+    constexpr int XT = 128 * 128, YT = 64 * 128;                    // u16 elements of an X tile (32 KB) / Y tile (16 KB)
+    constexpr int NTYPE = SURGERY ? 4 : 1;
+    // surgery: XQ XK XV | YQ YK YV ; else double-buffered (XQ, YK)
+    constexpr int TILES_EL = SURGERY ? 3 * XT + 3 * YT : 2 * (XT + YT);
+    __shared__ __attribute__((aligned(1024))) u16 tiles[TILES_EL];
+    __shared__ __attribute__((aligned(1024))) float2 lstats[2 * NTYPE * 128 + 32];   // [buffer][type][128 q] + a dump slot
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, kh = lane >> 5;
+    const int wq = wave >> 1, wk = wave & 1;
+    const int kt = blockIdx.x, qt = blockIdx.y, b = blockIdx.z;
+    const int N = p.N;
+
+    // staging: the tile image is lane-linear (one wave-instruction = 1 KB = 4 rows x 16 chunks), so the swizzle
+    // (chunk c at slot c ^ (row & 15)) is applied to the source address.  X: wave w rows 16w..16w+15 (4 instr);
+    // Y: rows 8w..8w+7 (2 instr).
+    int rowx[4], coffx[4], rowy[2], coffy[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row_l = wave * 16 + j * 4 + (lane >> 4);
+        coffx[j] = ((lane & 15) ^ (row_l & 15)) * 8;
+        rowx[j] = min(qt * 128 + row_l, N - 1);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row_l = wave * 8 + j * 4 + (lane >> 4);
+        coffy[j] = ((lane & 15) ^ (row_l & 15)) * 8;
+        rowy[j] = min(kt * 64 + row_l, N - 1);
+    }
+    auto issue_x = [&](int off, int typ, int h) {
+        const u16* src = p.qkvs + (((long long)b * 3 + typ) * p.H + h) * (long long)N * 128;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (long long)rowx[j] * 128 + coffx[j]),
+                                             (__attribute__((address_space(3))) void*)(tiles + off + (wave * 16 + j * 4) * 128), 16, 0, 0);
+    };
+    auto issue_y = [&](int off, int typ, int h) {
+        const u16* src = p.qkvs + (((long long)b * 3 + typ) * p.H + h) * (long long)N * 128;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (long long)rowy[j] * 128 + coffy[j]),
+                                             (__attribute__((address_space(3))) void*)(tiles + off + (wave * 8 + j * 4) * 128), 16, 0, 0);
+    };
+    // row stats of head h: NTYPE x 128 float2 = NTYPE KB; every wave moves 2 x 256 B (global_load_lds_dword)
+    auto issue_stats = [&](int h) {
+        float* dst = reinterpret_cast<float*>(lstats + (h & 1) * NTYPE * 128);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int piece = wave * 2 + j;                          // 16 pieces of 64 floats (= 32 float2)
+            if (SURGERY || piece < 4) {
+                const int ty = piece >> 2, q32 = (piece & 3) * 32 + (lane >> 1);
+                const float* src = reinterpret_cast<const float*>(p.stats + (((long long)b * p.H + h) * 4 + ty) * N + min(qt * 128 + q32, N - 1)) + (lane & 1);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(dst + piece * 64), 4, 0, 0);
+            } else {   // keep the per-wave instruction count uniform (counted vmcnt): harmless reload of piece 0
+                const float* src = reinterpret_cast<const float*>(p.stats + (((long long)b * p.H + h) * 4) * N + min(qt * 128 + (lane >> 1), N - 1)) + (lane & 1);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(reinterpret_cast<float*>(lstats) + 2 * NTYPE * 256), 4, 0, 0);
+            }
+        }
+    };
+
+    f32x16 accW, accA;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { accW[e] = 0.f; accA[e] = 0.f; }
+    const float c2 = p.scale * 1.4426950408889634f;               // row stats are in log2 units (rowpass_body_bf)
+    const bool last_kt = kt * 64 + wk * 32 + 32 > N;              // wave-uniform: only the last key tile holds keys >= N
+
+    auto score = [&](int offY, int offX, int type, int h, f32x16& acc) {
+        if (p.dbg & 1) return;
+        const float2 ml = lstats[((h & 1) * NTYPE + type) * 128 + wq * 32 + r];
+        const u16* y16 = tiles + offY + (wk * 32 + r) * 128;
+        const u16* x16 = tiles + offX + (wq * 32 + r) * 128;
+        f32x16 s;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int ch = ((s4 * 2 + kh) ^ (r & 15)) * 8, cl = ((8 + s4 * 2 + kh) ^ (r & 15)) * 8;
+            const bf16x8 yh = *reinterpret_cast<const bf16x8*>(y16 + ch), yl = *reinterpret_cast<const bf16x8*>(y16 + cl);
+            const bf16x8 xh = *reinterpret_cast<const bf16x8*>(x16 + ch), xl = *reinterpret_cast<const bf16x8*>(x16 + cl);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl, xh, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh, xl, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh, xh, s, 0, 0, 0);
+        }
+        if (last_kt) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = kt * 64 + wk * 32 + c32_row(e, lane);
+                const float pr = __builtin_amdgcn_exp2f(fmaf(s[e], c2, -ml.x));
+                acc[e] += (key < N) ? pr * ml.y : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = fmaf(__builtin_amdgcn_exp2f(fmaf(s[e], c2, -ml.x)), ml.y, acc[e]);
+        }
+    };
+
+    if (SURGERY) {
+        constexpr int XQ = 0, XK = XT, XV = 2 * XT, YQ = 3 * XT, YK = 3 * XT + YT, YV = 3 * XT + 2 * YT;
+        issue_y(YQ, 0, 0);
+        issue_stats(0);
+        issue_x(XQ, 0, 0);
+        issue_x(XK, 1, 0);
+        issue_y(YK, 1, 0);
+        for (int h = 0; h < p.H; ++h) {
+            const bool more = h + 1 < p.H && !(p.dbg & 2);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          // YQ,stats,XQ(h) landed (XK,YK(h) may be in flight)
+            __builtin_amdgcn_s_barrier();
+            if (!(p.dbg & 2) || h == 0) { issue_x(XV, 2, h); issue_y(YV, 2, h); }
+            score(YQ, XQ, 1, h, accA);                                // q.q
+            if (!(p.dbg & 2) || h == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // XK,YK(h) landed (XV,YV in flight)
+            __builtin_amdgcn_s_barrier();
+            if (more) { issue_y(YQ, 0, h + 1); issue_stats(h + 1); }
+            score(YK, XQ, 0, h, accW);                                // q.k
+            __builtin_amdgcn_s_barrier();                             // everyone is done with XQ(h)
+            if (more) issue_x(XQ, 0, h + 1);
+            score(YK, XK, 2, h, accA);                                // k.k
+            if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // XV,YV(h) landed (YQ,stats,XQ(h+1) in flight)
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (more) { issue_x(XK, 1, h + 1); issue_y(YK, 1, h + 1); }
+            score(YV, XV, 3, h, accA);                                // v.v
+        }
+    } else {
+        // head-mean weights of an nn.MultiheadAttention block: only q.k; (XQ, YK, stats) double buffered
+        issue_x(0, 0, 0);
+        issue_y(XT, 1, 0);
+        issue_stats(0);
+        for (int h = 0; h < p.H; ++h) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int cur = (h & 1) * (XT + YT), nxt = (XT + YT) - cur;
+            if (h + 1 < p.H) { issue_x(nxt, 0, h + 1); issue_y(nxt + XT, 1, h + 1); issue_stats(h + 1); }
+            score(cur + XT, cur, 0, h, accW);
+        }
+    }
+    __syncthreads();
+    if (p.dbg & 4) { if (accA[0] + accW[0] == 12345.f) p.a_sum[0] = 1.f; return; }
+
+    // transpose each wave's [key][q] tile through LDS (pitch 33) and store rows of q with consecutive keys
+    float* tb = reinterpret_cast<float*>(tiles) + wave * (32 * 33);
+    const int qbase = qt * 128 + wq * 32, kbase = kt * 64 + wk * 32;
+    auto emit = [&](const f32x16& acc, int which) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tb[r * 33 + c32_row(e, lane)] = acc[e];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        // unrolled: the 16 read-modify-write round trips on w_aff must be in flight together, not one after the other
+        float oldw[16];
+        if (which == 1 && p.w_aff && !p.aff_init) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int qg = qbase + 2 * i + kh, kg = kbase + r;
+                const long long P = N - 1;
+                oldw[i] = (qg < N && qg >= 1 && kg >= 1 && kg < N) ? p.w_aff[((long long)b * P + (qg - 1)) * P + (kg - 1)] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oldw[i] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int qq = 2 * i + kh;
+            const int qg = qbase + qq, kg = kbase + r;
+            const float v = tb[qq * 33 + r];
+            if (qg >= N) continue;
+            if (which == 0) {
+                if (kg < p.NP) {
+                    const float av = v * (1.f / 3.f);
+                    if (p.a_sum_split) {
+                        __bf16* o = reinterpret_cast<__bf16*>(p.a_sum) + ((long long)b * N + qg) * 2 * p.NP + split_off(kg, 0);
+                        const __bf16 hi = (__bf16)av;
+                        o[0] = hi;
+                        o[32] = (__bf16)(av - (float)hi);
+                    } else {
+                        p.a_sum[((long long)b * N + qg) * p.NP + kg] = av;
+                    }
+                }
+            } else {
+                const float pw = v * p.w_scale;
+                if (p.attn_out && kg < N) p.attn_out[((long long)b * N + qg) * N + kg] = pw;
+                if (p.w_aff && qg >= 1 && kg >= 1 && kg < N) {
+                    const long long P = N - 1;
+                    p.w_aff[((long long)b * P + (qg - 1)) * P + (kg - 1)] = oldw[i] + pw * p.aff_scale;
                 }
             }
         }
@@ -630,9 +854,15 @@ int excel_launch_attn_accum(const float* qkvh, const float* stats, float* a_sum,
     ProfScope prof__(PROF_ATTN_ACCUM, st);
     EXCEL_CHECK_ARG(hd == HD, "attention: head_dim must be 64 (got %d)", hd);
     EXCEL_CHECK_ARG(!surgery || (a_sum && NP >= N && NP <= cdiv(N, 64) * 64), "attn_accum: bad a_sum/NP");
-    AccumArgs a{qkvh, reinterpret_cast<const float2*>(stats), a_sum, w_aff, attn_out, B, H, N, NP, scale, w_scale, aff_scale, aff_init, qkvs, a_sum_split};
+    AccumArgs a{qkvh, reinterpret_cast<const float2*>(stats), a_sum, w_aff, attn_out, B, H, N, NP, scale, w_scale, aff_scale, aff_init, qkvs, 0, a_sum_split};
     dim3 grid(cdiv(N, 64), cdiv(N, 64), B);
-    if (surgery && qkvs)
+    static const char* old = getenv("EXCEL_ACCUM_OLD");
+    { static const char* d = getenv("EXCEL_ACCUM_DBG"); if (d) a.dbg = atoi(d); }
+    if (qkvs && !old) {
+        dim3 g2(cdiv(N, 64), cdiv(N, 128), B);
+        if (surgery) hipLaunchKernelGGL((attn_accum_bf_kernel<true>), g2, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((attn_accum_bf_kernel<false>), g2, dim3(512), 0, st, a);
+    } else if (surgery && qkvs)
         hipLaunchKernelGGL((attn_accum_kernel<true, true>), grid, dim3(256), 0, st, a);
     else if (surgery)
         hipLaunchKernelGGL((attn_accum_kernel<true, false>), grid, dim3(256), 0, st, a);

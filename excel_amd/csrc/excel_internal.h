@@ -39,6 +39,7 @@ struct GemmBfArgs {
     int act, out_mode;
     int tokN, heads, hd;
     unsigned short* qkv_split;   // GEMM_OUT_QKV_HEADMAJOR: also write q|k|v head-major in split format [B,3,H,N][2][hd] (may be null)
+    int dbg;                     // dev only: bit0 = skip MFMA/LDS-read work, bit1 = skip the staging loads after the first tile
     int batch;                   // >= 1: blockIdx.y; operands advance by sA / sB bf16 elements, C by sC floats, Cs by sCs bf16 elements
     long long sA, sB, sC, sCs;
 };
