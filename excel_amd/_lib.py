@@ -68,6 +68,8 @@ SIGNATURES = {
     "excel_pos_embed_resize": (c_i, [c_f, c_i, c_i, c_i, c_f, c_f]),
     "excel_flip_max_normalize": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f]),
     "excel_prof_enable": (c_i, [c_i]),
+    "excel_prof_set_mask": (c_i, [C.c_ulonglong]),
+    "excel_prof_set_sampling": (c_i, [c_i]),
     "excel_prof_num_categories": (c_i, []),
     "excel_prof_category_name": (C.c_char_p, [c_i]),
     "excel_prof_collect": (c_i, [C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),

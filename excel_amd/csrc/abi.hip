@@ -21,6 +21,9 @@ extern "C" int excel_abi_version(void) { return 1; }
 
 // ------------------------------------------------------------------------------------ profiling hooks
 bool g_excel_prof_on = false;
+unsigned long long g_excel_prof_mask = ~0ull;
+int g_excel_prof_every = 1;
+unsigned g_excel_prof_seen[PROF_NCAT];
 namespace {
 struct ProfRec { int cat; hipEvent_t a, b; };
 std::vector<ProfRec> g_prof_recs;
@@ -46,6 +49,15 @@ void excel_prof_end(int cat, hipStream_t st) {
 }
 extern "C" int excel_prof_enable(int on) {
     g_excel_prof_on = on != 0;
+    return EXCEL_OK;
+}
+extern "C" int excel_prof_set_mask(unsigned long long mask) {
+    g_excel_prof_mask = mask;
+    return EXCEL_OK;
+}
+extern "C" int excel_prof_set_sampling(int every) {
+    g_excel_prof_every = every > 0 ? every : 1;
+    for (int c = 0; c < PROF_NCAT; ++c) g_excel_prof_seen[c] = 0;
     return EXCEL_OK;
 }
 extern "C" int excel_prof_num_categories(void) { return PROF_NCAT; }

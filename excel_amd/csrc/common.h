@@ -73,11 +73,15 @@ enum ExcelProfCat {
     PROF_ARGMAX, PROF_CONFUSION, PROF_OTHER, PROF_NCAT
 };
 extern bool g_excel_prof_on;
+extern unsigned long long g_excel_prof_mask;   // bit c set: category c is bracketed with events
+extern int g_excel_prof_every;                 // bracket every n-th launch of a category (an event pair costs ~10 us of GPU idle)
+extern unsigned g_excel_prof_seen[];
 void excel_prof_begin(int cat, hipStream_t st, double work);
 void excel_prof_end(int cat, hipStream_t st);
 struct ProfScope {
     int cat; hipStream_t st; bool on;
-    ProfScope(int c, hipStream_t s, double work = 0.0) : cat(c), st(s), on(g_excel_prof_on) { if (on) excel_prof_begin(cat, st, work); }
+    ProfScope(int c, hipStream_t s, double work = 0.0)
+        : cat(c), st(s), on(g_excel_prof_on && ((g_excel_prof_mask >> c) & 1) && (g_excel_prof_seen[c]++ % g_excel_prof_every) == 0) { if (on) excel_prof_begin(cat, st, work); }
     ~ProfScope() { if (on) excel_prof_end(cat, st); }
 };
 

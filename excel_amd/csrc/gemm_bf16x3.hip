@@ -73,7 +73,7 @@ __device__ __forceinline__ void bf_epilogue(const GemmBfArgs& p, const f32x16 (&
                     int n = qn + dr, b = qb;
                     while (n >= p.tokN) { n -= p.tokN; ++b; }
                     const long long off = qcol_off + ((long long)b * 3 * p.heads * p.tokN + n) * p.hd;
-                    p.C[off] = v;
+                    if (!p.qkv_split || col >= 2 * p.heads * p.hd) p.C[off] = v;
                     if (p.qkv_split) {     // same (b,type,head,n) row, [hi hd | lo hd] bf16: operand of the bf16x3 attention scores
                         __bf16* o = reinterpret_cast<__bf16*>(p.qkv_split) + (off - qd) * 2 + qd;
                         const __bf16 hi = (__bf16)v;
@@ -141,7 +141,8 @@ __device__ __forceinline__ void bf_epilogue_lds(const GemmBfArgs& p, const f32x1
                 } else {   // q|k|v head-major: fp32 for P.V / A.V, and [hi hd | lo hd] bf16 for the bf16x3 scores
                     const int b = row / p.tokN, n = row - b * p.tokN;
                     const long long rowidx = (((long long)b * 3 + qt) * p.heads + qh) * p.tokN + n;
-                    *reinterpret_cast<f32x4*>(p.C + rowidx * p.hd + qd) = v;
+                    // fp32 q and k are not consumed when the split copy exists (bf16x3 attention): write only v in fp32
+                    if (!p.qkv_split || qt == 2) *reinterpret_cast<f32x4*>(p.C + rowidx * p.hd + qd) = v;
                     if (p.qkv_split) {
                         __bf16* o = reinterpret_cast<__bf16*>(p.qkv_split) + rowidx * 2 * p.hd + qd;
                         *reinterpret_cast<uint2*>(o) = *reinterpret_cast<const uint2*>(hi);

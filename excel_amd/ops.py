@@ -349,7 +349,17 @@ def flip_max_normalize(attr, g):
 
 
 # ------------------------------------------------------------------ live kernel timing (HIP events on the launch stream)
-def prof_enable(on=True):
+def prof_enable(on=True, categories=None, every=1):
+    """categories: iterable of category names to bracket (None = all); every: bracket every n-th launch of a category
+    (each event pair costs ~10 us of GPU idle time, so the timed region samples)."""
+    check(lib().excel_prof_set_sampling(int(every)), "excel_prof_set_sampling")
+    mask = (1 << 64) - 1
+    if categories is not None:
+        names = [lib().excel_prof_category_name(i).decode() for i in range(lib().excel_prof_num_categories())]
+        mask = 0
+        for c in categories:
+            mask |= 1 << names.index(c)
+    check(lib().excel_prof_set_mask(mask), "excel_prof_set_mask")
     check(lib().excel_prof_enable(1 if on else 0), "excel_prof_enable")
 
 

@@ -44,3 +44,47 @@ class TrainingFreePipeline:
             return labels, dict(attr=attr, w_aff=attn_w.w_aff, refined=refined, cams=cams, par_out=par_out,
                                 cls_idx=idx, ncls=ncls)
         return labels
+
+    # ------------------------------------------------------------------ two-stream software pipeline
+    # Stage A (ViT + CAM + random walk + up-sampling: matrix-core bound) and stage B (PAR + argmax + confusion:
+    # HBM bound) use different hardware resources.  run_batch_overlapped enqueues stage A of batch i on stream A and
+    # its stage B on stream B behind an event, so stage B of batch i overlaps stage A of batch i+1.  Results are
+    # identical to run_batch (same kernels, same order per batch); only the issue order across batches changes.
+    def _streams(self):
+        if not hasattr(self, "_sa"):
+            self._sa = torch.cuda.Stream()
+            self._sb = torch.cuda.Stream()
+            self._sb_done = None
+        return self._sa, self._sb
+
+    @torch.no_grad()
+    def run_batch_overlapped(self, inputs, cls_labels, gts=None, label_hw=None):
+        sa, sb = self._streams()
+        cur = torch.cuda.current_stream()
+        B, _, S, _ = inputs.shape
+        g = S // 16
+        H, W = (gts.shape[-2:] if gts is not None else (label_hw or (S, S)))
+        sa.wait_stream(cur)
+        with torch.cuda.stream(sa):
+            _, _, attr, attn_w, _ = self.model(inputs)
+            idx, ncls, nchan = ops.cls_compact(cls_labels, self.smax, want_nchan=True)
+            refined = ops.refine_cams_with_aff_batched(attr, attn_w.w_aff, idx, ncls, g, self.caa_thre)
+            cams = ops.cam_upsample_bkg(refined, ncls, g, H, W)
+            ready = torch.cuda.Event()
+            ready.record(sa)
+        with torch.cuda.stream(sb):
+            sb.wait_event(ready)
+            for t in (cams, nchan, idx, inputs) + ((gts,) if gts is not None else ()):
+                t.record_stream(sb)
+            par_out = ops.par_forward(inputs, cams, self.dilations, self.num_iter, nchan=nchan)
+            labels = ops.argmax_label(par_out, nchan, idx)
+            if gts is not None:
+                self.hist = ops.confusion_accumulate(gts, labels, self.num_classes, self.hist)
+        return labels
+
+    def drain(self):
+        """Make the caller's stream wait for both pipeline streams (call before reading hist / labels)."""
+        if hasattr(self, "_sa"):
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(self._sa)
+            cur.wait_stream(self._sb)

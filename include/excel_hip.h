@@ -184,6 +184,8 @@ int excel_flip_max_normalize(const float* attr, float* out, int B, int g, int F,
  * excel_prof_collect synchronises, fills ms[c] (summed elapsed), launches[c], work[c] (algorithmic FLOPs for the GEMM
  * categories, 0 otherwise) for c < excel_prof_num_categories(), and clears the log. */
 int excel_prof_enable(int on);
+int excel_prof_set_mask(unsigned long long category_mask);   /* bit c: bracket category c (default all) */
+int excel_prof_set_sampling(int every);                      /* bracket every n-th launch of a category (default 1) */
 int excel_prof_num_categories(void);
 const char* excel_prof_category_name(int cat);
 int excel_prof_collect(double* ms /*host*/, long long* launches /*host*/, double* work /*host*/);
