@@ -67,6 +67,8 @@ SIGNATURES = {
     "excel_bilinear_resize": (c_i, [c_f, c_f, c_ll, c_i, c_i, c_i, c_i, c_i, c_f]),
     "excel_pos_embed_resize": (c_i, [c_f, c_i, c_i, c_i, c_f, c_f]),
     "excel_flip_max_normalize": (c_i, [c_f, c_f, c_i, c_i, c_i, c_f]),
+    "excel_lam_scale_accumulate": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f]),
+    "excel_plane_minmax_normalize": (c_i, [c_f, c_ll, c_ll, c_f]),
     "excel_prof_enable": (c_i, [c_i]),
     "excel_prof_set_mask": (c_i, [C.c_ulonglong]),
     "excel_prof_set_sampling": (c_i, [c_i]),

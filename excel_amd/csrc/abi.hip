@@ -626,3 +626,13 @@ extern "C" int excel_flip_max_normalize(const float* attr, float* out, int B, in
     EXCEL_CHECK_ARG(attr && out, "flip_max_normalize: null argument");
     return excel_launch_flip_max_normalize(attr, out, B, g, F, ST(stream));
 }
+
+extern "C" int excel_lam_scale_accumulate(const float* maps, float* acc, int B, int g, int F, int H, int W, int init, void* stream) {
+    EXCEL_CHECK_ARG(maps && acc && B > 0 && g > 0, "lam_scale_accumulate: bad argument");
+    return excel_launch_lam_scale_accumulate(maps, acc, B, g, F, H, W, init, ST(stream));
+}
+
+extern "C" int excel_plane_minmax_normalize(float* lam, long long planes, long long HW, void* stream) {
+    EXCEL_CHECK_ARG(lam && planes > 0 && HW > 0, "plane_minmax_normalize: bad argument");
+    return excel_launch_plane_minmax_normalize(lam, planes, HW, ST(stream));
+}

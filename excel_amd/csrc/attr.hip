@@ -110,6 +110,59 @@ __global__ __launch_bounds__(256) void flip_max_normalize_kernel(const float* __
     for (int p = threadIdx.x; p < P; p += 256) out[((long long)b * P + p) * F + f] = (val(p) - mn) / den;
 }
 
+// multi-scale / flip fuse of cure-style LAMs (utils/camutils.py:41-61 in its evident intent):
+//   maps [2B,P,F] of one scale (second half from flipped inputs) -> bilinear (align_corners=False) to (H,W) ->
+//   max(lam, flip_x(lam_flipped)) -> acc[B,F,H,W] (+)= ...        (one thread per output pixel, all in one pass)
+__global__ __launch_bounds__(256) void lam_scale_accumulate_kernel(const float* __restrict__ maps, float* __restrict__ acc, int B, int g,
+                                                                   int F, int H, int W, int init) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)B * F * H * W;
+    if (i >= total) return;
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const int f = (int)((i / ((long long)W * H)) % F), b = (int)(i / ((long long)W * H * F));
+    auto sample = [&](int bb, int xx) {   // F.interpolate(bilinear, align_corners=False) of map [g,g] at (y, xx)
+        const float fy = fmaxf(((float)g / (float)H) * ((float)y + 0.5f) - 0.5f, 0.f);
+        const float fx = fmaxf(((float)g / (float)W) * ((float)xx + 0.5f) - 0.5f, 0.f);
+        const int y0 = min((int)fy, g - 1), x0 = min((int)fx, g - 1);
+        const int y1 = min(y0 + 1, g - 1), x1 = min(x0 + 1, g - 1);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float* m = maps + (long long)bb * g * g * F + f;
+        const float top = (1.f - lx) * m[(long long)(y0 * g + x0) * F] + lx * m[(long long)(y0 * g + x1) * F];
+        const float bot = (1.f - lx) * m[(long long)(y1 * g + x0) * F] + lx * m[(long long)(y1 * g + x1) * F];
+        return (1.f - ly) * top + ly * bot;
+    };
+    const float v = fmaxf(sample(b, x), sample(b + B, W - 1 - x));     // torch.max(lam[:b], lam[b:].flip(-1))
+    acc[i] = init ? v : acc[i] + v;
+}
+
+// lam = lam - min_hw ; lam /= max_hw + 1e-5 per (b, f) plane (camutils.py:58-59), in place
+__global__ __launch_bounds__(256) void plane_minmax_normalize_kernel(float* __restrict__ lam, long long HW) {
+    __shared__ float smn[4], smx[4];
+    float* pl = lam + (long long)blockIdx.x * HW;
+    float mn = INFINITY, mx = -INFINITY;
+    for (long long p = threadIdx.x; p < HW; p += 256) { const float v = pl[p]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+    mn = wave_min(mn); mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+    mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+    const float den = (mx - mn) + 1e-5f;
+    for (long long p = threadIdx.x; p < HW; p += 256) pl[p] = (pl[p] - mn) / den;
+}
+
+int excel_launch_lam_scale_accumulate(const float* maps, float* acc, int B, int g, int F, int H, int W, int init, hipStream_t st) {
+    const long long total = (long long)B * F * H * W;
+    hipLaunchKernelGGL(lam_scale_accumulate_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, maps, acc, B, g, F, H, W, init);
+    EXCEL_CHECK_LAUNCH("lam_scale_accumulate");
+    return EXCEL_OK;
+}
+
+int excel_launch_plane_minmax_normalize(float* lam, long long planes, long long HW, hipStream_t st) {
+    hipLaunchKernelGGL(plane_minmax_normalize_kernel, dim3((unsigned)planes), dim3(256), 0, st, lam, HW);
+    EXCEL_CHECK_LAUNCH("plane_minmax_normalize");
+    return EXCEL_OK;
+}
+
 int excel_launch_attr_aggregate(const float* text, const float* bank, int F, int T, int C, int K, int drop, float* out,
                                 hipStream_t st) {
     EXCEL_CHECK_ARG(K >= 1 && K <= AA_KMAX && drop >= 0 && drop < K && F <= T, "attr_aggregate: need K <= %d, 0 <= drop < K", AA_KMAX);

@@ -83,3 +83,5 @@ int excel_launch_attr_aggregate(const float* text, const float* bank, int F, int
 int excel_launch_bilinear_resize(const float* in, float* out, long long planes, int h, int w, int H, int W, int align_corners,
                                  hipStream_t st);
 int excel_launch_flip_max_normalize(const float* attr, float* out, int B, int g, int F, hipStream_t st);
+int excel_launch_lam_scale_accumulate(const float* maps, float* acc, int B, int g, int F, int H, int W, int init, hipStream_t st);
+int excel_launch_plane_minmax_normalize(float* lam, long long planes, long long HW, hipStream_t st);

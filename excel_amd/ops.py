@@ -348,6 +348,25 @@ def flip_max_normalize(attr, g):
     return out
 
 
+def lam_scale_accumulate(maps, acc, g, H, W, init):
+    """maps [2B,P,F] of one scale -> resize to (H,W), flip-max, (+)= into acc [B,F,H,W]."""
+    maps = f32c(maps)
+    B2, P, F_ = maps.shape
+    if acc is None:
+        acc = torch.empty((B2 // 2, F_, H, W), dtype=torch.float32, device=maps.device)
+        init = True
+    check(lib().excel_lam_scale_accumulate(_p(maps), _p(acc), B2 // 2, g, F_, H, W, 1 if init else 0, _stream()),
+          "excel_lam_scale_accumulate")
+    return acc
+
+
+def plane_minmax_normalize_(lam):
+    """in place: lam -= min_hw ; lam /= max_hw + 1e-5 for every [..., H, W] plane."""
+    H, W = lam.shape[-2:]
+    check(lib().excel_plane_minmax_normalize(_p(lam), lam.numel() // (H * W), H * W, _stream()), "excel_plane_minmax_normalize")
+    return lam
+
+
 # ------------------------------------------------------------------ live kernel timing (HIP events on the launch stream)
 def prof_enable(on=True, categories=None, every=1):
     """categories: iterable of category names to bracket (None = all); every: bracket every n-th launch of a category

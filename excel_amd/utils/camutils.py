@@ -25,3 +25,19 @@ def cure_attr_map_flip(model, inputs, ex_fts=False, flip=True, raw_fts=None):
     inputs_cat = torch.cat([inputs, inputs.flip(-1)], dim=0)          # :15 (memory plumbing)
     attr = model(inputs_cat)[2]                                        # :20
     return ops.flip_max_normalize(attr, h // 16)                       # :21-26
+
+
+@torch.no_grad()
+def multi_scale_lam(model, inputs, scales=(1.0, 0.5, 0.75, 1.5)):
+    """Multi-scale + flip fused LAMs [B,F,h,w] (utils/camutils.py:32-63 `multi_scale_lam2`, written as the evident intent:
+    the reference interpolates the 3-D [2b,P,F] tensor directly, which cannot run - SURVEY 8 a16).  Scales follow
+    scripts/train_voc.py:53.  Scaled inputs are rounded to a multiple of the patch size (the ViT needs whole patches)."""
+    b, c, h, w = inputs.shape
+    acc = None
+    for s in scales:
+        hs, ws = int(s * h) // 16 * 16, int(s * w) // 16 * 16
+        x = inputs if (hs, ws) == (h, w) else ops.bilinear_resize(inputs, hs, ws, align_corners=False)     # :50
+        x2 = torch.cat([x, x.flip(-1)], dim=0)                                                              # :51
+        maps = model(x2)[2]                                                                                  # :53-54
+        acc = ops.lam_scale_accumulate(maps, acc, hs // 16, h, w, init=acc is None)                         # :56-59 resize, flip-max, sum
+    return ops.plane_minmax_normalize_(acc)                                                                  # :61-63

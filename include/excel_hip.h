@@ -178,6 +178,13 @@ int excel_pos_embed_resize(const float* pos, int side, int g, int D, float* out,
 /* flip-TTA fuse of cure_attr_map_flip (utils/camutils.py:21-26): attr [2B,P,F] -> out [B,P,F]. */
 int excel_flip_max_normalize(const float* attr, float* out, int B, int g, int F, void* stream);
 
+/* multi-scale LAM fuse (utils/camutils.py:41-61, multi_scale_lam2 in its evident intent): for one scale, maps [2B,P,F]
+ * (second half from horizontally flipped inputs) are bilinearly resized (align_corners=False) to (H,W), flip-maxed and
+ * accumulated into acc [B,F,H,W] (init=1: overwrite).  excel_plane_minmax_normalize then applies
+ * lam -= min_hw; lam /= max_hw + 1e-5 per (b,f) plane. */
+int excel_lam_scale_accumulate(const float* maps, float* acc, int B, int g, int F, int H, int W, int init, void* stream);
+int excel_plane_minmax_normalize(float* lam, long long planes, long long HW, void* stream);
+
 /* ------------------------------------------------------------------ live per-kernel timing (bench.py) */
 
 /* When enabled, every kernel launch is bracketed by hipEvents on its launch stream, grouped by category.

@@ -242,3 +242,101 @@ def test_infer_lam_harness_single_rank(gpu):
     args2 = infer_lam.get_parser().parse_args(["--synthetic", "6", "--api_path", "true", "--resize_size", "448"])
     score2, total2 = infer_lam.validate(args2)
     assert np.abs(host(total) - host(total2)).sum() <= 1e-4 * host(total).sum()      # batched == per-image API path
+
+
+# ------------------------------------------------------------------ COCO-shaped config (BASELINE configs[4] shapes) and flip / multi-scale LAMs
+SMALL512 = VitConfig(width=128, layers=7, heads=2, patch=16, out_dim=64, input_resolution=224, n_surgery=5)
+SMALL512_KW = dict(width=128, layers=7, heads=2, patch=16, output_dim=64, input_resolution=224)
+
+
+@pytest.mark.parametrize("gemm_mode", ["f32", "bf16x3"])
+def test_coco_shaped_512_pipeline_vs_oracle(gpu, gemm_mode):
+    """512x512 (N = 1025: exercises the K/N paddings 1028/1056), T = 103 text rows, F = 80 classes, up to 5 present
+    classes per image (PAR with 6 channels), COCO-style caa threshold; small-width ViT so the oracle stays fast.
+
+    scoremap2bbox thresholds a uint8-truncated map (affutils.py:96-101), so the path is discontinuous in its input:
+    a 1e-5 difference in a CAM can move a box.  In exact-fp32 mode the whole path is compared end to end; in bf16x3 mode
+    (CAM error ~1e-5, inside the 1e-3 gate) the CAM stage is gated on its own and the discontinuous stages are compared
+    stage-wise: the oracle continues from the GPU's own CAMs and mean attention and must then agree tightly."""
+    from excel_amd.model import ExCEL_model
+    from excel_amd.pipeline import TrainingFreePipeline
+    rs = np.random.RandomState(5)
+    w = make_vit_weights(SMALL512, seed=3)
+    text = rs.standard_normal((103, 64)).astype(np.float32)
+    text /= np.linalg.norm(text, axis=1, keepdims=True)
+    model = ExCEL_model(clip_model="small", num_classes=81, img_size=512, mode="train", state_dict=w, vit_cfg=SMALL512_KW,
+                        text_attr=text.T.copy(), gemm_mode=gemm_mode)
+    wo = oracle.vit.reload_self_attn(w, SMALL512, 32, "train")
+    B, S, F = 2, 512, 80
+    imgs = rs.standard_normal((B, 3, S, S)).astype(np.float32)
+    gts = rs.randint(0, 81, (B, S, S)).astype(np.uint8)
+    cls = np.zeros((B, F), np.float32)
+    cls[0, [3, 17, 40, 41, 79]] = 1
+    cls[1, [0, 62]] = 1
+    pipe = TrainingFreePipeline(model, num_classes=81, smax=5, caa_thre=0.88)      # train_coco.py:193
+    w_aff0 = host(model(dev(imgs))[3].w_aff)                                       # before the in-place Sinkhorn
+    labels, inter = pipe.run_batch(dev(imgs), dev(cls), dev(gts), return_intermediates=True)
+    par = oracle.par.PAR([1, 2, 4, 8, 12, 24], 20)
+    ref_hist = np.zeros((81, 81), np.int64)
+    for b in range(B):
+        k = int(cls[b].sum())
+        r = oracle.pipeline.run_sample(imgs[b], cls[b], (S, S), wo, SMALL512, text.T.copy(), F, par, S, caa_thre=0.88, return_all=True)
+        assert maxabs(host(inter["attr"])[b], r["attr_maps_raw"][0]) < 1e-3
+        # softmax probabilities: a bf16x3 logit error of ~1e-5 * |logit| is a relative probability error of the same size
+        assert maxabs(w_aff0[b], r["attn_weights"][-6:, 0, 1:, 1:].mean(0)) < (1e-5 if gemm_mode == "f32" else 2e-4)
+        if gemm_mode == "bf16x3":                      # continue the oracle from the GPU's CAM-stage outputs
+            attn = np.zeros((1, 1025, 1025), np.float32)
+            attn[0, 1:, 1:] = w_aff0[b]
+            refined, cls_lst = oracle.aff.refine_cams_with_aff(host(inter["attr"])[b], attn, cls[b], size=(S, S), caa_thre=0.88, attn_layers=1)
+            label, cams = oracle.aff.refine_cams_with_bkg_weclip(refined, imgs[b], cls_lst, par, (S, S))
+            r = dict(refined=refined, cams=cams, label=label[0])
+        assert maxabs(host(inter["refined"])[b, :k].reshape(k, 32, 32), np.asarray(r["refined"])) < 1e-5
+        assert maxabs(host(inter["cams"])[b, :k + 1], r["cams"]) < 1e-3
+        assert float(np.mean(host(labels)[b] == r["label"])) >= 0.999
+        ref_hist += oracle.evaluate.fast_hist(gts[b].flatten(), host(labels)[b].flatten(), 81)
+    assert np.array_equal(host(pipe.hist), ref_hist)
+
+
+def _oracle_maps(imgs, w, cfg, text_attr, F):
+    return oracle.cam.attr_maps_raw(imgs, w, cfg, text_attr, F)[0]
+
+
+def test_cure_attr_map_flip_vs_oracle(gpu):
+    from excel_amd.utils.camutils import cure_attr_map_flip
+    rs = np.random.RandomState(8)
+    text = rs.standard_normal((9, 64)).astype(np.float32)
+    text /= np.linalg.norm(text, axis=1, keepdims=True)
+    model, w = tiny_model(text.T.copy(), gemm_mode="f32")
+    wo = oracle.vit.reload_self_attn(w, TINY, 6, "train")
+    x = rs.standard_normal((2, 3, 96, 96)).astype(np.float32)
+    got = host(cure_attr_map_flip(model, dev(x), ex_fts=False, flip=True))
+    m = _oracle_maps(np.concatenate([x, x[..., ::-1]], 0), wo, TINY, text.T.copy(), 4)          # camutils.py:15,20
+    lam = m.transpose(0, 2, 1).reshape(4, 4, 6, 6)
+    lam = np.maximum(lam[:2], lam[2:][..., ::-1])                                                 # :22
+    lam = lam - lam.min(axis=(2, 3), keepdims=True)                                               # :24
+    lam = lam / (lam.max(axis=(2, 3), keepdims=True) + 1e-5)                                      # :25
+    ref = lam.reshape(2, 4, 36).transpose(0, 2, 1)
+    assert got.shape == ref.shape and maxabs(got, ref) < 2e-4
+
+
+def test_multi_scale_lam_vs_oracle(gpu):
+    from excel_amd.utils.camutils import multi_scale_lam
+    rs = np.random.RandomState(9)
+    text = rs.standard_normal((9, 64)).astype(np.float32)
+    text /= np.linalg.norm(text, axis=1, keepdims=True)
+    model, w = tiny_model(text.T.copy(), gemm_mode="f32", img_size=64)
+    wo = oracle.vit.reload_self_attn(w, TINY, 4, "train")
+    x = rs.standard_normal((2, 3, 64, 64)).astype(np.float32)
+    scales = (1.0, 0.5, 0.75, 1.5)
+    got = host(multi_scale_lam(model, dev(x), scales))
+    acc = 0
+    for s in scales:
+        hs = int(s * 64) // 16 * 16
+        xs = x if hs == 64 else oracle.interp.bilinear_resize(x, hs, hs, align_corners=False)
+        m = _oracle_maps(np.concatenate([xs, xs[..., ::-1]], 0), wo, TINY, text.T.copy(), 4)
+        g = hs // 16
+        lam = oracle.interp.bilinear_resize(m.transpose(0, 2, 1).reshape(4, 4, g, g), 64, 64, align_corners=False)
+        acc = acc + np.maximum(lam[:2], lam[2:][..., ::-1])
+    acc = acc - acc.min(axis=(2, 3), keepdims=True)
+    ref = acc / (acc.max(axis=(2, 3), keepdims=True) + 1e-5)
+    assert got.shape == (2, 4, 64, 64) and maxabs(got, ref) < 5e-4
