@@ -175,13 +175,14 @@ def main():
             gemm_launches = max(prof[cat]["launches"], 1)
             gemm_flops = prof[cat]["work"]                          # sum of 2*M*N*K over the launches (algorithmic)
             achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-            traffic = None
+            traffic = par_traffic = None
             tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
             if os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get(cat + "_bytes_per_launch")
+                    tj = json.load(open(tpath))
+                    traffic, par_traffic = tj.get(cat + "_bytes_per_launch"), tj.get("par_iterate_bytes_per_launch")
                 except Exception:
-                    traffic = None
+                    traffic = par_traffic = None
             if mode == "bf16x3":
                 peak = BF16_MFMA_PEAK_TF
                 kname = ("gemm_bf16x3_kernel (fp32 operands as bf16 hi+lo planes, 3 x v_mfma_f32_32x32x16_bf16 per product; "
@@ -208,7 +209,8 @@ def main():
                 per_launch = float(np.mean([sum((48 + 2 * (int(k) + 1)) * S * S * 4 for k in kk) for kk in ks]))
                 gbs = per_launch * par_it["launches"] / (par_it["ms"] * 1e-3) / 1e9
                 out["roofline_par_iterate"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                               "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                               "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": par_traffic,
+                                               "algorithmic_bytes_per_launch": int(per_launch),
                                                "avg_launch_ms": round(par_it["ms"] / max(par_it["launches"], 1), 5)}
             vit_ms = sum(prof_all[k]["ms"] for k in ("gemm_nt", "gemm_nn", "gemm_bf16x3", "attn_rowpass", "attn_accum", "layernorm", "embed",
                                                   "token_norm", "cam_epilogue"))
