@@ -348,6 +348,11 @@ extern "C" int excel_vit_forward(excel_vit_t h, const float* img, int B, int S, 
             }
             hipLaunchKernelGGL(pos_resize_kernel, dim3((unsigned)cdivl((long long)N * D, 256)), dim3(256), 0, st, h->w.pos_emb, buf, c.pos_grid, g, D);
             EXCEL_CHECK_LAUNCH("pos_resize");
+            // one-time per grid size: the cached table may be read from OTHER streams by later calls
+            if (hipStreamSynchronize(st) != hipSuccess) {
+                excel_set_error("excel_vit_forward: pos_resize failed");
+                return EXCEL_ERR_LAUNCH;
+            }
             it = h->pos_cache.emplace(g, buf).first;
         }
         pos = it->second;

@@ -226,28 +226,55 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16x3_kernel(GemmBfArgs
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             const int ch = ((s2 * 2 + kh) ^ sw) * 8, cl = ((4 + s2 * 2 + kh) ^ sw) * 8;
-            bf16x8 ah[TI], al[TI], bh[2], bl[2];
-#pragma unroll
-            for (int i = 0; i < TI; ++i) {
-                const u16* rowp = as + (wm * (TI * 32) + i * 32 + r) * TROW;
-                ah[i] = *reinterpret_cast<const bf16x8*>(rowp + ch);
-                al[i] = *reinterpret_cast<const bf16x8*>(rowp + cl);
-            }
+            bf16x8 bh[2], bl[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const u16* rowp = bs + (wn * 64 + j * 32 + r) * TROW;
                 bh[j] = *reinterpret_cast<const bf16x8*>(rowp + ch);
                 bl[j] = *reinterpret_cast<const bf16x8*>(rowp + cl);
             }
+            if (TI <= 4) {
+                bf16x8 ah[TI], al[TI];
 #pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    // small terms first, the dominant hi.hi product last
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < TI; ++i) {
+                    const u16* rowp = as + (wm * (TI * 32) + i * 32 + r) * TROW;
+                    ah[i] = *reinterpret_cast<const bf16x8*>(rowp + ch);
+                    al[i] = *reinterpret_cast<const bf16x8*>(rowp + cl);
                 }
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        // small terms first, the dominant hi.hi product last
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            } else {
+                // register-tight variant (TI*2*16 accumulator registers leave < 100 for everything else): A fragments
+                // are streamed one row tile ahead instead of all at once, and the scheduler may not hoist them
+                bf16x8 ah[2], al[2];
+                {
+                    const u16* rowp = as + (wm * (TI * 32) + r) * TROW;
+                    ah[0] = *reinterpret_cast<const bf16x8*>(rowp + ch);
+                    al[0] = *reinterpret_cast<const bf16x8*>(rowp + cl);
+                }
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    if (i + 1 < TI) {
+                        const u16* rowp = as + (wm * (TI * 32) + (i + 1) * 32 + r) * TROW;
+                        ah[(i + 1) & 1] = *reinterpret_cast<const bf16x8*>(rowp + ch);
+                        al[(i + 1) & 1] = *reinterpret_cast<const bf16x8*>(rowp + cl);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i & 1], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i & 1], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i & 1], bh[j], acc[i][j], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
     };
 
@@ -365,13 +392,35 @@ int excel_launch_gemm_bf16x3(const GemmBfArgs& p_in, hipStream_t stream) {
     EXCEL_CHECK_ARG(p.out_mode != GEMM_OUT_SPLIT_BF16 || (p.N % 32) == 0, "gemm_bf16x3: split output needs N %% 32 == 0");
     EXCEL_CHECK_ARG((p.lda % 8) == 0 && (p.ldb % 8) == 0 && p.lda >= 2 * p.K && p.ldb >= 2 * p.K, "gemm_bf16x3: bad lda/ldb");
     EXCEL_CHECK_ARG((((uintptr_t)p.A | (uintptr_t)p.B) & 15) == 0, "gemm_bf16x3: operands must be 16-byte aligned");
-    static const char* force = getenv("EXCEL_BF_TILE");      // dev knob: "128" | "256x128" | "256"
-    int kind;   // 0: 128x128, 1: 256x128, 2: 256x256
-    if (force) kind = !strcmp(force, "256") ? 2 : (!strcmp(force, "256x128") ? 1 : 0);
+    static const char* force = getenv("EXCEL_BF_TILE");      // dev knob: "128" | "256x128" | "256" | "320"
+    int kind;   // 0: 128x128, 1: 256x128, 2: 256x256, 3: 320x256
+    if (force) kind = !strcmp(force, "320") ? 3 : !strcmp(force, "256") ? 2 : (!strcmp(force, "256x128") ? 1 : 0);
     else if (p.M < 2048 || (p.batch > 1)) kind = 0;
-    else kind = (p.N >= 1536) ? 2 : 1;
+    else {
+        // The big tiles run one workgroup per CU, so a launch is ceil(tiles / 256) rounds and the last round is mostly
+        // idle unless the tile count lands just under a multiple of the CU count (25120 x 768: 594 tiles of 256x128 =
+        // 2.3 rounds -> 77 % busy; 237 tiles of 320x256 = 0.93 rounds -> 93 %).  Pick the tile with the best
+        // busy fraction x intrinsic efficiency (bytes staged per flop: measured 1.0 / 0.97 / 0.88 / 0.80).
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0; hipDeviceProp_t prop;
+            n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+        }
+        const int bm[4] = {128, 256, 256, 320}, bn[4] = {128, 128, 256, 256}, wg_per_cu[4] = {2, 1, 1, 1};
+        const double intrinsic[4] = {0.80, 0.88, 0.97, 1.0};
+        double best = -1.0;
+        kind = 3;
+        for (int k = 0; k < 4; ++k) {
+            const long long tiles = (long long)cdiv(p.M, bm[k]) * cdiv(p.N, bn[k]), slots = (long long)n_cu * wg_per_cu[k];
+            const long long rounds = (tiles + slots - 1) / slots;
+            const double busy = ((double)p.M * p.N) / ((double)rounds * slots * bm[k] * bn[k]);
+            if (busy * intrinsic[k] > best) { best = busy * intrinsic[k]; kind = k; }
+        }
+    }
     const int nb = p.batch > 1 ? p.batch : 1;
-    if (kind == 2) {
+    if (kind == 3) {
+        hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 4, 5, 2>), dim3(cdiv(p.M, 320) * cdiv(p.N, 256), nb), dim3(512), 0, stream, p);
+    } else if (kind == 2) {
         hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 4, 4, 2>), dim3(cdiv(p.M, 256) * cdiv(p.N, 256), nb), dim3(512), 0, stream, p);
     } else if (kind == 1) {
         hipLaunchKernelGGL((gemm_bf16x3_kernel<4, 2, 2, 3>), dim3(cdiv(p.M, 256) * cdiv(p.N, 128), nb), dim3(512), 0, stream, p);

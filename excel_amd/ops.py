@@ -135,7 +135,7 @@ class VitHandle:
             if mode == "bf16x3" and (width % 32 or (3 * patch * patch) % 32):
                 mode = "f32"
             self.set_gemm_mode(mode)
-        self._ws = None
+        self._ws = {}          # one workspace per launch stream: the same weights can serve concurrent streams
 
     def __del__(self):
         try:
@@ -156,10 +156,13 @@ class VitHandle:
         need = lib().excel_vit_workspace_bytes(self._h, B, S)
         if need == 0:
             raise ValueError(f"bad ViT input shape B={B} S={S}")
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = None
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._ws, need
+        key = torch.cuda.current_stream().cuda_stream
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            self._ws.pop(key, None)
+            ws = None
+            ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return ws, need
 
     def forward(self, imgs, want_w_aff=True, aff_layers=6, n_attn_out=0, want_feats=False, want_raw=False):
         """-> dict(image_features [B,N,C], w_aff [B,P,P]|None, attn [n,B,N,N]|None, feats [L,B,N,D]|None, x_raw|None)"""
