@@ -652,7 +652,12 @@ __global__ __launch_bounds__(512, 2) void attn_accum_bf_kernel(AccumArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, kh = lane >> 5;
     const int wq = wave >> 1, wk = wave & 1;
-    const int kt = blockIdx.x, qt = blockIdx.y, b = blockIdx.z;
+    int kt = blockIdx.x, qt = blockIdx.y, b = blockIdx.z;
+    if (p.dbg & 8) {      // experiment: XCD-contiguous tile order (workgroups sharing X / Y tiles on one L2)
+        const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int id = xcd_remap(lin, gridDim.x * gridDim.y * gridDim.z);
+        kt = id % gridDim.x; qt = (id / gridDim.x) % gridDim.y; b = id / (gridDim.x * gridDim.y);
+    }
     const int N = p.N;
 
     // staging: the tile image is lane-linear (one wave-instruction = 1 KB = 4 rows x 16 chunks), so the swizzle

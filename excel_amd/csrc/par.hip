@@ -56,21 +56,26 @@ __global__ __launch_bounds__(256) void par_affinity_kernel(const float* __restri
 #pragma unroll
         for (int t = 0; t < NT; ++t) { const float dv = nb[t] - mean; var += dv * dv; }
         const float den = sqrtf(var / (float)(NT - 1)) + 1e-8f;     // unbiased std (torch.std default)
+        // (|nb - ctr| / den / w1)^2 as one fma per tap: 3 true divisions per pixel instead of 2 x 144 (the divisions
+        // were ~80 % of this kernel's instructions); differs from the literal form by one rounding (~1e-7 relative)
+        const float k = 1.f / (den * w1);
+        const float k2 = k * k;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const float a = fabsf(nb[t] - ctr) / den / w1;
-            acc[t] -= a * a;
+            const float dv = nb[t] - ctr;
+            acc[t] = fmaf(-(dv * dv), k2, acc[t]);
         }
     }
     float m = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) { acc[t] = acc[t] / 3.f; m = fmaxf(m, acc[t]); }
+    for (int t = 0; t < NT; ++t) { acc[t] = acc[t] * (1.f / 3.f); m = fmaxf(m, acc[t]); }
     float s = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) { acc[t] = __expf(acc[t] - m); s += acc[t]; }
+    const float inv_s = 1.f / s;
     float* out = aff + (long long)b * NT * HW + (long long)y * W + x;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) out[(long long)t * HW] = acc[t] / s + dl.pos_sm[t];
+    for (int t = 0; t < NT; ++t) out[(long long)t * HW] = fmaf(acc[t], inv_s, dl.pos_sm[t]);
 }
 
 #define PAR_CCH 8
