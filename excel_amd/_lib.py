@@ -48,6 +48,11 @@ SIGNATURES = {
     "excel_vit_set_gemm_mode": (c_i, [C.c_void_p, c_i]),
     "excel_vit_get_gemm_mode": (c_i, [C.c_void_p]),
     "excel_vit_forward": (c_i, [C.c_void_p, c_f, c_i, c_i, c_f, c_sz, c_f, c_f, c_f, c_i, c_f, c_i, c_f, c_f]),
+    "excel_vit_forward_ex": (c_i, [C.c_void_p, c_f, c_i, c_i, c_f, c_sz, c_f, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f]),
+    "excel_feature_affinity_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
+    "excel_feature_affinity": (c_i, [c_f, c_i, c_i, c_i, C.c_float, C.c_float, c_i, c_f, c_f, c_f]),
+    "excel_attn_select_workspace_bytes": (c_sz, [c_i, c_i]),
+    "excel_attn_select_mean": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f]),
     "excel_cam_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "excel_clip_feature_surgery": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, C.c_float, c_f, c_f, c_f, c_f]),
     "excel_attn_layer_mean": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),

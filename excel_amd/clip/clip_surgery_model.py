@@ -60,7 +60,8 @@ class VisionTransformer:
     def forward(self, x, return_weights=False, ex_feats=None, **kw):
         """:419-448 -> (x [B,N,C] token features, attn_weights, all_feats).  See clip.generate_clip_fts."""
         if ex_feats is not None:
-            raise NotImplementedError("the LVC ex_feats branch (clip_surgery_model.py:127-141) is SURVEY 8(f) 'next'")
+            # Attention.forward :127-137: the cue is the same for every head and every surgery block -> built once
+            kw["ex_attn"] = ops.feature_affinity(ex_feats, "mask_softmax", beta=1.0, gamma=3.0)
         return self.handle().forward(x, **kw)
 
     __call__ = forward

@@ -320,9 +320,41 @@ extern "C" size_t excel_vit_workspace_bytes(excel_vit_t h, int B, int S) {
     return vit_ws_layout(h->cfg, B, S, nullptr).total;
 }
 
+static int vit_forward_impl(excel_vit_t h, const float* img, int B, int S, void* workspace, size_t workspace_bytes,
+                            float* image_features, float* x_raw, float* w_aff, int aff_layers, float* attn_out,
+                            int n_attn_out, float* feats_out, const float* ex_attn, void* stream);
+
 extern "C" int excel_vit_forward(excel_vit_t h, const float* img, int B, int S, void* workspace, size_t workspace_bytes,
                                  float* image_features, float* x_raw, float* w_aff, int aff_layers, float* attn_out,
                                  int n_attn_out, float* feats_out, void* stream) {
+    return vit_forward_impl(h, img, B, S, workspace, workspace_bytes, image_features, x_raw, w_aff, aff_layers, attn_out, n_attn_out,
+                            feats_out, nullptr, stream);
+}
+
+extern "C" int excel_vit_forward_ex(excel_vit_t h, const float* img, int B, int S, void* workspace, size_t workspace_bytes,
+                                    float* image_features, float* x_raw, float* w_aff, int aff_layers, float* attn_out,
+                                    int n_attn_out, float* feats_out, const float* ex_attn, void* stream) {
+    return vit_forward_impl(h, img, B, S, workspace, workspace_bytes, image_features, x_raw, w_aff, aff_layers, attn_out, n_attn_out,
+                            feats_out, ex_attn, stream);
+}
+
+extern "C" size_t excel_feature_affinity_workspace_bytes(int B, int C, int P) { return excel_feature_affinity_ws_bytes(B, C, P); }
+
+extern "C" int excel_feature_affinity(const float* feats, int B, int C, int P, float beta, float gamma, int mode, float* out,
+                                      void* workspace, void* stream) {
+    return excel_launch_feature_affinity(feats, B, C, P, beta, gamma, mode, out, workspace, ST(stream));
+}
+
+extern "C" size_t excel_attn_select_workspace_bytes(int B, int n_layers) { return excel_attn_select_ws_bytes(B, n_layers); }
+
+extern "C" int excel_attn_select_mean(const float* attn, int Lw, int B, int N, int first_layer, int n_layers, const float* seg_attn,
+                                      float* w_out, void* workspace, void* stream) {
+    return excel_launch_attn_select_mean(attn, Lw, B, N, first_layer, n_layers, seg_attn, w_out, workspace, ST(stream));
+}
+
+static int vit_forward_impl(excel_vit_t h, const float* img, int B, int S, void* workspace, size_t workspace_bytes,
+                            float* image_features, float* x_raw, float* w_aff, int aff_layers, float* attn_out,
+                            int n_attn_out, float* feats_out, const float* ex_attn, void* stream) {
     EXCEL_CHECK_ARG(h && img && workspace && image_features, "excel_vit_forward: null argument");
     const excel_vit_config& c = h->cfg;
     EXCEL_CHECK_ARG(B > 0 && S > 0 && S % c.patch == 0, "excel_vit_forward: S must be a positive multiple of the patch size");
@@ -415,7 +447,7 @@ extern "C" int excel_vit_forward(excel_vit_t h, const float* img, int B, int S, 
         if (surgery || in_aff || attn_l) {
             TRY(excel_launch_attn_accum(ws.qkvh, ws.stats, surgery ? ws.a_sum : nullptr, in_aff ? w_aff : nullptr, attn_l, B, H, N,
                                         bf ? ws.KP : ws.NP, 64, scale, surgery ? 1 : 0, surgery ? 1.f : 1.f / (float)H,
-                                        1.f / (float)aff_layers, (l == L - aff_layers) ? 1 : 0, st, qkvs, bf ? 1 : 0));
+                                        1.f / (float)aff_layers, (l == L - aff_layers) ? 1 : 0, st, qkvs, bf ? 1 : 0, ex_attn));
         }
         if (!surgery) {
             TRY(linear(ws.ao, bw.out_proj_w, sw.out_proj, bw.out_proj_b, ws.x, ws.x, D, D, GEMM_ACT_NONE, GEMM_OUT_PLAIN));   // x += out_proj(attn)

@@ -465,6 +465,8 @@ struct AccumArgs {
     const unsigned short* qkvs;   // split-bf16 q|k|v for bf16x3 scores (null = exact fp32)
     int dbg;              // dev: bit0 skip scoring, bit1 skip tile loads, bit2 skip the output epilogue
     int a_sum_split;      // 1: a_sum is written in split-bf16 format [B,N][2*NP] (NP % 32 == 0): A operand of the bf16x3 A_sum.V GEMM
+    const float* ex_attn; // [B,P,P] LVC cue added to every head's attn[1:,1:] of a surgery block (may be null)
+    float ex_scale;       // = H (the head sum of a per-head constant)
 };
 
 template <bool SURGERY, bool BF>
@@ -601,7 +603,9 @@ __global__ __launch_bounds__(256, 1) void attn_accum_kernel(AccumArgs p) {
             if (qg >= N) continue;
             if (which == 0) {
                 if (kg < p.NP) {
-                    const float av = v * (1.f / 3.f);
+                    float av = v * (1.f / 3.f);
+                    // LVC branch (clip_surgery_model.py:140-141): every head's attn[1:,1:] += ex_attn -> head-sum gains H x ex_attn
+                    if (p.ex_attn && qg >= 1 && kg >= 1 && kg < N) av += p.ex_scale * p.ex_attn[((long long)b * (N - 1) + (qg - 1)) * (N - 1) + (kg - 1)];
                     if (p.a_sum_split) {
                         __bf16* o = reinterpret_cast<__bf16*>(p.a_sum) + ((long long)b * N + qg) * 2 * p.NP + split_off(kg, 0);
                         const __bf16 hi = (__bf16)av;
@@ -815,7 +819,9 @@ __global__ __launch_bounds__(512, 2) void attn_accum_bf_kernel(AccumArgs p) {
             if (qg >= N) continue;
             if (which == 0) {
                 if (kg < p.NP) {
-                    const float av = v * (1.f / 3.f);
+                    float av = v * (1.f / 3.f);
+                    // LVC branch (clip_surgery_model.py:140-141): every head's attn[1:,1:] += ex_attn -> head-sum gains H x ex_attn
+                    if (p.ex_attn && qg >= 1 && kg >= 1 && kg < N) av += p.ex_scale * p.ex_attn[((long long)b * (N - 1) + (qg - 1)) * (N - 1) + (kg - 1)];
                     if (p.a_sum_split) {
                         __bf16* o = reinterpret_cast<__bf16*>(p.a_sum) + ((long long)b * N + qg) * 2 * p.NP + split_off(kg, 0);
                         const __bf16 hi = (__bf16)av;
@@ -855,11 +861,11 @@ int excel_launch_attn_rowpass(const float* qkvh, float* out, float* stats, int B
 
 int excel_launch_attn_accum(const float* qkvh, const float* stats, float* a_sum, float* w_aff, float* attn_out, int B, int H,
                             int N, int NP, int hd, float scale, int surgery, float w_scale, float aff_scale, int aff_init,
-                            hipStream_t st, const unsigned short* qkvs, int a_sum_split) {
+                            hipStream_t st, const unsigned short* qkvs, int a_sum_split, const float* ex_attn) {
     ProfScope prof__(PROF_ATTN_ACCUM, st);
     EXCEL_CHECK_ARG(hd == HD, "attention: head_dim must be 64 (got %d)", hd);
     EXCEL_CHECK_ARG(!surgery || (a_sum && NP >= N && NP <= cdiv(N, 64) * 64), "attn_accum: bad a_sum/NP");
-    AccumArgs a{qkvh, reinterpret_cast<const float2*>(stats), a_sum, w_aff, attn_out, B, H, N, NP, scale, w_scale, aff_scale, aff_init, qkvs, 0, a_sum_split};
+    AccumArgs a{qkvh, reinterpret_cast<const float2*>(stats), a_sum, w_aff, attn_out, B, H, N, NP, scale, w_scale, aff_scale, aff_init, qkvs, 0, a_sum_split, surgery ? ex_attn : nullptr, (float)H};
     dim3 grid(cdiv(N, 64), cdiv(N, 64), B);
     static const char* old = getenv("EXCEL_ACCUM_OLD");
     { static const char* d = getenv("EXCEL_ACCUM_DBG"); if (d) a.dbg = atoi(d); }

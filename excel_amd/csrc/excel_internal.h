@@ -59,7 +59,7 @@ int excel_launch_attn_rowpass(const float* qkvh, float* out, float* stats, int B
                               const unsigned short* vt = nullptr, int KP = 0);
 int excel_launch_attn_accum(const float* qkvh, const float* stats, float* a_sum, float* w_aff, float* attn_out, int B, int H,
                             int N, int NP, int hd, float scale, int surgery, float w_scale, float aff_scale, int aff_init,
-                            hipStream_t st, const unsigned short* qkvs = nullptr, int a_sum_split = 0);
+                            hipStream_t st, const unsigned short* qkvs = nullptr, int a_sum_split = 0, const float* ex_attn = nullptr);
 int excel_launch_cam_epilogue(float* S, float* out_full, float* out_slice, int B, int N, int T, int ldS, int F, float temp,
                               hipStream_t st);
 int excel_launch_trans_mat_sym(const float* W, float* T, float* Tsym, float* cs, int B, int P, hipStream_t st);
@@ -85,3 +85,10 @@ int excel_launch_bilinear_resize(const float* in, float* out, long long planes, 
 int excel_launch_flip_max_normalize(const float* attr, float* out, int B, int g, int F, hipStream_t st);
 int excel_launch_lam_scale_accumulate(const float* maps, float* acc, int B, int g, int F, int H, int W, int init, hipStream_t st);
 int excel_launch_plane_minmax_normalize(float* lam, long long planes, long long HW, hipStream_t st);
+// LVC side (lvc.hip)
+size_t excel_feature_affinity_ws_bytes(int B, int C, int P);
+int excel_launch_feature_affinity(const float* feats, int B, int C, int P, float beta, float gamma, int mode, float* out, void* ws,
+                                  hipStream_t st);
+size_t excel_attn_select_ws_bytes(int B, int n_layers);
+int excel_launch_attn_select_mean(const float* attn, int Lw, int B, int N, int first_layer, int n_layers, const float* seg_attn,
+                                  float* out, void* ws, hipStream_t st);

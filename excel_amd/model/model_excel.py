@@ -46,16 +46,33 @@ class ExCEL_model:
     def to(self, *a, **k):
         return self
 
+    # The learned decoder (decoder_fts_fuse + SegFormerHead, :60-68) is outside this library.  A caller that
+    # owns one plugs it in here: feature_head(all_feats [L,B,N,D]) -> attn_fts [B,C,g,g]; forward then also returns
+    # attn_fts and attn_pred like the reference.
+    feature_head = None
+
+    @staticmethod
+    def attn_pred_from(attn_fts):
+        """:70-76: sigmoid((f^T f - mean) * 3) of the channel-normalised decoder features -> [B,P,P]."""
+        return ops.feature_affinity(attn_fts, "sigmoid", beta=1.0, gamma=3.0)
+
     def forward(self, img, ex_feats=None, n_attn_out=0, want_feats=False):
-        """model(img) -> (seg, attn_fts, attr_maps_raw [B,P,F], attn_weights, attn_pred)      (:48-78)"""
+        """model(img) -> (seg, attn_fts, attr_maps_raw [B,P,F], attn_weights, attn_pred)      (:48-78)
+        model(img, ex_feats=[B,C,g,g]) -> attr_maps_raw of the LVC branch                       (:50-53)"""
         if ex_feats is not None:
-            raise NotImplementedError("ex_feats / LVC path (model_excel.py:50-53) is SURVEY 8(f) 'next'")
+            image_features, _, _ = clip.generate_clip_fts(img, self.encoder, return_weights=True, ex_feats=ex_feats)       # :51
+            return ops.clip_feature_surgery(image_features, self._text_rows, num_fg=self.num_classes - 1, want_full=False)[1]   # :52
+        want_feats = want_feats or self.feature_head is not None
         image_features, attn_weights, all_feats = clip.generate_clip_fts(img, self.encoder, return_weights=True,
                                                                          n_attn_out=n_attn_out, want_feats=want_feats)   # :57
         _, attr_maps_raw = ops.clip_feature_surgery(image_features, self._text_rows, num_fg=self.num_classes - 1,
                                                     want_full=False)                                                    # :58
         self.last_image_features = image_features
         self.last_all_feats = all_feats
-        return None, None, attr_maps_raw, attn_weights, None
+        attn_fts = attn_pred = None
+        if self.feature_head is not None:
+            attn_fts = self.feature_head(all_feats)                                                                     # :60-66
+            attn_pred = self.attn_pred_from(attn_fts)                                                                   # :70-76
+        return None, attn_fts, attr_maps_raw, attn_weights, attn_pred
 
     __call__ = forward

@@ -164,8 +164,9 @@ class VitHandle:
             ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
         return ws, need
 
-    def forward(self, imgs, want_w_aff=True, aff_layers=6, n_attn_out=0, want_feats=False, want_raw=False):
-        """-> dict(image_features [B,N,C], w_aff [B,P,P]|None, attn [n,B,N,N]|None, feats [L,B,N,D]|None, x_raw|None)"""
+    def forward(self, imgs, want_w_aff=True, aff_layers=6, n_attn_out=0, want_feats=False, want_raw=False, ex_attn=None):
+        """-> dict(image_features [B,N,C], w_aff [B,P,P]|None, attn [n,B,N,N]|None, feats [L,B,N,D]|None, x_raw|None)
+        ex_attn [B,P,P]: LVC cue added to every head of every surgery block (clip_surgery_model.py:127-141)."""
         imgs = f32c(imgs)
         B, _, S, S2 = imgs.shape
         assert S == S2
@@ -179,8 +180,12 @@ class VitHandle:
         attn = torch.empty((n_attn_out, B, N, N), dtype=torch.float32, device=dev) if n_attn_out else None
         feats = torch.empty((c["layers"], B, N, c["width"]), dtype=torch.float32, device=dev) if want_feats else None
         ws, need = self.workspace(B, S)
-        check(lib().excel_vit_forward(self._h, _p(imgs), B, S, _p(ws, torch.uint8), need, _p(f), _p(raw), _p(w_aff),
-                                      aff_layers, _p(attn), n_attn_out, _p(feats), _stream()), "excel_vit_forward")
+        if ex_attn is not None:
+            ex_attn = f32c(ex_attn)
+            if tuple(ex_attn.shape) != (B, N - 1, N - 1):
+                raise ValueError(f"ex_attn must be [B,P,P] = {(B, N - 1, N - 1)}, got {tuple(ex_attn.shape)}")
+        check(lib().excel_vit_forward_ex(self._h, _p(imgs), B, S, _p(ws, torch.uint8), need, _p(f), _p(raw), _p(w_aff),
+                                         aff_layers, _p(attn), n_attn_out, _p(feats), _p(ex_attn), _stream()), "excel_vit_forward")
         return dict(image_features=f, w_aff=w_aff, attn=attn, feats=feats, x_raw=raw)
 
 
@@ -209,6 +214,34 @@ def attn_layer_mean(attn, n_layers=6):
     n = min(n_layers, Lw)
     out = torch.empty((B, N - 1, N - 1), dtype=torch.float32, device=attn.device)
     check(lib().excel_attn_layer_mean(_p(attn), Lw, B, N, Lw - n, n, _p(out), _stream()), "excel_attn_layer_mean")
+    return out
+
+
+def attn_select_mean(attn, seg_attn, n_layers=6):
+    """seg_attn branch of refine_cams_with_aff (affutils.py:182-195): attn [Lw,B,N,N], seg_attn [B,P,P] -> [B,P,P]."""
+    attn = f32c(attn)
+    seg_attn = f32c(seg_attn)
+    Lw, B, N, _ = attn.shape
+    n = min(n_layers, Lw)
+    if tuple(seg_attn.shape) != (B, N - 1, N - 1):
+        raise ValueError(f"seg_attn must be [B,P,P] = {(B, N - 1, N - 1)}, got {tuple(seg_attn.shape)}")
+    out = torch.empty((B, N - 1, N - 1), dtype=torch.float32, device=attn.device)
+    ws = _ws(lib().excel_attn_select_workspace_bytes(B, n), attn.device)
+    check(lib().excel_attn_select_mean(_p(attn), Lw, B, N, Lw - n, n, _p(seg_attn), _p(out), _p(ws, torch.uint8), _stream()),
+          "excel_attn_select_mean")
+    return out
+
+
+def feature_affinity(feats, mode, beta=1.0, gamma=3.0):
+    """feats [B,C,g,g] | [B,C,P] -> [B,P,P].  mode "sigmoid": attn_pred (model_excel.py:70-76);
+    mode "mask_softmax": ex_attn of the LVC branch (clip_surgery_model.py:128-137)."""
+    feats = f32c(feats)
+    feats = feats.reshape(feats.shape[0], feats.shape[1], -1)
+    B, Cc, P = feats.shape
+    out = torch.empty((B, P, P), dtype=torch.float32, device=feats.device)
+    ws = _ws(lib().excel_feature_affinity_workspace_bytes(B, Cc, P), feats.device)
+    check(lib().excel_feature_affinity(_p(feats), B, Cc, P, float(beta), float(gamma), {"sigmoid": 0, "mask_softmax": 1}[mode],
+                                       _p(out), _p(ws, torch.uint8), _stream()), "excel_feature_affinity")
     return out
 
 

@@ -108,11 +108,21 @@ def build_validation(model=None, par=None, dataset=None, indices=None, device="c
             inputs = ops.bilinear_resize(inputs, S, S, align_corners=False)                 # :74
         cls_labels = torch.from_numpy(cls).to(device, non_blocking=True)
         gt_dev = torch.from_numpy(gts).to(device, non_blocking=True)
-        if args.api_path:
-            _, _, attr_maps_raw, attn_weights, _ = model(inputs)                            # :79
+        training_free = bool(getattr(args, "training_free", True))
+        if args.api_path or not training_free:
+            if training_free:
+                _, _, attr_maps_raw, attn_weights, attn_pred = model(inputs)                # :79
+            else:
+                # optimised-LAM regime (:84-85, :91): needs the caller's decoder as model.feature_head
+                from ..utils.camutils import cure_attr_map_flip
+                _, _, _, attn_weights, attn_pred = model(inputs, n_attn_out=6)              # :79
+                if attn_pred is None:
+                    raise RuntimeError("--training_free false needs model.feature_head (the learned decoder, SURVEY 8f #2)")
+                attr_maps_raw = cure_attr_map_flip(model, inputs)                           # :85
             for i, attr_map in enumerate(attr_maps_raw):                                    # :88
+                seg_attn = None if training_free else attn_pred[i][None]                    # :91-92
                 refined, cls_lst = refine_cams_with_aff(attr_map, attn_weights[:, i], cls_labels[i], size=inputs.shape[2:],
-                                                        caa_thre=0.79)                      # :93
+                                                        seg_attn=seg_attn, caa_thre=0.79)   # :93
                 labels, _ = refine_cams_with_bkg_weclip(refined, inputs[i], cls_lst, par, gts.shape[-2:])   # :94
                 hist = evaluate.hist_from_labels([gt_dev[i]], [labels[0]], args.num_classes, device, hist)
         else:

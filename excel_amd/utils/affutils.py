@@ -1,7 +1,7 @@
 """Mirror of the hot functions of utils/affutils.py over the HIP kernels.
 
   compute_trans_mat            :8-24
-  refine_cams_with_aff         :177-223 (seg_attn=None)
+  refine_cams_with_aff         :177-223 (both branches; seg_attn needs per-layer maps: model(img, n_attn_out>=6))
   refine_cams_with_bkg_weclip  :161-174  (+ generate_cam_label/scale_cam_image :55-78, _refine_cams :80-89)
 
 The reference hops to the host per class (numpy + OpenCV, :207-217, :59-66); here everything stays on the device:
@@ -32,11 +32,17 @@ def _w_aff_of(attn_weights, attn_layers):
 @torch.no_grad()
 def refine_cams_with_aff(attr_map, attn_weights, cls_label, size, caa_thre=0.79, attn_layers=6, seg_attn=None):
     """attr_map [P,F], attn_weights [L,N,N] | LazyAttnWeights, cls_label [F] -> (list of k x [g,g], cls_lst cpu int64)."""
-    if seg_attn is not None:
-        raise NotImplementedError("seg_attn branch (affutils.py:182-195) is SURVEY 8(f) 'next'")
     h, w = size
     g = h // 16
-    w_aff = _w_aff_of(attn_weights, attn_layers)
+    if seg_attn is not None:                                                                  # :182-195
+        stacked = attn_weights.stacked if isinstance(attn_weights, LazyAttnWeights) else attn_weights
+        if stacked is None or stacked.shape[0] < attn_layers:
+            raise ValueError("the seg_attn branch needs the per-layer attention maps: call model(img, n_attn_out=%d)" % attn_layers)
+        if stacked.dim() == 3:
+            stacked = stacked[:, None]
+        w_aff = ops.attn_select_mean(stacked[:, :1].contiguous(), seg_attn.reshape(1, g * (w // 16), -1), attn_layers)
+    else:
+        w_aff = _w_aff_of(attn_weights, attn_layers)
     cls_label = torch.as_tensor(cls_label)
     cls_lst = torch.where(cls_label.detach().cpu() != 0)[0]                                   # :203
     k = int(cls_lst.numel())

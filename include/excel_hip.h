@@ -104,6 +104,22 @@ int excel_vit_forward(excel_vit_t h, const float* img, int B, int S, void* works
                       float* image_features, float* x_raw, float* w_aff, int aff_layers,
                       float* attn_out, int n_attn_out, float* feats_out, void* stream);
 
+/* Same, with the LVC cue of Attention.forward's `ex_feats` branch (clip/clip_surgery_model.py:127-141):
+ *   ex_attn [B,P,P] (= excel_feature_affinity(ex_feats, mode 1)) is added to attn[:, :, 1:, 1:] of EVERY head of every
+ *   surgery block before the head sum; NULL = the ex_feats=None branch (identical to excel_vit_forward). */
+int excel_vit_forward_ex(excel_vit_t h, const float* img, int B, int S, void* workspace, size_t workspace_bytes,
+                         float* image_features, float* x_raw, float* w_aff, int aff_layers,
+                         float* attn_out, int n_attn_out, float* feats_out, const float* ex_attn, void* stream);
+
+/* Token affinity of decoder features, shared by attn_pred (model/model_excel.py:70-76) and the ex_feats branch
+ * (clip/clip_surgery_model.py:128-137):  feats [B,C,P] -> F.normalize over C -> sim = f^T f [B,P,P]
+ *   -> z = (sim - mean(sim over the WHOLE batch tensor) * beta) * gamma
+ *   mode 0: out = sigmoid(z)                                  (attn_pred: beta 1, gamma 3)
+ *   mode 1: z < 0 -> -inf, out = softmax(z, dim=-1)           (ex_attn:   beta 1, gamma 3)                       */
+size_t excel_feature_affinity_workspace_bytes(int B, int C, int P);
+int excel_feature_affinity(const float* feats, int B, int C, int P, float beta, float gamma, int mode, float* out,
+                           void* workspace, void* stream);
+
 /* ------------------------------------------------------------------ patch-text CAM */
 
 /* clip_feature_surgery (clip/clip.py:288-310, redundant_feats=None) on normalised features:
@@ -120,6 +136,13 @@ int excel_attn_layer_mean(const float* attn, int Lw, int B, int N, int first_lay
 
 /* compute_trans_mat (utils/affutils.py:8-24): 3x(col,row) normalise, symmetrise, square (batched fp32 MFMA GEMM).
  * workspace: (2*B*P*P + B*P) floats. */
+/* seg_attn branch of refine_cams_with_aff (utils/affutils.py:182-195): of the n_layers per-layer maps
+ * attn[first_layer .. first_layer+n_layers) ([Lw,B,N,N] stacked, [1:,1:] used) keep those whose total difference to
+ * seg_attn [B,P,P] is <= the mean difference, average them (/ (count + 1e-5)) and gate by seg_attn -> w_out [B,P,P]. */
+size_t excel_attn_select_workspace_bytes(int B, int n_layers);
+int excel_attn_select_mean(const float* attn, int Lw, int B, int N, int first_layer, int n_layers, const float* seg_attn,
+                           float* w_out, void* workspace, void* stream);
+
 size_t excel_trans_mat_workspace_bytes(int B, int P);
 int excel_compute_trans_mat(const float* w_aff, int B, int P, float* trans_out, void* workspace, void* stream);
 

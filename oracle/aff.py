@@ -93,11 +93,25 @@ def box_mask(scoremap, threshold):
     return m
 
 
-def refine_cams_with_aff(attr_map, attn_weights, cls_label, size, caa_thre=0.79, attn_layers=6):
+def select_attn_layers(aw, seg_attn):
+    """:182-195: keep the layers whose attention is closest (in total mass) to the decoder's affinity prediction,
+    average them, gate by the prediction.  aw [L,P,P], seg_attn [1,P,P] or [P,P] -> [P,P]."""
+    sa = np.asarray(seg_attn, np.float32).reshape(1, *aw.shape[1:])
+    diff = (sa - aw).reshape(aw.shape[0], -1).sum(1, dtype=np.float32)                 # :183-184
+    th = diff.mean(dtype=np.float32)                                                   # :185
+    mask = (diff <= th).astype(np.float32).reshape(-1, 1, 1)                           # :187-190
+    sel = (mask * aw).sum(0, dtype=np.float32) / (mask.sum(0, dtype=np.float32) + np.float32(1e-5))   # :193
+    return (sel * sa[0]).astype(np.float32)                                            # :195
+
+
+def refine_cams_with_aff(attr_map, attn_weights, cls_label, size, caa_thre=0.79, attn_layers=6, seg_attn=None):
     """attr_map [P,F], attn_weights [L,N,N], cls_label [F] -> (list of [g,g], cls_lst)."""
     h, w = size
     aw = np.asarray(attn_weights, np.float32)[:, 1:, 1:][-attn_layers:]               # :180
-    aw = aw.mean(0, dtype=np.float32)                                                  # :197
+    if seg_attn is not None:
+        aw = select_attn_layers(aw, seg_attn)                                          # :182-195
+    else:
+        aw = aw.mean(0, dtype=np.float32)                                              # :197
     trans = compute_trans_mat(aw)                                                      # :200
     cls_lst = np.where(np.asarray(cls_label) != 0)[0]                                  # :203
     out = []

@@ -7,13 +7,13 @@ and model/model_excel.py:57-58 (the slice [:, 1:, :num_classes-1]).
 """
 import numpy as np
 
-from .vit import vit_forward, softmax
+from .vit import vit_forward, softmax, feature_similarity
 
 
-def generate_clip_fts(imgs, w, cfg):
+def generate_clip_fts(imgs, w, cfg, ex_feats=None):
     """-> image_features [B,N,C] (L2-normalised over dim=1 = the TOKEN axis, clip.py:353),
     attn_weights [L,B,N,N], all_feats [L,B,N,D]."""
-    x, attn, feats = vit_forward(imgs, w, cfg)
+    x, attn, feats = vit_forward(imgs, w, cfg, ex_feats)
     norm = np.sqrt((x * x).sum(axis=1, keepdims=True, dtype=np.float32))
     return (x / norm).astype(np.float32), attn, feats
 
@@ -40,8 +40,15 @@ def clip_feature_surgery(image_features, text_features, t=2):
     return np.stack(out, 0).astype(np.float32)
 
 
-def attr_maps_raw(imgs, w, cfg, text_attr, num_fg):
-    """ExCEL_model.forward hot lines (model_excel.py:57-58): text_attr is [C,T]."""
-    f, attn, feats = generate_clip_fts(imgs, w, cfg)
+def attn_pred(attn_fts):
+    """model/model_excel.py:70-76: sigmoid of the shifted/scaled channel-normalised similarity of the decoder
+    features.  attn_fts [B,C,g,g] -> [B,P,P]."""
+    z = feature_similarity(attn_fts, 1.0, 3.0)
+    return (1.0 / (1.0 + np.exp(-z.astype(np.float64)))).astype(np.float32)
+
+
+def attr_maps_raw(imgs, w, cfg, text_attr, num_fg, ex_feats=None):
+    """ExCEL_model.forward hot lines (model_excel.py:57-58; :50-53 with ex_feats): text_attr is [C,T]."""
+    f, attn, feats = generate_clip_fts(imgs, w, cfg, ex_feats)
     maps = clip_feature_surgery(f, text_attr.T)[:, 1:, :num_fg]
     return maps, attn, f, feats

@@ -134,8 +134,28 @@ def mha_block_attention(y, p, w, cfg):
     return o.astype(np.float32), a.mean(0, dtype=np.float32)
 
 
-def surgery_attention(y, p, w, cfg):
-    """Attention.forward :95-159 -> (x [N,D], x_ori [N,D], head-SUM of attn_ori [N,N])."""
+def feature_similarity(feats, beta=1.0, gamma=3.0):
+    """Shared front of the LVC branch (:130-133) and of attn_pred (model/model_excel.py:71-75): channel-normalised
+    token similarity, shifted by beta x the mean over the WHOLE batch tensor and scaled by gamma.
+    feats [B,C,g,g] (or [B,C,P]) -> [B,P,P] f32."""
+    f = np.asarray(feats, np.float32)
+    f = f.reshape(f.shape[0], f.shape[1], -1)
+    nrm = np.sqrt((f * f).sum(1, keepdims=True, dtype=np.float32))
+    f = f / np.maximum(nrm, np.float32(1e-12))                        # F.normalize(dim=1), eps 1e-12
+    sim = np.einsum("bcm,bcn->bmn", f, f).astype(np.float32)          # :131
+    return ((sim - sim.mean(dtype=np.float32) * np.float32(beta)) * np.float32(gamma)).astype(np.float32)   # :132
+
+
+def ex_attention(ex_feats):
+    """Attention.forward :128-137: negatives of the similarity -> -inf, row softmax.  [B,C,g,g] -> ex_attn [B,P,P]."""
+    sim = feature_similarity(ex_feats, 1.0, 3.0)
+    sim = np.where(sim < 0, -np.inf, sim).astype(np.float32)          # :133
+    return softmax(sim)                                               # :137 (identical for every head)
+
+
+def surgery_attention(y, p, w, cfg, ex_attn=None):
+    """Attention.forward :95-159 -> (x [N,D], x_ori [N,D], head-SUM of attn_ori [N,N]).
+    ex_attn [P,P] (LVC branch :127-141) is added to every head's attn[1:,1:]."""
     h = cfg.heads
     q, k, v = _qkv(y, p, w, h)
     scale = np.float32(cfg.head_dim ** -0.5)
@@ -143,7 +163,9 @@ def surgery_attention(y, p, w, cfg):
     a1 = softmax((q @ q.transpose(0, 2, 1)) * scale)                  # :119
     a2 = softmax((k @ k.transpose(0, 2, 1)) * scale)                  # :120
     a3 = softmax((v @ v.transpose(0, 2, 1)) * scale)                  # :121
-    attn = (a1 + a2 + a3) / np.float32(3)                             # :125
+    attn = (a1 + a2 + a3) / np.float32(3)                             # :125 / :139
+    if ex_attn is not None:
+        attn[:, 1:, 1:] = attn[:, 1:, 1:] + np.asarray(ex_attn, np.float32)[None]    # :140-141
     attn = attn.sum(0, keepdims=True, dtype=np.float32)               # :146  head-summed, broadcast on V
     x_ori = _merge_heads(attn_ori @ v)                                # :148
     x = _merge_heads(attn @ v)                                        # :149
@@ -167,7 +189,7 @@ def patch_embed(img, w, cfg):
     return (patches @ w["conv1.weight"].reshape(cfg.width, -1).T).astype(np.float32)
 
 
-def vit_forward_single(img, w, cfg: VitConfig, pos=None):
+def vit_forward_single(img, w, cfg: VitConfig, pos=None, ex_attn=None):
     """VisionTransformer.forward :419-448 for ONE image [3,S,S].
 
     Returns x [N,out_dim], attn_weights list(L) of [N,N], all_feats list(L) of [N,D]
@@ -198,7 +220,7 @@ def vit_forward_single(img, w, cfg: VitConfig, pos=None):
         else:
             src = x if x_ori is None else x_ori                      # :323 vs :315
             x_res, x_ori_res, a = surgery_attention(
-                layer_norm(src, w[p + "ln_1.weight"], w[p + "ln_1.bias"]), p, w, cfg)
+                layer_norm(src, w[p + "ln_1.weight"], w[p + "ln_1.bias"]), p, w, cfg, ex_attn)
             x_ori = src + x_ori_res                                  # :317 / :326
             x_ori = x_ori + mlp(layer_norm(x_ori, w[p + "ln_2.weight"], w[p + "ln_2.bias"]), p, w)
             x_ori = x_ori.astype(np.float32)
@@ -214,13 +236,15 @@ def vit_forward_single(img, w, cfg: VitConfig, pos=None):
     return x, attn_weights, all_feats
 
 
-def vit_forward(imgs, w, cfg: VitConfig):
-    """Batched wrapper: imgs [B,3,S,S] -> x [B,N,out], attn [L,B,N,N], feats [L,B,N,D]."""
+def vit_forward(imgs, w, cfg: VitConfig, ex_feats=None):
+    """Batched wrapper: imgs [B,3,S,S] -> x [B,N,out], attn [L,B,N,N], feats [L,B,N,D].
+    ex_feats [B,C,g,g]: the LVC branch (the batch-global mean of :132 makes this a batch-level quantity)."""
     g = imgs.shape[-1] // cfg.patch
     pos = resize_pos_embed(w["positional_embedding"], g)
+    ex = ex_attention(ex_feats) if ex_feats is not None else None
     xs, attns, feats = [], [], []
     for b in range(imgs.shape[0]):
-        x, a, f = vit_forward_single(np.asarray(imgs[b], np.float32), w, cfg, pos)
+        x, a, f = vit_forward_single(np.asarray(imgs[b], np.float32), w, cfg, pos, None if ex is None else ex[b])
         xs.append(x)
         attns.append(np.stack(a, 0))
         feats.append(np.stack(f, 0))

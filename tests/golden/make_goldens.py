@@ -256,9 +256,35 @@ def gold_pipeline():
     save("pipeline_tiny.npz", seed_w=11, hist=hist, miou=sc["miou"], **out)
 
 
+# ---------------------------------------------------------------- 5. LVC branch: ex_feats in the surgery attention, seg_attn layer selection
+def gold_lvc():
+    w = make_vit_weights(TINY, seed=11)
+    vit = build_ref_vit(TINY, w, feat_size=6, mode="train")
+    rs = np.random.RandomState(41)
+    imgs = rs.standard_normal((2, 3, 96, 96)).astype(np.float32)
+    ex_feats = rs.standard_normal((2, 32, 6, 6)).astype(np.float32)
+    text = rs.standard_normal((9, 64)).astype(np.float32)
+    text /= np.linalg.norm(text, axis=1, keepdims=True)
+    x, attn_list, _ = vit(torch.from_numpy(imgs), True, torch.from_numpy(ex_feats))       # clip_surgery_model.py:419, :127-141
+    f = x / x.norm(dim=1, keepdim=True)                                                  # clip.py:353
+    cam = ref_clip_fs(f, torch.from_numpy(text))
+    attn = torch.stack(attn_list, 0)
+    # attn_pred: model/model_excel.py:70-76 cannot be imported (mmcv); the five tensor lines are re-typed HERE (harness
+    # only) -- the same similarity is pinned through the reference's own Attention.forward above.
+    fl = F.normalize(torch.from_numpy(ex_feats).reshape(2, 32, 36), dim=1)
+    ap = fl.transpose(2, 1).bmm(fl)
+    ap = torch.sigmoid((ap - torch.mean(ap) * 1.) * 3.0)
+    # refine_cams_with_aff with seg_attn (utils/affutils.py:182-195), image 0
+    cls_label = np.array([1, 0, 1, 0], np.float32)
+    maps = cam[:, 1:, :4]
+    refined, cls_lst = ref_aff.refine_cams_with_aff(maps[0], attn[:, 0], torch.from_numpy(cls_label), size=(96, 96),
+                                                    seg_attn=ap[0].unsqueeze(0), caa_thre=0.79)
+    save("lvc_tiny.npz", seed_w=11, imgs=imgs, ex_feats=ex_feats, text=text, x=x, cam=cam, attn=attn, attn_pred=ap,
+         cls=cls_label, refined=torch.stack(refined, 0), cls_lst=cls_lst)
+
+
 if __name__ == "__main__":
+    which = sys.argv[1:] or ["vit_cam", "ops", "attr", "pipeline", "lvc"]       # e.g. `make_goldens.py lvc` mints one file
     with torch.no_grad():
-        gold_vit_cam()
-        gold_ops()
-        gold_attr()
-        gold_pipeline()
+        for name in which:
+            globals()["gold_" + name]()

@@ -361,3 +361,124 @@ def test_split_batch_matches_single_stream(gpu, b16_model):
         p2.drain()
         assert np.array_equal(host(got), host(ref))
         assert np.array_equal(host(p2.hist), 2 * host(p1.hist))
+
+
+# ------------------------------------------------------------------ LVC branch (ex_feats, attn_pred, seg_attn)
+def test_feature_affinity_vs_golden_and_oracle(gpu, golden):
+    from excel_amd import ops
+    g = golden("lvc_tiny.npz")
+    ap = host(ops.feature_affinity(dev(g["ex_feats"]), "sigmoid"))
+    assert maxabs(ap, g["attn_pred"]) < 1e-6                                     # model_excel.py:70-76 (golden)
+    ex = host(ops.feature_affinity(dev(g["ex_feats"]), "mask_softmax"))
+    ref = oracle.vit.ex_attention(g["ex_feats"])                                 # clip_surgery_model.py:128-137 (pinned via the ViT golden)
+    assert maxabs(ex, ref) < 1e-6
+    np.testing.assert_allclose(ex.sum(-1), 1.0, atol=1e-5)
+    # odd channel count (K padding of the similarity GEMM) and a larger grid
+    rs = np.random.RandomState(3)
+    f = rs.standard_normal((3, 37, 14, 14)).astype(np.float32)
+    assert maxabs(host(ops.feature_affinity(dev(f), "sigmoid")), oracle.cam.attn_pred(f)) < 1e-6
+    assert maxabs(host(ops.feature_affinity(dev(f), "mask_softmax")), oracle.vit.ex_attention(f)) < 1e-6
+
+
+@pytest.mark.parametrize("gemm_mode,tol", [("f32", 2e-4), ("bf16x3", 1e-3)])
+def test_lvc_ex_feats_forward_matches_golden(gpu, golden, gemm_mode, tol):
+    """model(img, ex_feats=...) (model_excel.py:50-53 -> Attention.forward :127-141) against the reference's own output."""
+    from excel_amd.utils.camutils import cure_attr_map
+    g = golden("lvc_tiny.npz")
+    model, _ = tiny_model(g["text"].T.copy(), gemm_mode=gemm_mode)
+    maps = host(model(dev(g["imgs"]), ex_feats=dev(g["ex_feats"])))
+    assert maps.shape == (2, 36, 4)
+    assert maxabs(maps, g["cam"][:, 1:, :4]) < tol
+    base = host(model(dev(g["imgs"]))[2])
+    assert maxabs(base, g["cam"][:, 1:, :4]) > 10 * tol          # the cue is not silently ignored
+    assert np.array_equal(host(cure_attr_map(model, dev(g["imgs"]), dev(g["ex_feats"]))), maps)
+    # raw token features of the branch
+    from excel_amd import ops
+    r = model.encoder.visual.handle().forward(dev(g["imgs"]), want_raw=True,
+                                              ex_attn=ops.feature_affinity(dev(g["ex_feats"]), "mask_softmax"))
+    assert maxabs(host(r["x_raw"]), g["x"]) / float(np.abs(g["x"]).max()) < (2e-5 if gemm_mode == "f32" else 2e-4)
+
+
+def test_refine_with_seg_attn_matches_golden(gpu, golden):
+    """refine_cams_with_aff(..., seg_attn=attn_pred[i]) (tools/infer_lam.py:91-93, affutils.py:182-195)."""
+    from excel_amd.utils.affutils import refine_cams_with_aff
+    from excel_amd import ops
+    g = golden("lvc_tiny.npz")
+    model, _ = tiny_model(g["text"].T.copy(), gemm_mode="f32")
+    _, _, _, attn_weights, _ = model(dev(g["imgs"]), n_attn_out=6)
+    assert maxabs(host(attn_weights.stacked), g["attn"][-6:]) < 1e-4
+    seg_attn = dev(g["attn_pred"][0][None])
+    refined, cls_lst = refine_cams_with_aff(dev(g["cam"][0, 1:, :4].copy()), attn_weights[:, 0, ...], dev(g["cls"]), size=(96, 96),
+                                            seg_attn=seg_attn, caa_thre=0.79)
+    assert list(cls_lst.numpy()) == list(g["cls_lst"])
+    assert maxabs(np.stack([host(r) for r in refined], 0), g["refined"]) < 1e-6
+    # op level, batched, against the oracle
+    sel = host(ops.attn_select_mean(dev(g["attn"]), dev(g["attn_pred"]), 6))
+    for b in range(2):
+        assert maxabs(sel[b], oracle.aff.select_attn_layers(g["attn"][-6:, b, 1:, 1:], g["attn_pred"][b])) < 1e-7
+    with pytest.raises(ValueError):
+        refine_cams_with_aff(dev(g["cam"][0, 1:, :4].copy()), model(dev(g["imgs"]))[3][:, 0, ...], dev(g["cls"]), size=(96, 96), seg_attn=seg_attn)
+
+
+def test_flip_tta_with_feature_head(gpu, golden):
+    """cure_attr_map_flip(model, inputs) with ex_fts=True (camutils.py:8-30 as tools/infer_lam.py:85 calls it): the decoder is the
+    caller's; a deterministic stand-in head exercises the plumbing and is mirrored with the oracle."""
+    from excel_amd.utils.camutils import cure_attr_map_flip
+    g = golden("lvc_tiny.npz")
+    model, w = tiny_model(g["text"].T.copy(), gemm_mode="f32")
+    wo = oracle.vit.reload_self_attn(w, TINY, 6, "train")
+    head = lambda feats: feats[-1][:, 1:, :24].permute(0, 2, 1).reshape(feats.shape[1], 24, 6, 6).contiguous()
+    model.feature_head = head
+    x = g["imgs"]
+    got = host(cure_attr_map_flip(model, dev(x)))
+    xc = np.concatenate([x, x[..., ::-1]], 0)
+    _, _, feats = oracle.vit.vit_forward(xc, wo, TINY)
+    ex = feats[-1][:, 1:, :24].transpose(0, 2, 1).reshape(4, 24, 6, 6)
+    m = oracle.cam.attr_maps_raw(xc, wo, TINY, g["text"].T.copy(), 4, ex_feats=ex)[0]
+    lam = m.transpose(0, 2, 1).reshape(4, 4, 6, 6)
+    lam = np.maximum(lam[:2], lam[2:][..., ::-1])
+    lam = lam - lam.min(axis=(2, 3), keepdims=True)
+    lam = lam / (lam.max(axis=(2, 3), keepdims=True) + 1e-5)
+    assert maxabs(got, lam.reshape(2, 4, 36).transpose(0, 2, 1)) < 3e-4
+    out = model(dev(x))
+    assert out[1] is not None and out[4] is not None and maxabs(host(out[4]), oracle.cam.attn_pred(host(out[1]))) < 1e-6
+
+
+def test_harness_optimised_lam_regime_vs_oracle(gpu, golden):
+    """tools/infer_lam.py with --training_free false (:84-85, :91-93): flip-TTA LAMs through the LVC branch + seg_attn-gated
+    affinity, per image, with a stand-in decoder head; mirrored step by step with the oracle on one synthetic sample."""
+    from types import SimpleNamespace
+    from excel_amd.tools import infer_lam
+    from excel_amd.utils.PAR import PAR
+    g = golden("lvc_tiny.npz")
+    model, w = tiny_model(g["text"].T.copy(), gemm_mode="f32")
+    wo = oracle.vit.reload_self_attn(w, TINY, 6, "train")
+    model.feature_head = lambda feats: feats[-1][:, 1:, :24].permute(0, 2, 1).reshape(feats.shape[1], 24, 6, 6).contiguous()
+    rs = np.random.RandomState(12)
+    img = rs.standard_normal((1, 3, 96, 96)).astype(np.float32)
+    gt = rs.randint(0, 5, (1, 96, 96)).astype(np.uint8)
+    cls = np.array([[1, 0, 0, 1]], np.float32)
+
+    class DS:
+        def __len__(self): return 1
+        def max_k(self): return 2
+        def batch(self, idx): return ["s0"], img, gt, cls
+    args = SimpleNamespace(resize_size=96, num_classes=5, api_path=True, batch_size=1, training_free=False)
+    par = PAR(num_iter=20, dilations=[1, 2, 4, 8, 12, 24])
+    hist, nimg, _ = infer_lam.build_validation(model, par, DS(), [0], "cuda", args)
+    # oracle mirror
+    xc = np.concatenate([img, img[..., ::-1]], 0)
+    _, attn_c, feats = oracle.vit.vit_forward(xc, wo, TINY)
+    ex = feats[-1][:, 1:, :24].transpose(0, 2, 1).reshape(2, 24, 6, 6)
+    m = oracle.cam.attr_maps_raw(xc, wo, TINY, g["text"].T.copy(), 4, ex_feats=ex)[0]
+    lam = m.transpose(0, 2, 1).reshape(2, 4, 6, 6)
+    lam = np.maximum(lam[:1], lam[1:][..., ::-1])
+    lam = lam - lam.min(axis=(2, 3), keepdims=True)
+    lam = (lam / (lam.max(axis=(2, 3), keepdims=True) + 1e-5)).reshape(1, 4, 36).transpose(0, 2, 1)
+    _, attn1, feats1 = oracle.vit.vit_forward(img, wo, TINY)
+    ap = oracle.cam.attn_pred(feats1[-1][:, 1:, :24].transpose(0, 2, 1).reshape(1, 24, 6, 6))
+    refined, cls_lst = oracle.aff.refine_cams_with_aff(lam[0], attn1[:, 0], cls[0], size=(96, 96), caa_thre=0.79, seg_attn=ap[0][None])
+    label, _ = oracle.aff.refine_cams_with_bkg_weclip(refined, img[0], cls_lst, oracle.par.PAR([1, 2, 4, 8, 12, 24], 20), (96, 96))
+    ref_hist = oracle.evaluate.fast_hist(gt[0].flatten(), label[0].flatten(), 5)
+    assert nimg == 1 and int(host(hist).sum()) == 96 * 96
+    assert np.abs(host(hist) - ref_hist).sum() <= 0.002 * 96 * 96

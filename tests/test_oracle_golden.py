@@ -128,3 +128,26 @@ def test_pipeline_trace(golden):
     hist, _ = oracle.pipeline.build_validation(samples, w, TINY, text_attr, num_classes=5, resize_size=96)
     assert np.abs(hist - g["hist"]).sum() <= 4          # argmax near-ties only
     assert abs(oracle.evaluate.scores_from_hist(hist)["miou"] - float(g["miou"])) < 1e-3
+
+
+def test_lvc_branch_ex_feats_and_seg_attn(golden):
+    """ex_feats branch of the surgery attention (clip_surgery_model.py:127-141), attn_pred
+    (model_excel.py:70-76) and the seg_attn layer selection (affutils.py:182-195)."""
+    g = golden("lvc_tiny.npz")
+    w = make_vit_weights(TINY, seed=int(g["seed_w"]))
+    w = oracle.vit.reload_self_attn(w, TINY, feat_size=6, mode="train")
+    x, attn, _ = oracle.vit.vit_forward(g["imgs"], w, TINY, ex_feats=g["ex_feats"])
+    assert relmax(x, g["x"]) < 2e-5
+    assert maxabs(attn, g["attn"]) < 1e-4
+    f, _, _ = oracle.cam.generate_clip_fts(g["imgs"], w, TINY, ex_feats=g["ex_feats"])
+    cam = oracle.cam.clip_feature_surgery(f, g["text"])
+    assert maxabs(cam, g["cam"]) < 2e-5
+    # the branch really changes the result (guards against a silently ignored argument)
+    x0, _, _ = oracle.vit.vit_forward(g["imgs"], w, TINY)
+    assert relmax(x0, g["x"]) > 1e-3
+    ap = oracle.cam.attn_pred(g["ex_feats"])
+    assert maxabs(ap, g["attn_pred"]) < 1e-6
+    refined, cls_lst = oracle.aff.refine_cams_with_aff(g["cam"][0, 1:, :4], g["attn"][:, 0], g["cls"], size=(96, 96),
+                                                       caa_thre=0.79, seg_attn=g["attn_pred"][0][None])
+    assert list(cls_lst) == list(g["cls_lst"])
+    assert maxabs(np.stack(refined, 0), g["refined"]) < 1e-6
