@@ -234,12 +234,101 @@ __global__ __launch_bounds__(256) void par_iterate4_kernel(const float* __restri
 //   3. taps are conflict-free ds_read_b128: dilations that are multiples of 4 read the shifted aligned group,
 //      dilations 1..3 read the 3 aligned groups around the pixel once per row and shift in registers.
 // aff is read exactly once per step whatever the channel count (it stays in registers across channel pairs).
+// One channel pair of a tile: stage the pair's mask tile (+ halo) in LDS, accumulate the 8*ND taps.
+// WSRC(di, k) yields the aff float4 of tap (di, k): either the rolling double buffer (loads issued here, one dilation
+// ahead) or the per-thread register copy of all taps (KEEP: images with more than two channels read aff ONCE for all
+// their channel pairs instead of once per pair -- 41 % of VOC images have 3+ channels).
+template <int ND, int HALO, int KEEPN>
+__device__ __forceinline__ void par_lds_pair(const float* __restrict__ ac, const f32x4 (&wall)[KEEPN ? KEEPN : 1][8], float* tile,
+                                             const float* __restrict__ in_pair, float* __restrict__ out_px, int nc, const ParDil& dl,
+                                             int x0, int y0, int tid, int tx, int ty, bool valid, int H, int W, long long HW) {
+    constexpr int halo = HALO, TR = 16 + 2 * HALO, TP = 64 + 2 * HALO, TP4 = TP >> 2;
+    // opaque per call: otherwise LICM hoists the ~50 LDS tap offsets out of the caller's channel-pair loop and they
+    // compete with the pinned aff registers (spills)
+    asm volatile("" : "+v"(tx), "+v"(ty));
+    const int cb = halo + 4 * tx;
+    constexpr bool KEEP = KEEPN > 0;
+    f32x4 wbuf[2][8];
+    if (KEEPN < ND) {
+        // the first streamed dilation's loads are issued BEFORE the tile staging so their HBM latency overlaps it
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wbuf[KEEPN & 1][k] = *reinterpret_cast<const f32x4*>(ac + (long long)(KEEPN * 8 + k) * HW);
+    }
+    __syncthreads();
+    const int per_ch = TR * TP4;
+    for (int i = tid; i < nc * per_ch; i += 256) {
+        const int ch = i >= per_ch ? 1 : 0;
+        const int rem = i - ch * per_ch;
+        const int r = rem / TP4, g = rem - r * TP4;
+        const int gy = min(max(y0 - halo + r, 0), H - 1);
+        const f32x4 v = par_ldg4(in_pair + (long long)ch * HW + (long long)gy * W, x0 - halo + 4 * g, W);
+        *reinterpret_cast<f32x4*>(&tile[(ch * TR + r) * TP + 4 * g]) = v;
+    }
+    __syncthreads();
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int di = 0; di < ND; ++di) {
+        if (di >= KEEPN && di + 1 < ND) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                wbuf[(di + 1) & 1][k] = *reinterpret_cast<const f32x4*>(ac + (long long)((di + 1) * 8 + k) * HW);
+        }
+        const f32x4 (&w8)[8] = di < KEEPN ? wall[di < KEEPN ? di : 0] : wbuf[di & 1];
+        const int d = dl.d[di];
+        const int rr[3] = {ty + halo - d, ty + halo, ty + halo + d};
+        if ((d & 3) == 0) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    if (r == 1 && dx == 0) continue;
+                    const int k = (r == 0) ? dx + 1 : (r == 1 ? (dx < 0 ? 3 : 4) : dx + 6);
+                    const int off = rr[r] * TP + cb + dx * d;
+                    acc0 += *reinterpret_cast<const f32x4*>(&tile[off]) * w8[k];
+                    if (nc > 1) acc1 += *reinterpret_cast<const f32x4*>(&tile[TR * TP + off]) * w8[k];
+                    if (KEEP && dx == 1) __builtin_amdgcn_sched_barrier(0);
+                }
+        } else {
+            auto window = [&](auto shift_tag) {
+                constexpr int SH = decltype(shift_tag)::value;
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) {
+                    if (ch == 1 && nc < 2) break;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const float* rowp = &tile[(ch * TR + rr[r]) * TP + cb];
+                        const f32x4 L = *reinterpret_cast<const f32x4*>(rowp - 4), M = *reinterpret_cast<const f32x4*>(rowp),
+                                    R = *reinterpret_cast<const f32x4*>(rowp + 4);
+                        const float win[12] = {L[0], L[1], L[2], L[3], M[0], M[1], M[2], M[3], R[0], R[1], R[2], R[3]};
+#pragma unroll
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            if (r == 1 && dx == 0) continue;
+                            const int k = (r == 0) ? dx + 1 : (r == 1 ? (dx < 0 ? 3 : 4) : dx + 6);
+                            const f32x4 v = {win[4 + SH * dx], win[5 + SH * dx], win[6 + SH * dx], win[7 + SH * dx]};
+                            if (ch == 0) acc0 += v * w8[k]; else acc1 += v * w8[k];
+                        }
+                        if (KEEP) __builtin_amdgcn_sched_barrier(0);      // one row's window live at a time (192 aff VGPRs are pinned)
+                    }
+                }
+            };
+            if (d == 1) window(std::integral_constant<int, 1>{});
+            else if (d == 2) window(std::integral_constant<int, 2>{});
+            else window(std::integral_constant<int, 3>{});
+        }
+        __builtin_amdgcn_sched_barrier(0);   // do not hoist later dilations' loads (aff or LDS) above this point (VGPR cap)
+    }
+    if (valid) {
+        *reinterpret_cast<f32x4*>(out_px) = acc0;
+        if (nc > 1) *reinterpret_cast<f32x4*>(out_px + HW) = acc1;
+    }
+}
+
 template <int ND, int HALO>
 __global__ __launch_bounds__(256, 2) void par_iterate_lds_kernel(const float* __restrict__ aff, const float* __restrict__ in,
                                                                  float* __restrict__ out, const int* __restrict__ nchan,
                                                                  ParDil dl, int Cmax, int H, int W) {
     constexpr int NT = 8 * ND;
-    constexpr int halo = HALO, TR = 16 + 2 * HALO, TP = 64 + 2 * HALO, TP4 = TP >> 2;
+    constexpr int TR = 16 + 2 * HALO, TP = 64 + 2 * HALO;
     __shared__ __attribute__((aligned(16))) float tile[2 * TR * TP];   // [2][TR][TP]
     const int b = blockIdx.z, x0 = blockIdx.x * 64, y0 = blockIdx.y * 16;
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
@@ -247,84 +336,24 @@ __global__ __launch_bounds__(256, 2) void par_iterate_lds_kernel(const float* __
     const bool valid = px < W && py < H;
     const int nch = nchan ? min(nchan[b], Cmax) : Cmax;
     const long long HW = (long long)H * W;
-
     const float* a = aff + (long long)b * NT * HW + (long long)min(py, H - 1) * W + min(px, W - 4);
-    const int cb = halo + 4 * tx;
-    for (int c0 = 0; c0 < nch; c0 += 2) {
-        const int nc = min(2, nch - c0);
-        // aff weights: one dilation (8 float4) in use, the next one in flight (static double buffer by unrolling).
-        // Channel pairs beyond the first re-read aff (MALL/L2-resident: the block just streamed it).
-        // The first dilation's loads are issued BEFORE the tile staging so their HBM latency overlaps it.
-        f32x4 wbuf[2][8];
-        const float* ac = a;
-        asm volatile("" : "+v"(ac));   // opaque per channel pair: stops LICM from hoisting all 48 loads (192 VGPRs) out of the loop
+    const float* in_b = in + (long long)b * Cmax * HW;
+    float* out_px = out + (long long)b * Cmax * HW + (long long)py * W + px;
+    if (nch > 2) {
+        // two or more channel pairs: the workgroup is LDS-limited to 2 waves/SIMD anyway (256 VGPRs available), so the
+        // aff float4 of this thread's 4 pixels stay in registers across the pairs
+        constexpr int KEEPN = ND;
+        f32x4 wall[KEEPN][8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) wbuf[0][k] = *reinterpret_cast<const f32x4*>(ac + (long long)k * HW);
-        __syncthreads();
-        const int per_ch = TR * TP4;
-        for (int i = tid; i < nc * per_ch; i += 256) {
-            const int ch = i >= per_ch ? 1 : 0;
-            const int rem = i - ch * per_ch;
-            const int r = rem / TP4, g = rem - r * TP4;
-            const int gy = min(max(y0 - halo + r, 0), H - 1);
-            const f32x4 v = par_ldg4(in + ((long long)b * Cmax + c0 + ch) * HW + (long long)gy * W, x0 - halo + 4 * g, W);
-            *reinterpret_cast<f32x4*>(&tile[(ch * TR + r) * TP + 4 * g]) = v;
-        }
-        __syncthreads();
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        for (int di = 0; di < KEEPN; ++di)
 #pragma unroll
-        for (int di = 0; di < ND; ++di) {
-            if (di + 1 < ND) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    wbuf[(di + 1) & 1][k] = *reinterpret_cast<const f32x4*>(ac + (long long)((di + 1) * 8 + k) * HW);
-            }
-            const int d = dl.d[di];
-            const int rr[3] = {ty + halo - d, ty + halo, ty + halo + d};
-            if ((d & 3) == 0) {
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int dx = -1; dx <= 1; ++dx) {
-                        if (r == 1 && dx == 0) continue;
-                        const int k = (r == 0) ? dx + 1 : (r == 1 ? (dx < 0 ? 3 : 4) : dx + 6);
-                        const int off = rr[r] * TP + cb + dx * d;
-                        acc0 += *reinterpret_cast<const f32x4*>(&tile[off]) * wbuf[di & 1][k];
-                        if (nc > 1) acc1 += *reinterpret_cast<const f32x4*>(&tile[TR * TP + off]) * wbuf[di & 1][k];
-                    }
-            } else {
-                auto window = [&](auto shift_tag) {
-                    constexpr int SH = decltype(shift_tag)::value;
-#pragma unroll
-                    for (int ch = 0; ch < 2; ++ch) {
-                        if (ch == 1 && nc < 2) break;
-#pragma unroll
-                        for (int r = 0; r < 3; ++r) {
-                            const float* rowp = &tile[(ch * TR + rr[r]) * TP + cb];
-                            const f32x4 L = *reinterpret_cast<const f32x4*>(rowp - 4), M = *reinterpret_cast<const f32x4*>(rowp),
-                                        R = *reinterpret_cast<const f32x4*>(rowp + 4);
-                            const float win[12] = {L[0], L[1], L[2], L[3], M[0], M[1], M[2], M[3], R[0], R[1], R[2], R[3]};
-#pragma unroll
-                            for (int dx = -1; dx <= 1; ++dx) {
-                                if (r == 1 && dx == 0) continue;
-                                const int k = (r == 0) ? dx + 1 : (r == 1 ? (dx < 0 ? 3 : 4) : dx + 6);
-                                const f32x4 v = {win[4 + SH * dx], win[5 + SH * dx], win[6 + SH * dx], win[7 + SH * dx]};
-                                if (ch == 0) acc0 += v * wbuf[di & 1][k]; else acc1 += v * wbuf[di & 1][k];
-                            }
-                        }
-                    }
-                };
-                if (d == 1) window(std::integral_constant<int, 1>{});
-                else if (d == 2) window(std::integral_constant<int, 2>{});
-                else window(std::integral_constant<int, 3>{});
-            }
-            __builtin_amdgcn_sched_barrier(0);   // do not hoist the aff loads of later dilations above this point (VGPR cap)
-        }
-        if (valid) {
-            float* o = out + ((long long)b * Cmax + c0) * HW + (long long)py * W + px;
-            *reinterpret_cast<f32x4*>(o) = acc0;
-            if (nc > 1) *reinterpret_cast<f32x4*>(o + HW) = acc1;
-        }
+            for (int k = 0; k < 8; ++k) wall[di][k] = *reinterpret_cast<const f32x4*>(a + (long long)(di * 8 + k) * HW);
+        for (int c0 = 0; c0 < nch; c0 += 2)
+            par_lds_pair<ND, HALO, KEEPN>(a, wall, tile, in_b + (long long)c0 * HW, out_px + (long long)c0 * HW, min(2, nch - c0), dl,
+                                         x0, y0, tid, tx, ty, valid, H, W, HW);
+    } else {
+        f32x4 none[1][8];
+        par_lds_pair<ND, HALO, 0>(a, none, tile, in_b, out_px, nch, dl, x0, y0, tid, tx, ty, valid, H, W, HW);
     }
 }
 

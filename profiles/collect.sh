@@ -9,7 +9,8 @@ REPO=$PWD
 export TMPDIR=/tmp
 python bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
 cd /tmp
-rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o kt -- python "$REPO/bench.py" --steps 3 --warmup 1 --cpu-images 0 > "$OUT/kt_bench.json" 2> "$OUT/kt.err"
+# the SAME command under the tracer (kt_bench.json = its bench line; its roofline.avg_launch_ms vs the category lines of kernel_stats.txt)
+rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o kt -- python "$REPO/bench.py" > "$OUT/kt_bench.json" 2> "$OUT/kt.err"
 DB=$(find "$OUT/kt" -name '*.db' | head -1)
 [ -n "$DB" ] && python "$REPO/profiles/summarize_rocpd.py" "$DB" > "$OUT/kernel_stats.txt"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT" -o fetch -- python "$REPO/bench.py" --steps 2 --warmup 1 --cpu-images 0 > /dev/null 2> "$OUT/fetch.err"

@@ -15,6 +15,16 @@ def main(path):
         short = name if len(name) <= 72 else name[:69] + "..."
         print(f"{short:<72} {n:>6} {tot / 1e6:>10.3f} {avg / 1e3:>10.2f} {mn / 1e3:>10.2f} {mx / 1e3:>10.2f} {100.0 * tot / total:>6.2f}%")
     print(f"{'TOTAL':<72} {sum(r[1] for r in rows):>6} {total / 1e6:>10.3f}")
+    # bench.py's profiling categories span several template instances: launch-weighted aggregates for direct comparison
+    # with its roofline.avg_launch_ms / roofline_par_iterate.avg_launch_ms
+    print()
+    for cat, key in (("gemm_bf16x3 (all tiles)", "gemm_bf16x3_kernel"), ("par_iterate", "par_iterate"), ("attn_rowpass", "attn_rowpass"),
+                     ("attn_accum", "attn_accum")):
+        sel = [r for r in rows if key in r[0]]
+        n = sum(r[1] for r in sel)
+        if n:
+            tot = sum(r[2] for r in sel)
+            print(f"category {cat:<28} calls {n:>6}  total_ms {tot / 1e6:>9.3f}  avg_us {tot / n / 1e3:>9.2f}")
 
 
 if __name__ == "__main__":
