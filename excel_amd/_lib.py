@@ -33,6 +33,23 @@ class VitWeights(C.Structure):
         [("blocks", C.POINTER(VitBlockWeights))]
 
 
+class DecoderConfig(C.Structure):
+    _fields_ = [(n, c_i) for n in ("vit_layers", "vit_width", "embed", "dec_layers", "heads", "num_classes")]
+
+
+class FuseLayerWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("proj_w", "proj_b", "proj2_w", "proj2_b")]
+
+
+class DecoderBlockWeights(C.Structure):
+    _fields_ = VitBlockWeights._fields_
+
+
+class DecoderWeights(C.Structure):
+    _fields_ = [("fuse", C.POINTER(FuseLayerWeights)), ("fuse_w", C.c_void_p), ("fuse_b", C.c_void_p),
+                ("blocks", C.POINTER(DecoderBlockWeights)), ("pred_w", C.c_void_p), ("pred_b", C.c_void_p)]
+
+
 # name -> (restype, argtypes); mirrors include/excel_hip.h one to one
 SIGNATURES = {
     "excel_last_error": (C.c_char_p, []),
@@ -48,11 +65,16 @@ SIGNATURES = {
     "excel_vit_set_gemm_mode": (c_i, [C.c_void_p, c_i]),
     "excel_vit_get_gemm_mode": (c_i, [C.c_void_p]),
     "excel_vit_forward": (c_i, [C.c_void_p, c_f, c_i, c_i, c_f, c_sz, c_f, c_f, c_f, c_i, c_f, c_i, c_f, c_f]),
-    "excel_vit_forward_ex": (c_i, [C.c_void_p, c_f, c_i, c_i, c_f, c_sz, c_f, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_f]),
+    "excel_vit_forward_ex": (c_i, [C.c_void_p, c_f, c_i, c_i, c_f, c_sz, c_f, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_i, c_f]),
     "excel_feature_affinity_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "excel_feature_affinity": (c_i, [c_f, c_i, c_i, c_i, C.c_float, C.c_float, c_i, c_f, c_f, c_f]),
     "excel_attn_select_workspace_bytes": (c_sz, [c_i, c_i]),
     "excel_attn_select_mean": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f]),
+    "excel_decoder_create": (c_i, [C.POINTER(DecoderConfig), C.POINTER(DecoderWeights), C.POINTER(C.c_void_p)]),
+    "excel_decoder_destroy": (None, [C.c_void_p]),
+    "excel_decoder_workspace_bytes": (c_sz, [C.c_void_p, c_i, c_i]),
+    "excel_decoder_forward": (c_i, [C.c_void_p, c_f, c_i, c_i, c_f, c_sz, c_f, c_f, c_f]),
+    "excel_seg_scale_accumulate": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, C.c_float, c_f]),
     "excel_cam_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "excel_clip_feature_surgery": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, C.c_float, c_f, c_f, c_f, c_f]),
     "excel_attn_layer_mean": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),

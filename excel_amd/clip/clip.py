@@ -41,13 +41,14 @@ class LazyAttnWeights:
         return (self.aff_layers if self.stacked is None else self.stacked.shape[0], B, P + 1, P + 1)
 
 
-def generate_clip_fts(inputs, model, return_weights=True, ex_feats=None, n_attn_out=0, want_feats=False, aff_layers=6):
+def generate_clip_fts(inputs, model, return_weights=True, ex_feats=None, n_attn_out=0, want_feats=False, aff_layers=6,
+                      feats_as_reference=False):
     """-> (image_features [B,N,C] L2-normalised over the TOKEN axis (:353), attn_weights, all_feats).
 
     attn_weights is a LazyAttnWeights (fast path) unless n_attn_out > 0, in which case it also holds the stacked
     [n_attn_out,B,N,N] tensor of the last layers.  all_feats is [L,B,N,D] when want_feats else None."""
     r = model.encode_image(inputs, return_weights, ex_feats, want_w_aff=True, aff_layers=aff_layers,
-                           n_attn_out=n_attn_out, want_feats=want_feats)
+                           n_attn_out=n_attn_out, want_feats=want_feats, feats_as_reference=feats_as_reference)
     return r["image_features"], LazyAttnWeights(r["w_aff"], r["attn"], aff_layers), r["feats"]
 
 

@@ -322,20 +322,26 @@ extern "C" size_t excel_vit_workspace_bytes(excel_vit_t h, int B, int S) {
 
 static int vit_forward_impl(excel_vit_t h, const float* img, int B, int S, void* workspace, size_t workspace_bytes,
                             float* image_features, float* x_raw, float* w_aff, int aff_layers, float* attn_out,
-                            int n_attn_out, float* feats_out, const float* ex_attn, void* stream);
+                            int n_attn_out, float* feats_out, const float* ex_attn, int flags, void* stream);
 
 extern "C" int excel_vit_forward(excel_vit_t h, const float* img, int B, int S, void* workspace, size_t workspace_bytes,
                                  float* image_features, float* x_raw, float* w_aff, int aff_layers, float* attn_out,
                                  int n_attn_out, float* feats_out, void* stream) {
     return vit_forward_impl(h, img, B, S, workspace, workspace_bytes, image_features, x_raw, w_aff, aff_layers, attn_out, n_attn_out,
-                            feats_out, nullptr, stream);
+                            feats_out, nullptr, 0, stream);
 }
 
 extern "C" int excel_vit_forward_ex(excel_vit_t h, const float* img, int B, int S, void* workspace, size_t workspace_bytes,
                                     float* image_features, float* x_raw, float* w_aff, int aff_layers, float* attn_out,
-                                    int n_attn_out, float* feats_out, const float* ex_attn, void* stream) {
+                                    int n_attn_out, float* feats_out, const float* ex_attn, int flags, void* stream) {
     return vit_forward_impl(h, img, B, S, workspace, workspace_bytes, image_features, x_raw, w_aff, aff_layers, attn_out, n_attn_out,
-                            feats_out, ex_attn, stream);
+                            feats_out, ex_attn, flags, stream);
+}
+
+extern "C" int excel_seg_scale_accumulate(const float* segs, float* acc, int B, int nc, int h, int w, int H, int W, int flip_mean,
+                                         int init, float scale, void* stream) {
+    EXCEL_CHECK_ARG(segs && acc && B > 0 && nc > 0 && h > 0 && w > 0 && H > 0 && W > 0, "seg_scale_accumulate: bad argument");
+    return excel_launch_seg_scale_accumulate(segs, acc, B, nc, h, w, H, W, flip_mean, init, scale, ST(stream));
 }
 
 extern "C" size_t excel_feature_affinity_workspace_bytes(int B, int C, int P) { return excel_feature_affinity_ws_bytes(B, C, P); }
@@ -354,7 +360,8 @@ extern "C" int excel_attn_select_mean(const float* attn, int Lw, int B, int N, i
 
 static int vit_forward_impl(excel_vit_t h, const float* img, int B, int S, void* workspace, size_t workspace_bytes,
                             float* image_features, float* x_raw, float* w_aff, int aff_layers, float* attn_out,
-                            int n_attn_out, float* feats_out, const float* ex_attn, void* stream) {
+                            int n_attn_out, float* feats_out, const float* ex_attn, int flags, void* stream) {
+    const bool aliased_feats = feats_out && (flags & EXCEL_VIT_FEATS_AS_REFERENCE);
     EXCEL_CHECK_ARG(h && img && workspace && image_features, "excel_vit_forward: null argument");
     const excel_vit_config& c = h->cfg;
     EXCEL_CHECK_ARG(B > 0 && S > 0 && S % c.patch == 0, "excel_vit_forward: S must be a positive multiple of the patch size");
@@ -483,6 +490,10 @@ static int vit_forward_impl(excel_vit_t h, const float* img, int B, int S, void*
                 TRY(linear_ex(ws.hbuf, bw.fc2_w, sw.fc2, bw.fc2_b, ws.xo, ws.xo, B, D, 4 * D, 4 * D, (int)rs, (int)rs, GEMM_ACT_NONE, GEMM_OUT_PLAIN));
             } else {
                 TRY(linear(ws.ao, bw.out_proj_w, sw.out_proj, bw.out_proj_b, src, ws.xo, D, D, GEMM_ACT_NONE, GEMM_OUT_PLAIN));
+                // quirk Q4 (what the reference's decoder really sees): the previous block's all_feats entry is a view of
+                // x_ori, and this block's `x_ori += x_ori_res` (:317) mutates it before the name is re-bound (:318)
+                if (aliased_feats && l > L - c.n_surgery)
+                    hipMemcpyAsync(feats_out + (size_t)(l - 1) * M * D, ws.xo, sizeof(float) * (size_t)M * D, hipMemcpyDeviceToDevice, st);
                 TRY(linear(ws.y, bw.out_proj_w, sw.out_proj, bw.out_proj_b, ws.x, ws.x, D, D, GEMM_ACT_NONE, GEMM_OUT_PLAIN));
                 TRY(excel_launch_layernorm(ws.xo, nullptr, 1, bw.ln2_w, bw.ln2_b, ws.y, M, D, eps, st, bf));
                 TRY(linear(ws.y, bw.fc1_w, sw.fc1, bw.fc1_b, nullptr, ws.hbuf, 4 * D, D, GEMM_ACT_QUICKGELU, mid_mode));
@@ -490,6 +501,14 @@ static int vit_forward_impl(excel_vit_t h, const float* img, int B, int S, void*
             }
             if (feats_out) hipMemcpyAsync(feats_out + (size_t)l * M * D, ws.xo, sizeof(float) * (size_t)M * D, hipMemcpyDeviceToDevice, st);
         }
+    }
+    if (aliased_feats && c.n_surgery > 0 && c.n_surgery < L) {
+        // quirk Q4: the last single-path block's entry aliases the new-path x: all `x += x_res` (:319,:329) and the cls
+        // swap (:442) land in it
+        float* dst = feats_out + (size_t)(L - c.n_surgery - 1) * M * D;
+        hipMemcpyAsync(dst, ws.x, sizeof(float) * (size_t)M * D, hipMemcpyDeviceToDevice, st);
+        hipMemcpy2DAsync(dst, sizeof(float) * (size_t)N * D, ws.xo, sizeof(float) * (size_t)N * D, sizeof(float) * D, B,
+                         hipMemcpyDeviceToDevice, st);
     }
     // x[0] = x_ori[0] (:442) fused into ln_post (:445), then @ proj (:446)
     TRY(excel_launch_layernorm(ws.x, c.n_surgery > 0 ? ws.xo : nullptr, N, h->w.ln_post_w, h->w.ln_post_b, ws.y, M, D, eps, st, bf));

@@ -135,6 +135,43 @@ __global__ __launch_bounds__(256) void lam_scale_accumulate_kernel(const float* 
     acc[i] = init ? v : acc[i] + v;
 }
 
+// multi-scale / flip fuse of segmentation logits (tools/infer_seg_voc.py:66-82):
+//   segs [2B,nc,h,w] of one scale (second half from flipped inputs) -> bilinear (align_corners=False) to (H,W) ->
+//   flip_mean ? (seg + flip_x(seg_flipped)) / 2 : seg          (the reference uses the un-flipped half alone at scale 1.0, :69)
+//   -> acc[B,nc,H,W] (+)= ... ; the last call folds the mean over scales (:82) through `scale`
+__global__ __launch_bounds__(256) void seg_scale_accumulate_kernel(const float* __restrict__ segs, float* __restrict__ acc, int B, int nc,
+                                                                   int h, int w, int H, int W, int flip_mean, int init, float scale) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)B * nc * H * W;
+    if (i >= total) return;
+    const int x = (int)(i % W), y = (int)((i / W) % H);
+    const long long plane = i / ((long long)W * H);           // b * nc + c
+    auto sample = [&](long long pl, int xx) {
+        const float fy = fmaxf(((float)h / (float)H) * ((float)y + 0.5f) - 0.5f, 0.f);
+        const float fx = fmaxf(((float)w / (float)W) * ((float)xx + 0.5f) - 0.5f, 0.f);
+        const int y0 = min((int)fy, h - 1), x0 = min((int)fx, w - 1);
+        const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float* m = segs + pl * h * w;
+        const float top = (1.f - lx) * m[y0 * w + x0] + lx * m[y0 * w + x1];
+        const float bot = (1.f - lx) * m[y1 * w + x0] + lx * m[y1 * w + x1];
+        return (1.f - ly) * top + ly * bot;
+    };
+    float v = sample(plane, x);
+    if (flip_mean) v = (v + sample(plane + (long long)B * nc, W - 1 - x)) / 2.f;     // (segs[:1] + segs[1:].flip(-1)) / 2  (:79)
+    v = init ? v : acc[i] + v;
+    acc[i] = v * scale;
+}
+
+int excel_launch_seg_scale_accumulate(const float* segs, float* acc, int B, int nc, int h, int w, int H, int W, int flip_mean, int init,
+                                      float scale, hipStream_t st) {
+    const long long total = (long long)B * nc * H * W;
+    hipLaunchKernelGGL(seg_scale_accumulate_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, segs, acc, B, nc, h, w, H, W,
+                       flip_mean, init, scale);
+    EXCEL_CHECK_LAUNCH("seg_scale_accumulate");
+    return EXCEL_OK;
+}
+
 // lam = lam - min_hw ; lam /= max_hw + 1e-5 per (b, f) plane (camutils.py:58-59), in place
 __global__ __launch_bounds__(256) void plane_minmax_normalize_kernel(float* __restrict__ lam, long long HW) {
     __shared__ float smn[4], smx[4];

@@ -1,0 +1,178 @@
+// Decoder head inference: SegFormerHead fuse (model/segformer_head.py:47-77) + DecoderTransformer
+// (model/decoder/TransDecoder.py:62-124) over the ViT's per-block features.  A small model (width 256, 3 layers, 8 heads of
+// 32): orchestration of the exact-fp32 matrix-core GEMM with a row softmax in between; scores are materialised
+// ([B*heads, P, P] fp32, 0.6 GB at B=32, 448^2) -- at ~7 % of the ViT's flops this head is not worth a fused kernel yet.
+#include <vector>
+#include "common.h"
+#include "excel_internal.h"
+#include "../../include/excel_hip.h"
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct excel_decoder {
+    excel_decoder_config cfg;
+    std::vector<excel_fuse_layer_weights> fuse;
+    std::vector<excel_decoder_block_weights> blocks;
+    excel_decoder_weights w;
+};
+
+// in-place softmax over rows of length P stored with pitch Pp (pad columns are zeroed: they are the K tail of P.V)
+__global__ __launch_bounds__(256) void dec_row_softmax_kernel(float* __restrict__ s, long long rows, int P, int Pp) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float* r = s + row * Pp;
+    float m = -INFINITY;
+    for (int i = lane; i < P; i += 64) m = fmaxf(m, r[i]);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int i = lane; i < P; i += 64) sum += expf(r[i] - m);
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    for (int i = lane; i < Pp; i += 64) r[i] = i < P ? expf(r[i] - m) * inv : 0.f;
+}
+
+// [B, R, Cc] (pitch ld) -> [B, Cc, R]   (token-major -> channel-major maps)
+__global__ __launch_bounds__(256) void dec_transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cc, int ld) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + tx;
+        tile[j][tx] = (r < R && c < Cc) ? in[((long long)b * R + r) * ld + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + tx;
+        if (c < Cc && r < R) out[((long long)b * Cc + c) * R + r] = tile[tx][j];
+    }
+}
+
+static GemmArgs ga0(const float* A, const float* B, float* C, const float* bias, const float* res, int M, int N, int K, int lda, int ldb,
+                    int ldc, int ldr, int act) {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.B = B; g.C = C; g.bias = bias; g.res = res;
+    g.M = M; g.N = N; g.K = K; g.Kld = (K + 3) / 4 * 4;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
+    g.act = act; g.out_mode = GEMM_OUT_PLAIN; g.alpha = 1.f; g.zdiv = 1;
+    return g;
+}
+
+struct DecWs {
+    float *h1, *cat, *x, *y, *qkv, *s, *ao, *hb, *segt;
+    int Pp, ncp;
+    size_t total;
+};
+
+static DecWs dec_ws_layout(const excel_decoder_config& c, int B, int g, char* base) {
+    DecWs w;
+    const int P = g * g, E = c.embed;
+    const size_t M = (size_t)B * P;
+    w.Pp = (P + 3) / 4 * 4;
+    w.ncp = (c.num_classes + 3) / 4 * 4;
+    size_t off = 0;
+    auto take = [&](size_t floats) { float* p = (float*)(base + off); off += align_up(floats * sizeof(float), 256); return p; };
+    w.h1 = take(M * E);
+    w.cat = take(M * (size_t)c.vit_layers * E);
+    w.x = take(M * E);
+    w.y = take(M * E);
+    w.qkv = take(M * 3 * E);
+    w.s = take((size_t)B * c.heads * P * w.Pp);
+    w.ao = take(M * E);
+    w.hb = take(M * 4 * E);
+    w.segt = take(M * w.ncp);
+    w.total = off;
+    return w;
+}
+
+extern "C" int excel_decoder_create(const excel_decoder_config* cfg, const excel_decoder_weights* w, excel_decoder_t* out) {
+    EXCEL_CHECK_ARG(cfg && w && out && w->fuse && w->blocks, "excel_decoder_create: null argument");
+    EXCEL_CHECK_ARG(cfg->vit_layers >= 1 && cfg->dec_layers >= 0 && cfg->heads >= 1 && cfg->embed % cfg->heads == 0 &&
+                        (cfg->embed / cfg->heads) % 4 == 0 && cfg->vit_width % 4 == 0 && cfg->num_classes >= 1,
+                    "excel_decoder_create: embed must split into heads of a multiple of 4, vit_width %% 4 == 0");
+    excel_decoder* h = new excel_decoder();
+    h->cfg = *cfg;
+    h->w = *w;
+    h->fuse.assign(w->fuse, w->fuse + cfg->vit_layers);
+    h->blocks.assign(w->blocks, w->blocks + cfg->dec_layers);
+    h->w.fuse = h->fuse.data();
+    h->w.blocks = h->blocks.data();
+    *out = h;
+    return EXCEL_OK;
+}
+
+extern "C" void excel_decoder_destroy(excel_decoder_t h) { delete h; }
+
+extern "C" size_t excel_decoder_workspace_bytes(excel_decoder_t h, int B, int g) {
+    if (!h || B <= 0 || g <= 0) return 0;
+    return dec_ws_layout(h->cfg, B, g, nullptr).total;
+}
+
+#define TRYD(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
+
+extern "C" int excel_decoder_forward(excel_decoder_t h, const float* all_feats, int B, int g, void* workspace, size_t workspace_bytes,
+                                     float* attn_fts_out, float* seg_out, void* stream) {
+    EXCEL_CHECK_ARG(h && all_feats && workspace && B > 0 && g > 0, "excel_decoder_forward: bad argument");
+    const excel_decoder_config& c = h->cfg;
+    const int P = g * g, N = P + 1, D = c.vit_width, E = c.embed, L = c.vit_layers, H = c.heads, hd = E / H, nc = c.num_classes;
+    const int M = B * P;
+    hipStream_t st = (hipStream_t)stream;
+    DecWs ws = dec_ws_layout(c, B, g, (char*)workspace);
+    EXCEL_CHECK_ARG(workspace_bytes >= ws.total, "excel_decoder_forward: workspace too small (%zu < %zu)", workspace_bytes, ws.total);
+
+    // ---- SegFormerHead: per ViT layer Linear -> ReLU -> Linear on the patch tokens (cls row skipped), channel concat, 1x1 fuse
+    for (int l = 0; l < L; ++l) {
+        const excel_fuse_layer_weights& fw = h->fuse[l];
+        GemmArgs a = ga0(all_feats + ((size_t)l * B * N + 1) * D, fw.proj_w, ws.h1, fw.proj_b, nullptr, P, E, D, D, D, E, 0, GEMM_ACT_RELU);
+        a.sA = (long long)N * D; a.sC = (long long)P * E;                       // one image per batch entry: rows 1..P of [N,D]
+        TRYD(excel_launch_gemm(a, true, B, st));                                // segformer_head.py:23-24
+        GemmArgs b2 = ga0(ws.h1, fw.proj2_w, ws.cat + (size_t)l * E, fw.proj2_b, nullptr, M, E, E, E, E, L * E, 0, GEMM_ACT_NONE);
+        TRYD(excel_launch_gemm(b2, true, 1, st));                               // :25, written at channel offset l*E (:73)
+    }
+    GemmArgs fz = ga0(ws.cat, h->w.fuse_w, ws.x, h->w.fuse_b, nullptr, M, E, L * E, L * E, L * E, E, 0, GEMM_ACT_NONE);
+    TRYD(excel_launch_gemm(fz, true, 1, st));                                   // :74 (dropout inactive in eval)
+    if (attn_fts_out) {
+        hipLaunchKernelGGL(dec_transpose_kernel, dim3(cdiv(P, 32), cdiv(E, 32), B), dim3(256), 0, st, ws.x, attn_fts_out, P, E, E);
+        EXCEL_CHECK_LAUNCH("decoder/attn_fts");
+    }
+    if (!seg_out) return EXCEL_OK;
+
+    // ---- DecoderTransformer: pre-LN residual blocks (TransDecoder.py:78-83), tokens [B*P, E]
+    const float scale = 1.f / sqrtf((float)hd);
+    for (int l = 0; l < c.dec_layers; ++l) {
+        const excel_decoder_block_weights& bw = h->blocks[l];
+        TRYD(excel_launch_layernorm(ws.x, nullptr, 1, bw.ln1_w, bw.ln1_b, ws.y, M, E, 1e-5f, st));
+        GemmArgs q = ga0(ws.y, bw.in_proj_w, ws.qkv, bw.in_proj_b, nullptr, M, 3 * E, E, E, E, 3 * E, 0, GEMM_ACT_NONE);
+        q.out_mode = GEMM_OUT_QKV_HEADMAJOR; q.tokN = P; q.heads = H; q.hd = hd;                 // -> [B,3,H,P,hd]
+        TRYD(excel_launch_gemm(q, true, 1, st));
+        // scores[b,h] = scale * q k^T   (batched NT over (b,h))
+        GemmArgs sc = ga0(ws.qkv, ws.qkv + (size_t)H * P * hd, ws.s, nullptr, nullptr, P, P, hd, hd, hd, ws.Pp, 0, GEMM_ACT_NONE);
+        sc.alpha = scale; sc.zdiv = H;
+        sc.sA = sc.sB = (long long)3 * H * P * hd; sc.sA2 = sc.sB2 = (long long)P * hd;
+        sc.sC = (long long)H * P * ws.Pp; sc.sC2 = (long long)P * ws.Pp;
+        TRYD(excel_launch_gemm(sc, true, B * H, st));
+        hipLaunchKernelGGL(dec_row_softmax_kernel, dim3((unsigned)cdivl((long long)B * H * P, 4)), dim3(256), 0, st, ws.s, (long long)B * H * P,
+                           P, ws.Pp);
+        EXCEL_CHECK_LAUNCH("decoder/softmax");
+        // out[b, :, h*hd:(h+1)*hd] = P[b,h] . v[b,h]   (batched NN, heads merged through the column offset)
+        GemmArgs pv = ga0(ws.s, ws.qkv + (size_t)2 * H * P * hd, ws.ao, nullptr, nullptr, P, hd, P, ws.Pp, hd, E, 0, GEMM_ACT_NONE);
+        pv.Kld = ws.Pp; pv.zdiv = H;
+        pv.sA = (long long)H * P * ws.Pp; pv.sA2 = (long long)P * ws.Pp;
+        pv.sB = (long long)3 * H * P * hd; pv.sB2 = (long long)P * hd;
+        pv.sC = (long long)P * E; pv.sC2 = hd;
+        TRYD(excel_launch_gemm(pv, false, B * H, st));
+        GemmArgs op = ga0(ws.ao, bw.out_proj_w, ws.x, bw.out_proj_b, ws.x, M, E, E, E, E, E, E, GEMM_ACT_NONE);       // x += out_proj(.)
+        TRYD(excel_launch_gemm(op, true, 1, st));
+        TRYD(excel_launch_layernorm(ws.x, nullptr, 1, bw.ln2_w, bw.ln2_b, ws.y, M, E, 1e-5f, st));
+        GemmArgs f1 = ga0(ws.y, bw.fc1_w, ws.hb, bw.fc1_b, nullptr, M, 4 * E, E, E, E, 4 * E, 0, GEMM_ACT_QUICKGELU);
+        TRYD(excel_launch_gemm(f1, true, 1, st));
+        GemmArgs f2 = ga0(ws.hb, bw.fc2_w, ws.x, bw.fc2_b, ws.x, M, E, 4 * E, 4 * E, 4 * E, E, E, GEMM_ACT_NONE);      // x += mlp(ln_2(x))
+        TRYD(excel_launch_gemm(f2, true, 1, st));
+    }
+    GemmArgs lp = ga0(ws.x, h->w.pred_w, ws.segt, h->w.pred_b, nullptr, M, nc, E, E, E, ws.ncp, 0, GEMM_ACT_NONE);   // linear_pred (:122)
+    TRYD(excel_launch_gemm(lp, true, 1, st));
+    hipLaunchKernelGGL(dec_transpose_kernel, dim3(cdiv(P, 32), cdiv(nc, 32), B), dim3(256), 0, st, ws.segt, seg_out, P, nc, ws.ncp);
+    EXCEL_CHECK_LAUNCH("decoder/seg");
+    return EXCEL_OK;
+}

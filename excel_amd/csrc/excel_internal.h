@@ -2,7 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-enum { GEMM_ACT_NONE = 0, GEMM_ACT_QUICKGELU = 1 };
+enum { GEMM_ACT_NONE = 0, GEMM_ACT_QUICKGELU = 1, GEMM_ACT_RELU = 2 };
 enum { GEMM_OUT_PLAIN = 0, GEMM_OUT_QKV_HEADMAJOR = 1, GEMM_OUT_SPLIT_BF16 = 2 };
 
 struct GemmArgs {
@@ -85,6 +85,8 @@ int excel_launch_bilinear_resize(const float* in, float* out, long long planes, 
 int excel_launch_flip_max_normalize(const float* attr, float* out, int B, int g, int F, hipStream_t st);
 int excel_launch_lam_scale_accumulate(const float* maps, float* acc, int B, int g, int F, int H, int W, int init, hipStream_t st);
 int excel_launch_plane_minmax_normalize(float* lam, long long planes, long long HW, hipStream_t st);
+int excel_launch_seg_scale_accumulate(const float* segs, float* acc, int B, int nc, int h, int w, int H, int W, int flip_mean, int init,
+                                      float scale, hipStream_t st);
 // LVC side (lvc.hip)
 size_t excel_feature_affinity_ws_bytes(int B, int C, int P);
 int excel_launch_feature_affinity(const float* feats, int B, int C, int P, float beta, float gamma, int mode, float* out, void* ws,

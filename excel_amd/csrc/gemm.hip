@@ -170,6 +170,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
                 if (row >= p.M) continue;
                 float v = acc[i][j][e] * p.alpha + bv;
                 if (p.act == GEMM_ACT_QUICKGELU) v = v * (1.f / (1.f + __expf(-1.702f * v)));
+                else if (p.act == GEMM_ACT_RELU) v = fmaxf(v, 0.f);
                 if (res) v += res[(long long)row * p.ldr + col];
                 if (p.out_mode == GEMM_OUT_SPLIT_BF16) {
                     // split-bf16 output [rows][2][ldc]: plane width ldc, z2 offsets columns (in bf16 elements)

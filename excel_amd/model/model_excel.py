@@ -1,8 +1,9 @@
 """ExCEL_model: the drop-in boundary of the hot path (mirror of model/model_excel.py:16-78).
 
-Constructor signature and forward contract follow the reference; the learned decoder head
-(SegFormerHead + DecoderTransformer, :28-30, :61-76) is SURVEY 8(f) "next": in training-free mode its outputs
-are ignored by the caller (tools/infer_lam.py:79,92), so `seg`, `attn_fts` and `attn_pred` are returned as None.
+Constructor signature and forward contract follow the reference.  The decoder head (SegFormerHead + DecoderTransformer,
+:28-30, :60-76) is inference-only here: give its trained weights (`decoder_state_dict`, keys "decoder_fts_fuse.*" /
+"decoder.*" as in the reference model's state_dict) and forward returns `seg`, `attn_fts` and `attn_pred`; without
+them (training-free mode ignores all three, tools/infer_lam.py:79,92) they are None.
 """
 import torch
 
@@ -13,7 +14,8 @@ from .load_attr import attr_aggregate
 class ExCEL_model:
     def __init__(self, clip_model=None, embedding_dim=256, in_channels=512, dataset_name="pascal_voc",
                  num_classes=21, num_atrr_clusters=112, json_file=None, img_size=320, mode="train", device="cuda",
-                 state_dict=None, text_features=None, attr_bank=None, vit_cfg=None, text_attr=None, gemm_mode=None):
+                 state_dict=None, text_features=None, attr_bank=None, vit_cfg=None, text_attr=None, gemm_mode=None,
+                 decoder_state_dict=None, decoder_heads=8):
         """Extra keyword arguments (no network here): `state_dict` = CLIP visual weights, `text_features` [T,512] =
         output of encode_text_with_prompt_ensemble (clip/clip.py:252-269, one-time, out of scope),
         `attr_bank` [512,K] overrides the bank file, `vit_cfg` overrides the ViT-B/16 shape, `gemm_mode` = "bf16x3"
@@ -36,6 +38,19 @@ class ExCEL_model:
             self.text_attr, self.attr_flag = attr_aggregate(self.integral_text_features, dataset_name, num_classes - 1,
                                                             num_atrr_clusters, json_file, bank=attr_bank, device=device)   # :34
         self._text_rows = self.text_attr.permute(1, 0).contiguous()     # [T,C] view the CAM kernel consumes (:58)
+        self.decoder_fts_fuse = self.decoder = self._dec = None
+        if decoder_state_dict is not None:
+            from .decoder.TransDecoder import DecoderTransformer
+            from .segformer_head import SegFormerHead
+            fuse_sd = {k[len("decoder_fts_fuse."):]: v for k, v in decoder_state_dict.items() if k.startswith("decoder_fts_fuse.")}
+            dec_sd = {k[len("decoder."):]: v for k, v in decoder_state_dict.items() if k.startswith("decoder.")}
+            n_fuse = sum(1 for k in fuse_sd if k.endswith(".proj.weight"))
+            n_dec = sum(1 for k in dec_sd if k.endswith(".ln_1.weight"))
+            self.decoder_fts_fuse = SegFormerHead(in_channels=in_channels, embedding_dim=embedding_dim, num_classes=num_classes,
+                                                  index=n_fuse).load_state_dict(fuse_sd)                               # :28-29
+            self.decoder = DecoderTransformer(width=embedding_dim, layers=n_dec, heads=decoder_heads,
+                                              output_dim=num_classes).load_state_dict(dec_sd)                      # :30
+            self._dec = ops.DecoderHandle(fuse_sd, dec_sd, heads=decoder_heads, device=device)
 
     def eval(self):
         return self
@@ -62,17 +77,22 @@ class ExCEL_model:
         if ex_feats is not None:
             image_features, _, _ = clip.generate_clip_fts(img, self.encoder, return_weights=True, ex_feats=ex_feats)       # :51
             return ops.clip_feature_surgery(image_features, self._text_rows, num_fg=self.num_classes - 1, want_full=False)[1]   # :52
-        want_feats = want_feats or self.feature_head is not None
+        want_feats = want_feats or self.feature_head is not None or self._dec is not None
+        # the decoder consumes the list exactly as the reference stacks it (in-place aliasing quirk, include/excel_hip.h)
         image_features, attn_weights, all_feats = clip.generate_clip_fts(img, self.encoder, return_weights=True,
-                                                                         n_attn_out=n_attn_out, want_feats=want_feats)   # :57
+                                                                         n_attn_out=n_attn_out, want_feats=want_feats,
+                                                                         feats_as_reference=self._dec is not None)   # :57
         _, attr_maps_raw = ops.clip_feature_surgery(image_features, self._text_rows, num_fg=self.num_classes - 1,
                                                     want_full=False)                                                    # :58
         self.last_image_features = image_features
         self.last_all_feats = all_feats
-        attn_fts = attn_pred = None
-        if self.feature_head is not None:
+        seg = attn_fts = attn_pred = None
+        if self._dec is not None:
+            attn_fts, seg = self._dec.forward(all_feats)                                                                # :60-68
+            attn_pred = self.attn_pred_from(attn_fts)                                                                   # :70-76
+        elif self.feature_head is not None:
             attn_fts = self.feature_head(all_feats)                                                                     # :60-66
             attn_pred = self.attn_pred_from(attn_fts)                                                                   # :70-76
-        return None, attn_fts, attr_maps_raw, attn_weights, attn_pred
+        return seg, attn_fts, attr_maps_raw, attn_weights, attn_pred
 
     __call__ = forward

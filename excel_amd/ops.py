@@ -164,9 +164,11 @@ class VitHandle:
             ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=self.device)
         return ws, need
 
-    def forward(self, imgs, want_w_aff=True, aff_layers=6, n_attn_out=0, want_feats=False, want_raw=False, ex_attn=None):
+    def forward(self, imgs, want_w_aff=True, aff_layers=6, n_attn_out=0, want_feats=False, want_raw=False, ex_attn=None,
+                feats_as_reference=False):
         """-> dict(image_features [B,N,C], w_aff [B,P,P]|None, attn [n,B,N,N]|None, feats [L,B,N,D]|None, x_raw|None)
-        ex_attn [B,P,P]: LVC cue added to every head of every surgery block (clip_surgery_model.py:127-141)."""
+        ex_attn [B,P,P]: LVC cue added to every head of every surgery block (clip_surgery_model.py:127-141).
+        feats_as_reference: `feats` as the reference's decoder receives them (in-place aliasing quirk, include/excel_hip.h)."""
         imgs = f32c(imgs)
         B, _, S, S2 = imgs.shape
         assert S == S2
@@ -185,8 +187,93 @@ class VitHandle:
             if tuple(ex_attn.shape) != (B, N - 1, N - 1):
                 raise ValueError(f"ex_attn must be [B,P,P] = {(B, N - 1, N - 1)}, got {tuple(ex_attn.shape)}")
         check(lib().excel_vit_forward_ex(self._h, _p(imgs), B, S, _p(ws, torch.uint8), need, _p(f), _p(raw), _p(w_aff),
-                                         aff_layers, _p(attn), n_attn_out, _p(feats), _p(ex_attn), _stream()), "excel_vit_forward")
+                                         aff_layers, _p(attn), n_attn_out, _p(feats), _p(ex_attn), 1 if feats_as_reference else 0, _stream()),
+              "excel_vit_forward")
         return dict(image_features=f, w_aff=w_aff, attn=attn, feats=feats, x_raw=raw)
+
+
+class DecoderHandle:
+    """Device copies of the decoder head's weights + the C handle (SegFormerHead fuse: model/segformer_head.py:47-77;
+    DecoderTransformer: model/decoder/TransDecoder.py:105-124).  `fuse_sd` / `dec_sd` use the reference modules' state_dict keys."""
+
+    def __init__(self, fuse_sd, dec_sd, heads=8, device="cuda"):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("excel_amd.DecoderHandle needs a GPU device: the HIP library is the only compute path")
+        g = lambda sd, k: f32c(torch.as_tensor(sd[k])).to(self.device)
+        self.t = {}
+        L = 0
+        while f"linears_modulelist.{L}.proj.weight" in fuse_sd:
+            L += 1
+        nl = 0
+        while f"transformer.resblocks.{nl}.ln_1.weight" in dec_sd:
+            nl += 1
+        E, D = fuse_sd["linears_modulelist.0.proj.weight"].shape
+        nc = dec_sd["linear_pred.weight"].shape[0]
+        self.cfg = dict(vit_layers=L, vit_width=int(D), embed=int(E), dec_layers=nl, heads=heads, num_classes=int(nc))
+        self.fuse = (_lib.FuseLayerWeights * L)()
+        for l in range(L):
+            for f, k in (("proj_w", "proj.weight"), ("proj_b", "proj.bias"), ("proj2_w", "proj_2.weight"), ("proj2_b", "proj_2.bias")):
+                t = self.t[f"fuse{l}.{f}"] = g(fuse_sd, f"linears_modulelist.{l}.{k}")
+                setattr(self.fuse[l], f, t.data_ptr())
+        self.blocks = (_lib.DecoderBlockWeights * max(nl, 1))()
+        names = {"ln1_w": "ln_1.weight", "ln1_b": "ln_1.bias", "in_proj_w": "attn.in_proj_weight", "in_proj_b": "attn.in_proj_bias",
+                 "out_proj_w": "attn.out_proj.weight", "out_proj_b": "attn.out_proj.bias", "ln2_w": "ln_2.weight", "ln2_b": "ln_2.bias",
+                 "fc1_w": "mlp.c_fc.weight", "fc1_b": "mlp.c_fc.bias", "fc2_w": "mlp.c_proj.weight", "fc2_b": "mlp.c_proj.bias"}
+        for l in range(nl):
+            for f, k in names.items():
+                t = self.t[f"blk{l}.{f}"] = g(dec_sd, f"transformer.resblocks.{l}.{k}")
+                setattr(self.blocks[l], f, t.data_ptr())
+        w = _lib.DecoderWeights()
+        w.fuse, w.blocks = self.fuse, self.blocks
+        for f, (sd, k) in {"fuse_w": (fuse_sd, "linear_fuse.weight"), "fuse_b": (fuse_sd, "linear_fuse.bias"),
+                           "pred_w": (dec_sd, "linear_pred.weight"), "pred_b": (dec_sd, "linear_pred.bias")}.items():
+            t = self.t[f] = g(sd, k).reshape(sd[k].shape[0], -1).contiguous() if f.endswith("_w") else g(sd, k)
+            setattr(w, f, t.data_ptr())
+        cfg = _lib.DecoderConfig(L, int(D), int(E), nl, heads, int(nc))
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib().excel_decoder_create(C.byref(cfg), C.byref(w), C.byref(self._h)), "excel_decoder_create")
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().excel_decoder_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def forward(self, all_feats, want_seg=True):
+        """all_feats [L,B,N,D] -> (attn_fts [B,E,g,g], seg [B,nc,g,g] | None)"""
+        all_feats = f32c(all_feats)
+        L, B, N, D = all_feats.shape
+        c = self.cfg
+        if L != c["vit_layers"] or D != c["vit_width"]:
+            raise ValueError(f"all_feats must be [{c['vit_layers']},B,N,{c['vit_width']}], got {tuple(all_feats.shape)}")
+        g = int(round((N - 1) ** 0.5))
+        if g * g + 1 != N:
+            raise ValueError("all_feats must hold cls + a square grid of patch tokens")
+        dev = all_feats.device
+        fts = torch.empty((B, c["embed"], g, g), dtype=torch.float32, device=dev)
+        seg = torch.empty((B, c["num_classes"], g, g), dtype=torch.float32, device=dev) if want_seg else None
+        need = lib().excel_decoder_workspace_bytes(self._h, B, g)
+        ws = _ws(need, dev)
+        check(lib().excel_decoder_forward(self._h, _p(all_feats), B, g, _p(ws, torch.uint8), need, _p(fts), _p(seg), _stream()),
+              "excel_decoder_forward")
+        return fts, seg
+
+
+def seg_scale_accumulate(segs, acc, H, W, flip_mean, init, scale=1.0):
+    """tools/infer_seg_voc.py:66-82 for one scale: segs [2B,nc,h,w] -> acc [B,nc,H,W] (allocated when None)."""
+    segs = f32c(segs)
+    B2, nc, h, w = segs.shape
+    B = B2 // 2
+    if acc is None:
+        acc = torch.empty((B, nc, H, W), dtype=torch.float32, device=segs.device)
+        init = True
+    check(lib().excel_seg_scale_accumulate(_p(segs), _p(acc), B, nc, h, w, H, W, 1 if flip_mean else 0, 1 if init else 0, float(scale),
+                                           _stream()), "excel_seg_scale_accumulate")
+    return acc
 
 
 # ------------------------------------------------------------------ CAM

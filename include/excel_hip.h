@@ -106,10 +106,15 @@ int excel_vit_forward(excel_vit_t h, const float* img, int B, int S, void* works
 
 /* Same, with the LVC cue of Attention.forward's `ex_feats` branch (clip/clip_surgery_model.py:127-141):
  *   ex_attn [B,P,P] (= excel_feature_affinity(ex_feats, mode 1)) is added to attn[:, :, 1:, 1:] of EVERY head of every
- *   surgery block before the head sum; NULL = the ex_feats=None branch (identical to excel_vit_forward). */
+ *   surgery block before the head sum; NULL = the ex_feats=None branch (identical to excel_vit_forward).
+ *   flags: EXCEL_VIT_FEATS_AS_REFERENCE = feats_out holds what the reference's decoder receives: the reference stacks
+ *          its per-block list after the forward, and in-place updates (clip_surgery_model.py:317,319,329,442) have by then
+ *          rewritten the entries of the last single-path block (= final new-path x incl. the cls swap) and of every
+ *          surgery block but the last (= x_ori + the next block's attention residual).  Default: clean block outputs. */
+#define EXCEL_VIT_FEATS_AS_REFERENCE 1
 int excel_vit_forward_ex(excel_vit_t h, const float* img, int B, int S, void* workspace, size_t workspace_bytes,
                          float* image_features, float* x_raw, float* w_aff, int aff_layers,
-                         float* attn_out, int n_attn_out, float* feats_out, const float* ex_attn, void* stream);
+                         float* attn_out, int n_attn_out, float* feats_out, const float* ex_attn, int flags, void* stream);
 
 /* Token affinity of decoder features, shared by attn_pred (model/model_excel.py:70-76) and the ex_feats branch
  * (clip/clip_surgery_model.py:128-137):  feats [B,C,P] -> F.normalize over C -> sim = f^T f [B,P,P]
@@ -119,6 +124,39 @@ int excel_vit_forward_ex(excel_vit_t h, const float* img, int B, int S, void* wo
 size_t excel_feature_affinity_workspace_bytes(int B, int C, int P);
 int excel_feature_affinity(const float* feats, int B, int C, int P, float beta, float gamma, int mode, float* out,
                            void* workspace, void* stream);
+
+/* ------------------------------------------------------------------ decoder head
+ * SegFormerHead fuse (model/segformer_head.py:47-77: per ViT layer Linear(D,E) -> ReLU -> Linear(E,E) on the patch
+ * tokens, channel concat, 1x1 conv L*E -> E) and DecoderTransformer (model/decoder/TransDecoder.py:105-124: dec_layers
+ * pre-LN blocks of MHA(heads) + QuickGELU MLP(4E), then the 1x1 linear_pred E -> num_classes), exact fp32.
+ * Weight pointers are device pointers in the reference modules' state_dict layout (Linear: [out,in]; 1x1 conv:
+ * [out,in,1,1] == [out,in]) and must stay valid for the life of the handle.                                    */
+typedef struct excel_decoder* excel_decoder_t;
+typedef struct { int vit_layers, vit_width, embed, dec_layers, heads, num_classes; } excel_decoder_config;
+typedef struct { const float *proj_w, *proj_b, *proj2_w, *proj2_b; } excel_fuse_layer_weights;
+typedef struct {
+    const float *ln1_w, *ln1_b, *in_proj_w, *in_proj_b, *out_proj_w, *out_proj_b, *ln2_w, *ln2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+} excel_decoder_block_weights;
+typedef struct {
+    const excel_fuse_layer_weights* fuse;          /* [vit_layers] */
+    const float *fuse_w, *fuse_b;                  /* linear_fuse [E, L*E], [E] */
+    const excel_decoder_block_weights* blocks;     /* [dec_layers] */
+    const float *pred_w, *pred_b;                  /* linear_pred [num_classes, E], [num_classes] */
+} excel_decoder_weights;
+int excel_decoder_create(const excel_decoder_config* cfg, const excel_decoder_weights* w, excel_decoder_t* out);
+void excel_decoder_destroy(excel_decoder_t h);
+size_t excel_decoder_workspace_bytes(excel_decoder_t h, int B, int g);
+/* all_feats [L,B,N,D] (excel_vit_forward's feats_out; N = g*g+1, the cls row is skipped as model/model_excel.py:60 does)
+ *   -> attn_fts_out [B,E,g,g] (optional; model_excel.py:64-65) and seg_out [B,num_classes,g,g] (optional; :68).           */
+int excel_decoder_forward(excel_decoder_t h, const float* all_feats, int B, int g, void* workspace, size_t workspace_bytes,
+                          float* attn_fts_out, float* seg_out, void* stream);
+
+/* Multi-scale / flip fuse of the segmentation logits (tools/infer_seg_voc.py:66-82): segs [2B,nc,h,w] of one scale (second
+ * half from the x-flipped inputs) -> bilinear (align_corners=False) to (H,W) -> flip_mean ? (seg + flip_x(seg_flipped))/2 : seg
+ * (scale 1.0 uses the un-flipped half alone, :69) -> acc [B,nc,H,W] = ((init ? 0 : acc) + .) * scale (mean over scales: pass
+ * 1/n_scales with the last scale, 1 otherwise). */
+int excel_seg_scale_accumulate(const float* segs, float* acc, int B, int nc, int h, int w, int H, int W, int flip_mean, int init,
+                               float scale, void* stream);
 
 /* ------------------------------------------------------------------ patch-text CAM */
 

@@ -189,13 +189,18 @@ def patch_embed(img, w, cfg):
     return (patches @ w["conv1.weight"].reshape(cfg.width, -1).T).astype(np.float32)
 
 
-def vit_forward_single(img, w, cfg: VitConfig, pos=None, ex_attn=None):
+def vit_forward_single(img, w, cfg: VitConfig, pos=None, ex_attn=None, aliased_feats=False):
     """VisionTransformer.forward :419-448 for ONE image [3,S,S].
 
     Returns x [N,out_dim], attn_weights list(L) of [N,N], all_feats list(L) of [N,D]
-    (all_feats are the *clean* per-block original-path outputs: the reference's
-    in-place aliasing of all_feats[6..10] only touches the
-    out-of-scope decoder input and is deliberately not reproduced).
+    (all_feats are the *clean* per-block original-path outputs by default.  aliased_feats=True reproduces
+    what the reference's decoder really receives: the per-block list holds VIEWS that later
+    in-place updates mutate before clip.py:356 stacks them --
+      * the last single-path block's entry aliases `x`, which every surgery block updates with `x += x_res`
+        (:319,:329) and the cls swap overwrites (:442): it ends up as the FINAL new-path x;
+      * a surgery block's entry aliases its `x_ori`, which the NEXT block updates with `x_ori += x_ori_res`
+        (:317) before re-binding the name (:318): it ends up as x_ori + the next block's attention residual;
+      * the last block's entry is clean.)
     """
     L = cfg.layers
     first_surgery = L - cfg.n_surgery
@@ -222,6 +227,8 @@ def vit_forward_single(img, w, cfg: VitConfig, pos=None, ex_attn=None):
             x_res, x_ori_res, a = surgery_attention(
                 layer_norm(src, w[p + "ln_1.weight"], w[p + "ln_1.bias"]), p, w, cfg, ex_attn)
             x_ori = src + x_ori_res                                  # :317 / :326
+            if aliased_feats and i > first_surgery:
+                all_feats[i - 1] = x_ori.astype(np.float32).copy()   # Q4: the previous entry saw this in-place add
             x_ori = x_ori + mlp(layer_norm(x_ori, w[p + "ln_2.weight"], w[p + "ln_2.bias"]), p, w)
             x_ori = x_ori.astype(np.float32)
             x = (x + x_res).astype(np.float32)                       # :319 / :329  (no FFN on the new path)
@@ -231,12 +238,14 @@ def vit_forward_single(img, w, cfg: VitConfig, pos=None, ex_attn=None):
     x = x.copy()
     if x_ori is not None:
         x[0] = x_ori[0]                                              # :442
+        if aliased_feats and first_surgery >= 1:
+            all_feats[first_surgery - 1] = x.astype(np.float32).copy()   # Q4: aliases the new-path x, incl. the cls swap
     x = layer_norm(x, w["ln_post.weight"], w["ln_post.bias"])        # :445
     x = (x @ w["proj"]).astype(np.float32)                           # :446
     return x, attn_weights, all_feats
 
 
-def vit_forward(imgs, w, cfg: VitConfig, ex_feats=None):
+def vit_forward(imgs, w, cfg: VitConfig, ex_feats=None, aliased_feats=False):
     """Batched wrapper: imgs [B,3,S,S] -> x [B,N,out], attn [L,B,N,N], feats [L,B,N,D].
     ex_feats [B,C,g,g]: the LVC branch (the batch-global mean of :132 makes this a batch-level quantity)."""
     g = imgs.shape[-1] // cfg.patch
@@ -244,7 +253,7 @@ def vit_forward(imgs, w, cfg: VitConfig, ex_feats=None):
     ex = ex_attention(ex_feats) if ex_feats is not None else None
     xs, attns, feats = [], [], []
     for b in range(imgs.shape[0]):
-        x, a, f = vit_forward_single(np.asarray(imgs[b], np.float32), w, cfg, pos, None if ex is None else ex[b])
+        x, a, f = vit_forward_single(np.asarray(imgs[b], np.float32), w, cfg, pos, None if ex is None else ex[b], aliased_feats)
         xs.append(x)
         attns.append(np.stack(a, 0))
         feats.append(np.stack(f, 0))

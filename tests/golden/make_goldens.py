@@ -283,8 +283,40 @@ def gold_lvc():
          cls=cls_label, refined=torch.stack(refined, 0), cls_lst=cls_lst)
 
 
+# ---------------------------------------------------------------- 6. decoder head: SegFormerHead fuse + DecoderTransformer + attn_pred
+def gold_decoder():
+    mm, mc = types.ModuleType("mmcv"), types.ModuleType("mmcv.cnn")       # segformer_head.py:10 imports ConvModule (unused by the head)
+    mc.ConvModule = object
+    mm.cnn = mc
+    sys.modules.setdefault("mmcv", mm)
+    sys.modules.setdefault("mmcv.cnn", mc)
+    from model.segformer_head import SegFormerHead
+    from model.decoder.TransDecoder import DecoderTransformer
+    w = make_vit_weights(TINY, seed=11)
+    vit = build_ref_vit(TINY, w, feat_size=6, mode="train")
+    rs = np.random.RandomState(51)
+    imgs = rs.standard_normal((2, 3, 96, 96)).astype(np.float32)
+    # generate_clip_fts (clip/clip.py:348-358): the list is stacked AFTER the forward, i.e. with the in-place aliasing of
+    # clip_surgery_model.py:317,329,442 baked in -- this is what the decoder really sees
+    _, _, _, feats = ref_generate_clip_fts(vit, torch.from_numpy(imgs))
+    all_feats = torch.stack(feats, 0)                                      # [8,2,37,128]
+    torch.manual_seed(7)
+    fuse = SegFormerHead(in_channels=128, embedding_dim=32, num_classes=5, index=8).eval()        # model_excel.py:28-29
+    dec = DecoderTransformer(width=32, layers=3, heads=8, output_dim=5).eval()                   # :30
+    b, h, wd = 2, 96, 96
+    tok = all_feats[:, :, 1:, ...].permute(0, 1, 3, 2).reshape(8, b, 128, h // 16, wd // 16)     # :60-62
+    fts = fuse(tok)                                                        # :64
+    seg, attn_list = dec(fts)                                              # :68
+    fl = F.normalize(fts.reshape(b, 32, -1), dim=1)                        # :70-73 (re-typed: model_excel.py imports mmcv/clip)
+    ap = torch.sigmoid((fl.transpose(2, 1).bmm(fl) - torch.mean(fl.transpose(2, 1).bmm(fl)) * 1.) * 3.0)   # :74-76
+    sd = {"fuse." + k: v for k, v in fuse.state_dict().items()}
+    sd.update({"dec." + k: v for k, v in dec.state_dict().items()})
+    save("decoder_tiny.npz", seed_w=11, imgs=imgs, all_feats=all_feats, fts=fts, seg=seg, attn_pred=ap,
+         dec_attn_last=attn_list[-1], **sd)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["vit_cam", "ops", "attr", "pipeline", "lvc"]       # e.g. `make_goldens.py lvc` mints one file
+    which = sys.argv[1:] or ["vit_cam", "ops", "attr", "pipeline", "lvc", "decoder"]       # e.g. `make_goldens.py lvc` mints one file
     with torch.no_grad():
         for name in which:
             globals()["gold_" + name]()

@@ -482,3 +482,114 @@ def test_harness_optimised_lam_regime_vs_oracle(gpu, golden):
     ref_hist = oracle.evaluate.fast_hist(gt[0].flatten(), label[0].flatten(), 5)
     assert nimg == 1 and int(host(hist).sum()) == 96 * 96
     assert np.abs(host(hist) - ref_hist).sum() <= 0.002 * 96 * 96
+
+
+# ------------------------------------------------------------------ decoder head inference
+def _decoder_sd(g):
+    sd = {"decoder_fts_fuse." + k[len("fuse."):]: g[k] for k in g.files if k.startswith("fuse.")}
+    sd.update({"decoder." + k[len("dec."):]: g[k] for k in g.files if k.startswith("dec.")})
+    return sd
+
+
+def test_aliased_feats_match_reference_stack(gpu, golden):
+    """all_feats as the reference's decoder receives them (in-place aliasing) vs the reference's own stack."""
+    g = golden("decoder_tiny.npz")
+    model, _ = tiny_model(np.zeros((64, 9), np.float32) + 0.1, gemm_mode="f32")
+    r = model.encoder.visual.handle().forward(dev(g["imgs"]), want_feats=True, feats_as_reference=True)
+    for l in range(8):
+        assert maxabs(host(r["feats"])[l], g["all_feats"][l]) / float(np.abs(g["all_feats"][l]).max()) < 5e-5, l
+    clean = host(model.encoder.visual.handle().forward(dev(g["imgs"]), want_feats=True)["feats"])
+    assert maxabs(clean[-1], g["all_feats"][-1]) / float(np.abs(g["all_feats"][-1]).max()) < 5e-5      # last entry is never aliased
+    assert maxabs(clean[2], g["all_feats"][2]) / float(np.abs(g["all_feats"][2]).max()) > 1e-2
+
+
+def test_decoder_head_matches_golden(gpu, golden):
+    from excel_amd import ops
+    g = golden("decoder_tiny.npz")
+    sd = _decoder_sd(g)
+    fuse_sd = {k[len("decoder_fts_fuse."):]: v for k, v in sd.items() if k.startswith("decoder_fts_fuse.")}
+    dec_sd = {k[len("decoder."):]: v for k, v in sd.items() if k.startswith("decoder.")}
+    h = ops.DecoderHandle(fuse_sd, dec_sd, heads=8)
+    fts, seg = h.forward(dev(g["all_feats"]))
+    assert maxabs(host(fts), g["fts"]) / float(np.abs(g["fts"]).max()) < 1e-5
+    assert maxabs(host(seg), g["seg"]) / float(np.abs(g["seg"]).max()) < 2e-5
+    # a production-shaped head against the oracle: width 256, 8 heads of 32, 14x14 grid (P = 196), 21 classes (N % 4 != 0)
+    rs = np.random.RandomState(2)
+    L, B, N, D, E, nc = 3, 2, 197, 64, 256, 21
+    feats = rs.standard_normal((L, B, N, D)).astype(np.float32)
+    w = {}
+    for l in range(L):
+        w[f"fuse.linears_modulelist.{l}.proj.weight"] = (rs.standard_normal((E, D)) / 8).astype(np.float32)
+        w[f"fuse.linears_modulelist.{l}.proj.bias"] = (rs.standard_normal(E) * 0.1).astype(np.float32)
+        w[f"fuse.linears_modulelist.{l}.proj_2.weight"] = (rs.standard_normal((E, E)) / 16).astype(np.float32)
+        w[f"fuse.linears_modulelist.{l}.proj_2.bias"] = (rs.standard_normal(E) * 0.1).astype(np.float32)
+    w["fuse.linear_fuse.weight"] = (rs.standard_normal((E, L * E, 1, 1)) / 28).astype(np.float32)
+    w["fuse.linear_fuse.bias"] = (rs.standard_normal(E) * 0.1).astype(np.float32)
+    for l in range(2):
+        p = f"dec.transformer.resblocks.{l}."
+        w[p + "ln_1.weight"] = (1 + 0.1 * rs.standard_normal(E)).astype(np.float32); w[p + "ln_1.bias"] = (0.1 * rs.standard_normal(E)).astype(np.float32)
+        w[p + "ln_2.weight"] = (1 + 0.1 * rs.standard_normal(E)).astype(np.float32); w[p + "ln_2.bias"] = (0.1 * rs.standard_normal(E)).astype(np.float32)
+        w[p + "attn.in_proj_weight"] = (rs.standard_normal((3 * E, E)) / 10).astype(np.float32); w[p + "attn.in_proj_bias"] = (0.1 * rs.standard_normal(3 * E)).astype(np.float32)
+        w[p + "attn.out_proj.weight"] = (rs.standard_normal((E, E)) / 16).astype(np.float32); w[p + "attn.out_proj.bias"] = (0.1 * rs.standard_normal(E)).astype(np.float32)
+        w[p + "mlp.c_fc.weight"] = (rs.standard_normal((4 * E, E)) / 16).astype(np.float32); w[p + "mlp.c_fc.bias"] = (0.1 * rs.standard_normal(4 * E)).astype(np.float32)
+        w[p + "mlp.c_proj.weight"] = (rs.standard_normal((E, 4 * E)) / 32).astype(np.float32); w[p + "mlp.c_proj.bias"] = (0.1 * rs.standard_normal(E)).astype(np.float32)
+    w["dec.linear_pred.weight"] = (rs.standard_normal((nc, E, 1, 1)) / 16).astype(np.float32)
+    w["dec.linear_pred.bias"] = (0.1 * rs.standard_normal(nc)).astype(np.float32)
+    h2 = ops.DecoderHandle({k[5:]: v for k, v in w.items() if k.startswith("fuse.")}, {k[4:]: v for k, v in w.items() if k.startswith("dec.")}, heads=8)
+    fts2, seg2 = h2.forward(dev(feats))
+    ref_fts = oracle.decoder.segformer_fuse(feats, w)
+    ref_seg, _ = oracle.decoder.decoder_transformer(ref_fts, w, heads=8)
+    assert maxabs(host(fts2), ref_fts) / float(np.abs(ref_fts).max()) < 1e-5
+    assert maxabs(host(seg2), ref_seg) / float(np.abs(ref_seg).max()) < 2e-5
+
+
+def test_model_with_decoder_returns_reference_tuple(gpu, golden):
+    """model(img) -> (seg, attn_fts, attr_maps_raw, attn_weights, attn_pred) (model_excel.py:48-78) with trained-decoder weights."""
+    from excel_amd.model import ExCEL_model
+    g = golden("decoder_tiny.npz")
+    w = make_vit_weights(TINY, seed=int(g["seed_w"]))
+    rs = np.random.RandomState(1)
+    text = rs.standard_normal((9, 64)).astype(np.float32)
+    text /= np.linalg.norm(text, axis=1, keepdims=True)
+    model = ExCEL_model(clip_model="tiny", num_classes=5, img_size=96, mode="train", state_dict=w, vit_cfg=TINY_KW, text_attr=text.T.copy(),
+                        gemm_mode="f32", embedding_dim=32, in_channels=128, decoder_state_dict=_decoder_sd(g))
+    seg, attn_fts, attr, attn_w, attn_pred = model(dev(g["imgs"]))
+    assert maxabs(host(attn_fts), g["fts"]) / float(np.abs(g["fts"]).max()) < 5e-5
+    assert maxabs(host(seg), g["seg"]) / float(np.abs(g["seg"]).max()) < 1e-4
+    assert maxabs(host(attn_pred), g["attn_pred"]) < 1e-4
+    assert attr.shape == (2, 36, 4)
+
+
+def test_multi_scale_seg_inference_vs_oracle(gpu, golden):
+    """tools/infer_seg_voc.py:56-85 with the decoder head: resize, flip pairs, per-scale fuse, mean, label-size resize, arg-max."""
+    from excel_amd.model import ExCEL_model
+    from excel_amd.tools import infer_seg_voc
+    g = golden("decoder_tiny.npz")
+    w = make_vit_weights(TINY, seed=int(g["seed_w"]))
+    wo = oracle.vit.reload_self_attn(w, TINY, 4, "train")
+    dw = {k: g[k] for k in g.files if k.startswith(("fuse.", "dec."))}
+    text = np.eye(64, 9, dtype=np.float32)
+    model = ExCEL_model(clip_model="tiny", num_classes=5, img_size=64, mode="train", state_dict=w, vit_cfg=TINY_KW, text_attr=text,
+                        gemm_mode="f32", embedding_dim=32, in_channels=128, decoder_state_dict=_decoder_sd(g))
+    rs = np.random.RandomState(4)
+    x = rs.standard_normal((2, 3, 50, 70)).astype(np.float32)
+    gt = rs.randint(0, 5, (2, 41, 59)).astype(np.uint8)
+    scales = (1.0, 0.5, 1.5)
+    msc = host(infer_seg_voc.multi_scale_seg(model, dev(x), 64, scales))
+
+    def ref_seg(xs):
+        _, _, feats = oracle.vit.vit_forward(xs, wo, TINY, aliased_feats=True)
+        return oracle.decoder.decoder_transformer(oracle.decoder.segformer_fuse(feats, dw), dw, heads=8)[0]
+    acc = 0
+    for sc in scales:
+        S = 64 if sc == 1.0 else int(64 * sc)
+        xs = oracle.interp.bilinear_resize(x, S, S, align_corners=False)
+        segs = oracle.interp.bilinear_resize(ref_seg(np.concatenate([xs, xs[..., ::-1]], 0)), 50, 70, align_corners=False)
+        acc = acc + (segs[:2] if sc == 1.0 else (segs[:2] + segs[2:][..., ::-1]) / 2)
+    ref = acc / len(scales)
+    assert maxabs(msc, ref) / float(np.abs(ref).max()) < 1e-4
+    lab = host(infer_seg_voc.seg_labels(dev(ref.astype(np.float32)), (41, 59)))
+    ref_lab = oracle.interp.bilinear_resize(ref.astype(np.float32), 41, 59, align_corners=False).argmax(1)
+    assert np.array_equal(lab, ref_lab)
+    scores, hist = infer_seg_voc.validate_seg(model, [(dev(x), dev(gt))], 5, 64, scales)
+    assert int(host(hist).sum()) == gt.size and 0.0 <= scores["miou"] <= 1.0

@@ -151,3 +151,23 @@ def test_lvc_branch_ex_feats_and_seg_attn(golden):
                                                        caa_thre=0.79, seg_attn=g["attn_pred"][0][None])
     assert list(cls_lst) == list(g["cls_lst"])
     assert maxabs(np.stack(refined, 0), g["refined"]) < 1e-6
+
+
+def test_decoder_head_and_aliased_feats(golden):
+    """what the decoder receives (all_feats with the reference's in-place aliasing, quirk Q4), the SegFormer
+    fuse, the 3-layer decoder transformer and attn_pred, against the reference's own modules."""
+    g = golden("decoder_tiny.npz")
+    w = make_vit_weights(TINY, seed=int(g["seed_w"]))
+    w = oracle.vit.reload_self_attn(w, TINY, feat_size=6, mode="train")
+    _, _, feats = oracle.vit.vit_forward(g["imgs"], w, TINY, aliased_feats=True)
+    for l in range(TINY.layers):
+        assert relmax(feats[l], g["all_feats"][l]) < 5e-5, l
+    _, _, clean = oracle.vit.vit_forward(g["imgs"], w, TINY)
+    assert relmax(clean[2], g["all_feats"][2]) > 1e-2          # the quirk is real: entry 2 (last single-path block) differs
+    dw = {k: g[k] for k in g.files if k.startswith(("fuse.", "dec."))}
+    fts = oracle.decoder.segformer_fuse(g["all_feats"], dw)
+    assert relmax(fts, g["fts"]) < 1e-5
+    seg, attns = oracle.decoder.decoder_transformer(g["fts"], dw, heads=8)
+    assert relmax(seg, g["seg"]) < 1e-5
+    assert maxabs(attns[-1], g["dec_attn_last"]) < 1e-6
+    assert maxabs(oracle.cam.attn_pred(g["fts"]), g["attn_pred"]) < 1e-6
