@@ -39,6 +39,8 @@ def get_parser():
     p.add_argument("--resize_size", default=448, type=int)
     p.add_argument("--infer_set", default="train", type=str)
     p.add_argument("--training_free", default=True, type=_bool)
+    p.add_argument("--crf_post", default=False, type=_bool, help="write the per-image logits record of tools/infer_lam.py:116-119 (api path)")
+    p.add_argument("--logits_dir", default="./logits", type=str)
     p.add_argument("--num_classes", default=21, type=int)
     p.add_argument("--ignore_index", default=255, type=int)
     p.add_argument("--local_rank", default=int(os.environ.get("LOCAL_RANK", 0)), type=int)
@@ -102,7 +104,7 @@ def build_validation(model=None, par=None, dataset=None, indices=None, device="c
     nimg = 0
     bs = 1 if args.api_path else args.batch_size
     for s in range(0, len(indices), bs):
-        _, imgs, gts, cls = dataset.batch(indices[s:s + bs])
+        names, imgs, gts, cls = dataset.batch(indices[s:s + bs])
         inputs = torch.from_numpy(imgs).to(device, non_blocking=True)
         if inputs.shape[-2:] != (S, S):
             inputs = ops.bilinear_resize(inputs, S, S, align_corners=False)                 # :74
@@ -123,7 +125,10 @@ def build_validation(model=None, par=None, dataset=None, indices=None, device="c
                 seg_attn = None if training_free else attn_pred[i][None]                    # :91-92
                 refined, cls_lst = refine_cams_with_aff(attr_map, attn_weights[:, i], cls_labels[i], size=inputs.shape[2:],
                                                         seg_attn=seg_attn, caa_thre=0.79)   # :93
-                labels, _ = refine_cams_with_bkg_weclip(refined, inputs[i], cls_lst, par, gts.shape[-2:])   # :94
+                labels, normed = refine_cams_with_bkg_weclip(refined, inputs[i], cls_lst, par, gts.shape[-2:])   # :94
+                if getattr(args, "crf_post", False):                                         # :116-119 record for the CRF stage
+                    from ..utils import imutils
+                    imutils.save_logits(args.logits_dir, str(names[i]), normed, cls_lst)
                 hist = evaluate.hist_from_labels([gt_dev[i]], [labels[0]], args.num_classes, device, hist)
         else:
             pipe.hist = hist

@@ -1,0 +1,63 @@
+"""Host-side format helpers either side of the path: mirror of the live parts of utils/imutils.py and of the on-disk
+records tools/infer_lam.py exchanges with its CRF stage.
+
+  colormap / encode_cmap   utils/imutils.py:7-9, :32-50   (the PASCAL VOC palette: bit-interleaved class index)
+  save_logits/load_logits  tools/infer_lam.py:116-119 (writer), :203-206 (reader): np.save of the dict
+                           {"valid_lam": cams [k+1,H,W] f32, "keys_gt": present classes int64}
+  crf_keys_to_labels       tools/infer_lam.py:225-227: keys = pad(keys_gt + 1, (1, 0)); label = keys[argmax]
+  save_label_png           the colour-coded label image the reference writes with imageio (:228); PIL here
+
+Plain numpy / PIL on the host: these are file formats, not compute.  DenseCRF itself (utils/dcrf.py, pydensecrf) is not
+rebuilt (third-party CPU library, absent from this image).
+"""
+import os
+
+import numpy as np
+
+
+def colormap(N=256, normalized=False):
+    """VOC palette: colour channel bits are the class index's bits taken 3 at a time, MSB first (imutils.py:32-50)."""
+    idx = np.arange(N, dtype=np.int64)
+    cmap = np.zeros((N, 3), dtype=np.int64)
+    c = idx.copy()
+    for j in range(8):
+        for ch in range(3):
+            cmap[:, ch] |= ((c >> ch) & 1) << (7 - j)
+        c >>= 3
+    return (cmap / 255).astype(np.float32) if normalized else cmap.astype(np.uint8)
+
+
+def encode_cmap(label):
+    """label [H,W] (any integer dtype; 255 = ignore -> white-ish palette entry) -> RGB uint8 [H,W,3] (imutils.py:7-9)."""
+    return colormap()[np.asarray(label).astype(np.int16), :]
+
+
+def save_logits(logits_dir, name, valid_lam, keys_gt):
+    """tools/infer_lam.py:116-119."""
+    os.makedirs(logits_dir, exist_ok=True)
+    valid_lam = valid_lam.detach().cpu().numpy() if hasattr(valid_lam, "detach") else np.asarray(valid_lam)
+    keys_gt = keys_gt.detach().cpu().numpy() if hasattr(keys_gt, "detach") else np.asarray(keys_gt)
+    path = os.path.join(logits_dir, name + ".npy")
+    np.save(path, {"valid_lam": valid_lam, "keys_gt": keys_gt})
+    return path
+
+
+def load_logits(path):
+    """tools/infer_lam.py:203-206 -> (valid_lam, keys_gt)."""
+    d = np.load(path, allow_pickle=True).item()
+    return d["valid_lam"], d["keys_gt"]
+
+
+def crf_keys_to_labels(prob, keys_gt):
+    """tools/infer_lam.py:225-227: prob [k+1,H,W] -> uint8 labels through keys = [0, keys_gt + 1...]."""
+    pred = np.argmax(prob, axis=0)
+    keys = np.pad(np.asarray(keys_gt) + 1, (1, 0), mode="constant")
+    return keys[pred].astype(np.uint8)
+
+
+def save_label_png(path, label):
+    """Colour-coded label image (tools/infer_lam.py:228)."""
+    from PIL import Image
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    Image.fromarray(encode_cmap(np.squeeze(label)).astype(np.uint8)).save(path)
+    return path

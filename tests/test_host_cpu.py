@@ -192,3 +192,32 @@ def test_gather_hists_single_process_identity():
     h = torch.arange(9, dtype=torch.int64).reshape(3, 3)
     per_rank, total = gather_hists(h)
     assert per_rank.shape == (1, 3, 3) and torch.equal(total, h)
+
+
+def test_on_disk_formats(tmp_path):
+    """the VOC palette (known-answer entries of the published colormap), the logits record
+    tools/infer_lam.py hands to its CRF stage, and the key lookup that stage applies."""
+    from excel_amd.utils import imutils
+    cm = imutils.colormap()
+    assert cm.shape == (256, 3) and cm.dtype == np.uint8
+    known = {0: (0, 0, 0), 1: (128, 0, 0), 2: (0, 128, 0), 3: (128, 128, 0), 4: (0, 0, 128), 8: (64, 0, 0), 15: (192, 128, 128),
+             20: (0, 64, 128), 255: (224, 224, 192)}
+    for k, rgb in known.items():
+        assert tuple(int(v) for v in cm[k]) == rgb, k
+    lab = np.array([[0, 1, 255], [20, 15, 2]], np.uint8)
+    rgb = imutils.encode_cmap(lab)
+    assert rgb.shape == (2, 3, 3) and tuple(rgb[0, 2]) == (224, 224, 192)
+    rs = np.random.RandomState(0)
+    lam = rs.rand(3, 5, 7).astype(np.float32)
+    keys = np.array([4, 17], np.int64)
+    p = imutils.save_logits(str(tmp_path / "logits"), "2007_000032", lam, keys)
+    lam2, keys2 = imutils.load_logits(p)
+    assert np.array_equal(lam, lam2) and np.array_equal(keys, keys2)
+    d = np.load(p, allow_pickle=True).item()                       # exactly the reference reader's view (:203-206)
+    assert set(d) == {"valid_lam", "keys_gt"}
+    lab2 = imutils.crf_keys_to_labels(lam, keys)
+    assert set(np.unique(lab2)) <= {0, 5, 18} and lab2.dtype == np.uint8
+    png = imutils.save_label_png(str(tmp_path / "segs" / "x.png"), lab2)
+    from PIL import Image
+    back = np.asarray(Image.open(png))
+    assert np.array_equal(back, imutils.encode_cmap(lab2))
