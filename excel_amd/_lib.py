@@ -50,6 +50,15 @@ class DecoderWeights(C.Structure):
                 ("blocks", C.POINTER(DecoderBlockWeights)), ("pred_w", C.c_void_p), ("pred_b", C.c_void_p)]
 
 
+class TextConfig(C.Structure):
+    _fields_ = [(n, c_i) for n in ("vocab_size", "context_length", "width", "layers", "heads", "embed_dim")]
+
+
+class TextWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("token_embedding", "positional_embedding", "ln_final_w", "ln_final_b", "text_projection")] + \
+        [("blocks", C.POINTER(DecoderBlockWeights))]
+
+
 # name -> (restype, argtypes); mirrors include/excel_hip.h one to one
 SIGNATURES = {
     "excel_last_error": (C.c_char_p, []),
@@ -74,6 +83,11 @@ SIGNATURES = {
     "excel_decoder_destroy": (None, [C.c_void_p]),
     "excel_decoder_workspace_bytes": (c_sz, [C.c_void_p, c_i, c_i]),
     "excel_decoder_forward": (c_i, [C.c_void_p, c_f, c_i, c_i, c_f, c_sz, c_f, c_f, c_f]),
+    "excel_text_create": (c_i, [C.POINTER(TextConfig), C.POINTER(TextWeights), C.POINTER(C.c_void_p)]),
+    "excel_text_destroy": (None, [C.c_void_p]),
+    "excel_text_workspace_bytes": (c_sz, [C.c_void_p, c_i]),
+    "excel_text_encode": (c_i, [C.c_void_p, c_f, c_i, c_f, c_f, c_sz, c_f]),
+    "excel_prompt_ensemble": (c_i, [c_f, c_i, c_i, c_f, c_f]),
     "excel_seg_scale_accumulate": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, C.c_float, c_f]),
     "excel_cam_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "excel_clip_feature_surgery": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, C.c_float, c_f, c_f, c_f, c_f]),

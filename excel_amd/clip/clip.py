@@ -62,13 +62,61 @@ def clip_feature_surgery(image_features, text_features, redundant_feats=None, t=
 
 def load(name, device="cuda", state_dict=None, width=768, layers=12, heads=12, patch=16, output_dim=512,
          input_resolution=224, gemm_mode=None):
-    """clip.load("ExCEL_ViT-B/16") counterpart: builds the visual tower from a state_dict whose keys follow the
-    reference ("visual.conv1.weight" ... or without the "visual." prefix).  Returns (model, None)."""
+    """clip.load("ExCEL_ViT-B/16") counterpart (clip/clip.py:104-154).  `state_dict`: the CLIP checkpoint's state_dict
+    ("visual.conv1.weight" ... or a bare visual-tower dict); alternatively `name` may be the path of a local CLIP
+    TorchScript/state-dict file (there is no network: nothing is downloaded).  The text tower is kept when its keys are
+    present.  Returns (model, None)."""
     if state_dict is None:
-        raise RuntimeError("excel_amd.clip.load needs state_dict= (no network: the CLIP checkpoint cannot be downloaded)")
-    sd = {}
+        import os
+        if isinstance(name, str) and os.path.isfile(name):
+            try:
+                state_dict = torch.jit.load(name, map_location="cpu").state_dict()          # :138-141 the published archives
+            except RuntimeError:
+                state_dict = torch.load(name, map_location="cpu")                           # :147 plain state_dict
+        else:
+            raise RuntimeError("excel_amd.clip.load needs state_dict= or a local checkpoint path (no network: nothing is downloaded)")
+    sd, text_sd = {}, {}
+    has_prefix = any(k.startswith("visual.") for k in state_dict)
     for k, v in state_dict.items():
-        sd[k[len("visual."):] if k.startswith("visual.") else k] = v
+        if k.startswith("visual."):
+            sd[k[len("visual."):]] = v
+        elif has_prefix and (k.startswith(("transformer.", "token_embedding.", "ln_final.")) or k in ("positional_embedding", "text_projection")):
+            text_sd[k] = v
+        elif not has_prefix:
+            sd[k] = v
     vis = VisionTransformer(input_resolution, patch, width, layers, heads, output_dim, state_dict=sd, device=device,
                             gemm_mode=gemm_mode)
-    return ExCEL_CLIP(vis), None
+    return ExCEL_CLIP(vis, text_sd if "text_projection" in text_sd else None), None
+
+
+def tokenize(texts, context_length=77, truncate=False, tokenizer=None, vocab_path=None):
+    """clip/clip.py:206-248 -> int32 tensor [n, context_length].  Needs CLIP's merges file (excel_amd/clip/bpe.py)."""
+    from . import bpe
+    global _tokenizer
+    tk = tokenizer or _tokenizer
+    if tk is None:
+        tk = _tokenizer = bpe.BPETokenizer(vocab_path)
+    return torch.from_numpy(bpe.tokenize(texts, tk, context_length, truncate))
+
+
+_tokenizer = None
+
+
+
+def default_prompt_templates():
+    """The default list of clip/clip.py:256 (85 strings; data file next to this module)."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "prompt_templates.json")) as f:
+        return json.load(f)["templates"]
+
+
+@torch.no_grad()
+def encode_text_with_prompt_ensemble(model, texts, device=None, prompt_templates=None, tokenizer=None):
+    """clip/clip.py:252-269: per class: tokenize the prompted strings, encode_text, normalise, mean, normalise -> [n_classes, C]."""
+    templates = list(prompt_templates) if prompt_templates is not None else default_prompt_templates()
+    feats = []
+    for t in texts:
+        prompted = tokenize([tpl.format(t) for tpl in templates], context_length=model.context_length, tokenizer=tokenizer)   # :261-262
+        feats.append(ops.prompt_ensemble(model.encode_text(prompted)))                                                        # :263-266
+    return torch.stack(feats, dim=0)                                                                                         # :268

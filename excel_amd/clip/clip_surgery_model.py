@@ -74,10 +74,25 @@ class VisionTransformer:
 
 
 class ExCEL_CLIP:
-    """Only the visual tower lives on the hot path (encode_image, :548-549)."""
+    """The visual tower lives on the hot path (encode_image, :548-549); the text tower (encode_text, :551-564) is the one-time
+    text-bank step and exists when the checkpoint's text-side weights were given."""
 
-    def __init__(self, visual):
+    def __init__(self, visual, text_state_dict=None, text_heads=None):
         self.visual = visual
+        self._text = None
+        self.context_length = 77
+        if text_state_dict is not None:
+            width = int(text_state_dict["ln_final.weight"].shape[0])
+            self._text = ops.TextHandle(text_state_dict, heads=text_heads or max(width // 64, 1), device=visual.device)   # build_model: heads = width // 64
+            self.context_length = self._text.cfg["context_length"]
+
+    @torch.no_grad()
+    def encode_text(self, text):
+        """text: token ids [B, context_length] -> [B, embed_dim]   (:551-564)"""
+        if self._text is None:
+            raise RuntimeError("encode_text needs the text tower: clip.load(..., state_dict=<full CLIP state_dict>) keeps it when the "
+                               "text-side keys (token_embedding.weight, transformer.*, ln_final.*, text_projection) are present")
+        return self._text.encode(text)
 
     def encode_image(self, image, return_weights=True, ex_feats=None, **kw):
         return self.visual(image, return_weights, ex_feats, **kw)

@@ -15,7 +15,7 @@ class ExCEL_model:
     def __init__(self, clip_model=None, embedding_dim=256, in_channels=512, dataset_name="pascal_voc",
                  num_classes=21, num_atrr_clusters=112, json_file=None, img_size=320, mode="train", device="cuda",
                  state_dict=None, text_features=None, attr_bank=None, vit_cfg=None, text_attr=None, gemm_mode=None,
-                 decoder_state_dict=None, decoder_heads=8):
+                 decoder_state_dict=None, decoder_heads=8, class_names=None, tokenizer=None):
         """Extra keyword arguments (no network here): `state_dict` = CLIP visual weights, `text_features` [T,512] =
         output of encode_text_with_prompt_ensemble (clip/clip.py:252-269, one-time, out of scope),
         `attr_bank` [512,K] overrides the bank file, `vit_cfg` overrides the ViT-B/16 shape, `gemm_mode` = "bf16x3"
@@ -32,8 +32,14 @@ class ExCEL_model:
             self.integral_text_features, self.attr_flag = None, None
             self.text_attr = torch.as_tensor(text_attr).float().to(device)
         else:
+            if text_features is None and class_names is not None:
+                # :31-33: text_prompts = class names + background categories (clip/clip_text.py lists, passed by the caller),
+                # prompt template 'a clean origami {}.' -- runs on the library's text tower (needs the full CLIP state_dict
+                # and CLIP's BPE merges file, see excel_amd/clip/bpe.py)
+                text_features = clip.encode_text_with_prompt_ensemble(self.encoder, list(class_names), device,
+                                                                      prompt_templates=["a clean origami {}."], tokenizer=tokenizer)
             if text_features is None:
-                raise RuntimeError("ExCEL_model needs text_features= (the CLIP text tower is a one-time step outside the hot path)")
+                raise RuntimeError("ExCEL_model needs text_features= or class_names= (+ the CLIP text tower weights and BPE merges file)")
             self.integral_text_features = torch.as_tensor(text_features).float().to(device)
             self.text_attr, self.attr_flag = attr_aggregate(self.integral_text_features, dataset_name, num_classes - 1,
                                                             num_atrr_clusters, json_file, bank=attr_bank, device=device)   # :34

@@ -263,6 +263,74 @@ class DecoderHandle:
         return fts, seg
 
 
+_BLOCK_KEYS = {"ln1_w": "ln_1.weight", "ln1_b": "ln_1.bias", "in_proj_w": "attn.in_proj_weight", "in_proj_b": "attn.in_proj_bias",
+               "out_proj_w": "attn.out_proj.weight", "out_proj_b": "attn.out_proj.bias", "ln2_w": "ln_2.weight", "ln2_b": "ln_2.bias",
+               "fc1_w": "mlp.c_fc.weight", "fc1_b": "mlp.c_fc.bias", "fc2_w": "mlp.c_proj.weight", "fc2_b": "mlp.c_proj.bias"}
+
+
+class TextHandle:
+    """CLIP text tower (encode_text, clip/clip_surgery_model.py:551-564) over the HIP library.  `sd`: the CLIP state_dict keys of
+    the text side (token_embedding.weight, positional_embedding, transformer.resblocks.*, ln_final.*, text_projection)."""
+
+    def __init__(self, sd, heads, device="cuda"):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("excel_amd.TextHandle needs a GPU device: the HIP library is the only compute path")
+        g = lambda k: f32c(torch.as_tensor(sd[k])).to(self.device)
+        self.t = {}
+        nl = 0
+        while f"transformer.resblocks.{nl}.ln_1.weight" in sd:
+            nl += 1
+        self.blocks = (_lib.DecoderBlockWeights * max(nl, 1))()
+        for l in range(nl):
+            for f, k in _BLOCK_KEYS.items():
+                t = self.t[f"blk{l}.{f}"] = g(f"transformer.resblocks.{l}.{k}")
+                setattr(self.blocks[l], f, t.data_ptr())
+        w = _lib.TextWeights()
+        for f, k in (("token_embedding", "token_embedding.weight"), ("positional_embedding", "positional_embedding"),
+                     ("ln_final_w", "ln_final.weight"), ("ln_final_b", "ln_final.bias"), ("text_projection", "text_projection")):
+            t = self.t[f] = g(k)
+            setattr(w, f, t.data_ptr())
+        w.blocks = self.blocks
+        vocab, width = self.t["token_embedding"].shape
+        ctx = self.t["positional_embedding"].shape[0]
+        embed = self.t["text_projection"].shape[1]
+        self.cfg = dict(vocab_size=int(vocab), context_length=int(ctx), width=int(width), layers=nl, heads=heads, embed_dim=int(embed))
+        cfg = _lib.TextConfig(int(vocab), int(ctx), int(width), nl, heads, int(embed))
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib().excel_text_create(C.byref(cfg), C.byref(w), C.byref(self._h)), "excel_text_create")
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().excel_text_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def encode(self, tokens):
+        """tokens [B, context_length] (any integer dtype) -> [B, embed_dim] f32"""
+        tok = torch.as_tensor(tokens).to(device=self.device, dtype=torch.int32).contiguous()
+        B, ctx = tok.shape
+        if ctx != self.cfg["context_length"]:
+            raise ValueError(f"tokens must be [B,{self.cfg['context_length']}], got {tuple(tok.shape)}")
+        out = torch.empty((B, self.cfg["embed_dim"]), dtype=torch.float32, device=self.device)
+        need = lib().excel_text_workspace_bytes(self._h, B)
+        ws = _ws(need, self.device)
+        check(lib().excel_text_encode(self._h, _p(tok, torch.int32), B, _p(out), _p(ws, torch.uint8), need, _stream()), "excel_text_encode")
+        return out
+
+
+def prompt_ensemble(class_embeddings):
+    """clip/clip.py:262-266: [n,E] -> unit-norm mean of the unit-norm rows [E]."""
+    e = f32c(class_embeddings)
+    n, E = e.shape
+    out = torch.empty((E,), dtype=torch.float32, device=e.device)
+    check(lib().excel_prompt_ensemble(_p(e), n, E, _p(out), _stream()), "excel_prompt_ensemble")
+    return out
+
+
 def seg_scale_accumulate(segs, acc, H, W, flip_mean, init, scale=1.0):
     """tools/infer_seg_voc.py:66-82 for one scale: segs [2B,nc,h,w] -> acc [B,nc,H,W] (allocated when None)."""
     segs = f32c(segs)

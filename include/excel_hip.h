@@ -151,6 +151,23 @@ size_t excel_decoder_workspace_bytes(excel_decoder_t h, int B, int g);
 int excel_decoder_forward(excel_decoder_t h, const float* all_feats, int B, int g, void* workspace, size_t workspace_bytes,
                           float* attn_fts_out, float* seg_out, void* stream);
 
+/* ------------------------------------------------------------------ CLIP text tower (one-time text bank)
+ * encode_text (clip/clip_surgery_model.py:551-564): tokens [B,context_length] int32 -> token + positional embedding ->
+ * `layers` causal pre-LN blocks (nn.MultiheadAttention + QuickGELU MLP) -> ln_final -> row of the EOT token (first arg-max of
+ * the ids) @ text_projection [width, embed_dim] -> out [B, embed_dim].  Exact fp32.  Weights: device pointers, state_dict layout. */
+typedef struct excel_text* excel_text_t;
+typedef struct { int vocab_size, context_length, width, layers, heads, embed_dim; } excel_text_config;
+typedef struct {
+    const float *token_embedding, *positional_embedding, *ln_final_w, *ln_final_b, *text_projection;
+    const excel_decoder_block_weights* blocks;     /* [layers] */
+} excel_text_weights;
+int excel_text_create(const excel_text_config* cfg, const excel_text_weights* w, excel_text_t* out);
+void excel_text_destroy(excel_text_t h);
+size_t excel_text_workspace_bytes(excel_text_t h, int B);
+int excel_text_encode(excel_text_t h, const int32_t* tokens, int B, float* out, void* workspace, size_t workspace_bytes, void* stream);
+/* encode_text_with_prompt_ensemble's reduction (clip/clip.py:262-266): emb [n,E] -> rows normalised, mean, normalised -> out [E]. */
+int excel_prompt_ensemble(const float* emb, int n, int E, float* out, void* stream);
+
 /* Multi-scale / flip fuse of the segmentation logits (tools/infer_seg_voc.py:66-82): segs [2B,nc,h,w] of one scale (second
  * half from the x-flipped inputs) -> bilinear (align_corners=False) to (H,W) -> flip_mean ? (seg + flip_x(seg_flipped))/2 : seg
  * (scale 1.0 uses the un-flipped half alone, :69) -> acc [B,nc,H,W] = ((init ? 0 : acc) + .) * scale (mean over scales: pass

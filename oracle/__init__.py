@@ -23,4 +23,4 @@ Pinning status (see DESIGN.md "Oracle"):
     restated in oracle/aff.py and covered by hand-made known-answer cases.
 """
 
-from . import interp, vit, cam, attr, aff, par, evaluate, pipeline, decoder  # noqa: F401
+from . import interp, vit, cam, attr, aff, par, evaluate, pipeline, decoder, text  # noqa: F401

@@ -315,8 +315,40 @@ def gold_decoder():
          dec_attn_last=attn_list[-1], **sd)
 
 
+# ---------------------------------------------------------------- 7. CLIP text tower + tokenizer (one-time text bank)
+def gold_text():
+    torch.manual_seed(13)
+    m = csm.ExCEL_CLIP(embed_dim=32, image_resolution=64, vision_layers=1, vision_width=64, vision_patch_size=16, context_length=77,
+                       vocab_size=120, transformer_width=64, transformer_heads=2, transformer_layers=3).eval()
+    rs = np.random.RandomState(5)
+    tok = np.zeros((6, 77), np.int64)
+    for b in range(6):
+        n = rs.randint(3, 20)
+        tok[b, 0] = 118
+        tok[b, 1:n] = rs.randint(1, 117, n - 1)
+        tok[b, n] = 119                                   # eot = the largest id (clip_surgery_model.py:561)
+    out = m.encode_text(torch.from_numpy(tok))
+    emb = out / out.norm(dim=-1, keepdim=True)            # clip.py:263-265 on the six rows as one prompt ensemble
+    ens = emb.mean(dim=0)
+    ens = ens / ens.norm()
+    sd = {"w." + k: v for k, v in m.state_dict().items() if not k.startswith("visual.") and k != "logit_scale"}
+    # tokenizer: the reference's SimpleTokenizer on its own vocabulary file (ftfy is absent: identity stub, ASCII inputs)
+    ft = types.ModuleType("ftfy")
+    ft.fix_text = lambda t: t
+    sys.modules.setdefault("ftfy", ft)
+    st = _load_by_path("ref_simple_tokenizer", os.path.join(REF, "clip/simple_tokenizer.py"))
+    tk = st.SimpleTokenizer(os.path.join(REF, "clip/bpe_simple_vocab_16e6.txt.gz"))
+    texts = ["a clean origami aeroplane.", "a clean origami potted plant.", "a photo of a tv/monitor, it's nice!", "Ground  KEYBOARD  floor",
+             "a clean origami motorbike.", "there is the diningtable in the scene."]
+    ids = np.zeros((len(texts), 77), np.int32)
+    for i, t in enumerate(texts):
+        e = [tk.encoder["<|startoftext|>"]] + tk.encode(t) + [tk.encoder["<|endoftext|>"]]       # clip.py:233-235
+        ids[i, :len(e)] = e
+    save("text_tiny.npz", tokens=tok, out=out, ensemble=ens, texts=np.array(texts), token_ids=ids, **sd)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["vit_cam", "ops", "attr", "pipeline", "lvc", "decoder"]       # e.g. `make_goldens.py lvc` mints one file
+    which = sys.argv[1:] or ["vit_cam", "ops", "attr", "pipeline", "lvc", "decoder", "text"]       # e.g. `make_goldens.py lvc` mints one file
     with torch.no_grad():
         for name in which:
             globals()["gold_" + name]()

@@ -593,3 +593,64 @@ def test_multi_scale_seg_inference_vs_oracle(gpu, golden):
     assert np.array_equal(lab, ref_lab)
     scores, hist = infer_seg_voc.validate_seg(model, [(dev(x), dev(gt))], 5, 64, scales)
     assert int(host(hist).sum()) == gt.size and 0.0 <= scores["miou"] <= 1.0
+
+
+# ------------------------------------------------------------------ SURVEY 8(f) rank 4 (text-bank builder): CLIP text tower
+def test_text_tower_matches_golden(gpu, golden):
+    """encode_text (clip_surgery_model.py:551-564) and the prompt-ensemble reduction (clip.py:262-266) vs the reference's outputs."""
+    from excel_amd import ops
+    g = golden("text_tiny.npz")
+    sd = {k[2:]: g[k] for k in g.files if k.startswith("w.")}
+    h = ops.TextHandle(sd, heads=2)
+    out = host(h.encode(g["tokens"]))
+    assert maxabs(out, g["out"]) / float(np.abs(g["out"]).max()) < 1e-5
+    assert maxabs(host(ops.prompt_ensemble(dev(g["out"]))), g["ensemble"]) < 1e-6
+    # production shape against the oracle: width 512, 8 heads of 64, context 77
+    rs = np.random.RandomState(0)
+    E, ctx, V, C = 512, 77, 300, 512
+    w = {"token_embedding.weight": (0.02 * rs.standard_normal((V, E))).astype(np.float32),
+         "positional_embedding": (0.01 * rs.standard_normal((ctx, E))).astype(np.float32),
+         "ln_final.weight": np.ones(E, np.float32), "ln_final.bias": np.zeros(E, np.float32),
+         "text_projection": (rs.standard_normal((E, C)) * E ** -0.5).astype(np.float32)}
+    for l in range(2):
+        p = f"transformer.resblocks.{l}."
+        w[p + "ln_1.weight"] = (1 + 0.1 * rs.standard_normal(E)).astype(np.float32); w[p + "ln_1.bias"] = (0.1 * rs.standard_normal(E)).astype(np.float32)
+        w[p + "ln_2.weight"] = (1 + 0.1 * rs.standard_normal(E)).astype(np.float32); w[p + "ln_2.bias"] = (0.1 * rs.standard_normal(E)).astype(np.float32)
+        w[p + "attn.in_proj_weight"] = (rs.standard_normal((3 * E, E)) * E ** -0.5).astype(np.float32); w[p + "attn.in_proj_bias"] = np.zeros(3 * E, np.float32)
+        w[p + "attn.out_proj.weight"] = (rs.standard_normal((E, E)) * E ** -0.5).astype(np.float32); w[p + "attn.out_proj.bias"] = np.zeros(E, np.float32)
+        w[p + "mlp.c_fc.weight"] = (rs.standard_normal((4 * E, E)) * (2 * E) ** -0.5).astype(np.float32); w[p + "mlp.c_fc.bias"] = np.zeros(4 * E, np.float32)
+        w[p + "mlp.c_proj.weight"] = (rs.standard_normal((E, 4 * E)) * E ** -0.5).astype(np.float32); w[p + "mlp.c_proj.bias"] = np.zeros(E, np.float32)
+    tok = np.zeros((3, ctx), np.int64)
+    for b, n in enumerate((5, 40, 76)):
+        tok[b, :n] = rs.randint(1, V - 2, n)
+        tok[b, n] = V - 1
+    ref = oracle.text.encode_text(tok, w, heads=8)
+    got = host(ops.TextHandle(w, heads=8).encode(tok))
+    assert maxabs(got, ref) / float(np.abs(ref).max()) < 2e-5
+
+
+def test_clip_api_encode_text_with_prompt_ensemble(gpu, golden):
+    """clip.load keeps the text tower of a full CLIP state_dict; encode_text_with_prompt_ensemble (clip.py:252-269) over it,
+    with a stub tokenizer (the merges file is not shipped) -> rows are unit-norm class embeddings."""
+    from excel_amd import clip as xclip
+    from excel_amd.clip import bpe
+    g = golden("text_tiny.npz")
+    w = make_vit_weights(TINY, seed=11)
+    full = {"visual." + k: v for k, v in w.items()}
+    full.update({k[2:]: g[k] for k in g.files if k.startswith("w.")})
+    model, _ = xclip.load("tiny", state_dict=full, **TINY_KW)
+    assert model.context_length == 77
+
+    class StubTok:
+        encoder = {bpe.SOT: 118, bpe.EOT: 119}
+        def encode(self, text): return [1 + (ord(c) % 110) for c in text][:40]
+    tf = xclip.encode_text_with_prompt_ensemble(model, ["cat", "potted plant"], "cuda", prompt_templates=["a clean origami {}.", "a photo of a {}."],
+                                                tokenizer=StubTok())
+    assert tuple(tf.shape) == (2, 32)
+    np.testing.assert_allclose(np.linalg.norm(host(tf), axis=1), 1.0, atol=1e-5)
+    # the same through the oracle
+    for i, t in enumerate(["cat", "potted plant"]):
+        ids = bpe.tokenize([tpl.format(t) for tpl in ["a clean origami {}.", "a photo of a {}."]], StubTok())
+        e = oracle.text.encode_text(ids, {k[2:]: g[k] for k in g.files if k.startswith("w.")}, heads=1)
+        assert maxabs(host(tf)[i], oracle.text.prompt_ensemble(e)) < 1e-5
+    assert len(xclip.clip.default_prompt_templates()) == 85

@@ -221,3 +221,22 @@ def test_on_disk_formats(tmp_path):
     from PIL import Image
     back = np.asarray(Image.open(png))
     assert np.array_equal(back, imutils.encode_cmap(lab2))
+
+
+def test_bpe_tokenizer_matches_reference_ids(golden):
+    """Token ids minted with the reference's own tokenizer (tests/golden/make_goldens.py gold_text).  CLIP's merges file is
+    not shipped with this repo: the test runs where one is available (EXCEL_BPE_VOCAB or the build container's reference)."""
+    import os
+    from excel_amd.clip import bpe
+    path = os.environ.get("EXCEL_BPE_VOCAB") or "/root/reference/clip/bpe_simple_vocab_16e6.txt.gz"
+    if not os.path.exists(path):
+        pytest.skip("CLIP BPE merges file not available")
+    g = golden("text_tiny.npz")
+    tk = bpe.BPETokenizer(path)
+    assert len(tk.encoder) == 49408 and tk.encoder[bpe.SOT] == 49406 and tk.encoder[bpe.EOT] == 49407
+    ids = bpe.tokenize([str(t) for t in g["texts"]], tk)
+    assert np.array_equal(ids, g["token_ids"])
+    assert tk.decode(ids[0][1:list(ids[0]).index(49407)]).strip() == "a clean origami aeroplane ."
+    with pytest.raises(RuntimeError):
+        bpe.tokenize(["word " * 100], tk)
+    assert bpe.tokenize(["word " * 100], tk, truncate=True)[0, -1] == 49407

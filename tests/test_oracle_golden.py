@@ -171,3 +171,12 @@ def test_decoder_head_and_aliased_feats(golden):
     assert relmax(seg, g["seg"]) < 1e-5
     assert maxabs(attns[-1], g["dec_attn_last"]) < 1e-6
     assert maxabs(oracle.cam.attn_pred(g["fts"]), g["attn_pred"]) < 1e-6
+
+
+def test_text_tower_and_prompt_ensemble(golden):
+    """SURVEY 8f#4: encode_text (causal transformer, EOT row, projection) and the prompt-ensemble reduction."""
+    g = golden("text_tiny.npz")
+    w = {k[2:]: g[k] for k in g.files if k.startswith("w.")}
+    out = oracle.text.encode_text(g["tokens"], w, heads=2)
+    assert relmax(out, g["out"]) < 1e-5
+    assert maxabs(oracle.text.prompt_ensemble(g["out"]), g["ensemble"]) < 1e-6
