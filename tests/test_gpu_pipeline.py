@@ -654,3 +654,29 @@ def test_clip_api_encode_text_with_prompt_ensemble(gpu, golden):
         e = oracle.text.encode_text(ids, {k[2:]: g[k] for k in g.files if k.startswith("w.")}, heads=1)
         assert maxabs(host(tf)[i], oracle.text.prompt_ensemble(e)) < 1e-5
     assert len(xclip.clip.default_prompt_templates()) == 85
+
+
+def test_attr_clustering_builds_a_bank(gpu, golden):
+    """attr_clustering (model/load_attr.py:10-84) over the library's text tower; mirrored with the oracle + the same sklearn call."""
+    from sklearn.cluster import KMeans
+    from excel_amd import clip as xclip
+    from excel_amd.clip import bpe
+    from excel_amd.model.load_attr import attr_clustering
+    g = golden("text_tiny.npz")
+    tw = {k[2:]: g[k] for k in g.files if k.startswith("w.")}
+    full = {"visual." + k: v for k, v in make_vit_weights(TINY, seed=11).items()}
+    full.update(tw)
+    model, _ = xclip.load("tiny", state_dict=full, **TINY_KW)
+
+    class StubTok:
+        encoder = {bpe.SOT: 118, bpe.EOT: 119}
+        def encode(self, text): return [1 + (ord(c) % 110) for c in text][:40]
+    desc = {f"class{c}": [f"a {w} thing number {c} with {w}s" for w in ("red", "round", "furry", "metal", "wooden", "tiny")] for c in range(5)}
+    bank, flags = attr_clustering(desc, model, num_atrr_clusters=7, tokenizer=StubTok())
+    assert tuple(bank.shape) == (32, 7) and tuple(flags.shape) == (5, 7) and float(flags.sum(1).min()) >= 1
+    embs = []
+    for _, d in desc.items():
+        e = oracle.text.encode_text(bpe.tokenize([s.lower() for s in d], StubTok()), tw, heads=1)
+        embs.append(e / np.linalg.norm(e, axis=1, keepdims=True))
+    km = KMeans(n_clusters=7, random_state=0).fit(np.concatenate(embs, 0))
+    assert maxabs(bank.numpy(), km.cluster_centers_.T) < 1e-4
