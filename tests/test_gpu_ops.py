@@ -486,3 +486,55 @@ def test_vit_tiny_bf16x3_mode_vs_golden(ops, golden):
     r = h.forward(dev(g["imgs"]), want_raw=True)
     full, _ = ops.clip_feature_surgery(r["image_features"], dev(g["train_text"]))
     assert maxabs(host(full), g["train_cam"]) < 1e-3
+
+
+# ------------------------------------------------------------------ error conventions and degenerate inputs
+def test_abi_error_conventions(ops):
+    """C ABI: int status (0 ok, < 0 bad argument / launch failure) + excel_last_error(); Python raises RuntimeError with it."""
+    import ctypes as C
+    from excel_amd._lib import lib
+    L = lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    a = torch.zeros(8, 8, device="cuda")
+    # K not a multiple of 4 in NT mode
+    rc = L.excel_gemm_f32(a.data_ptr(), a.data_ptr(), a.data_ptr(), None, None, 8, 8, 7, 8, 8, 8, 0, 1, 0, 1, 0, 0, 0, 0, st)
+    assert rc < 0 and b"multiple of 4" in L.excel_last_error()
+    # null pointers
+    assert L.excel_compute_trans_mat(None, 1, 36, a.data_ptr(), a.data_ptr(), st) < 0
+    assert L.excel_par_forward(None, 8, 8, None, None, 1, 1, 8, 8, (C.c_int32 * 1)(1), 1, 1, 0.3, 0.01, None, None, st) < 0
+    # bad layer range
+    assert L.excel_attn_layer_mean(a.data_ptr(), 2, 1, 4, 1, 5, a.data_ptr(), st) < 0 and b"layer" in L.excel_last_error()
+    # a good call after failures returns 0 (errors are not sticky)
+    assert L.excel_layernorm(a.data_ptr(), a[0].data_ptr(), a[0].data_ptr(), a.data_ptr(), 8, 8, 1e-5, st) == 0
+    with pytest.raises(RuntimeError, match="head_dim|heads|width"):
+        make_handle(ops, VitConfig(width=96, layers=2, heads=2, patch=16, out_dim=32, input_resolution=32, n_surgery=1),
+                    make_vit_weights(VitConfig(width=96, layers=2, heads=2, patch=16, out_dim=32, input_resolution=32, n_surgery=1), seed=1)
+                    ).forward(torch.zeros(1, 3, 32, 32, device="cuda"))
+    with pytest.raises(RuntimeError, match="ndil"):
+        ops.par_forward(torch.zeros(1, 3, 8, 8, device="cuda"), torch.zeros(1, 1, 8, 8, device="cuda"), dilations=(1,) * 9)
+
+
+def test_degenerate_inputs_follow_the_reference(ops):
+    """Silent-NaN conventions of the reference: a constant similarity column gives 0/0 in clip_feature_surgery's
+    min-max (clip.py:308); scale_cam_image is eps-guarded (affutils.py:73); a zero row in the affinity gives NaN in Sinkhorn
+    (affutils.py:11-12).  The oracle (numpy) produces the same patterns."""
+    rs = np.random.RandomState(0)
+    f = np.tile(rs.standard_normal((1, 1, 16)).astype(np.float32), (1, 10, 1))       # every token identical
+    f /= np.linalg.norm(f, axis=1, keepdims=True)
+    t = rs.standard_normal((3, 16)).astype(np.float32)
+    with np.errstate(all="ignore"):
+        ref = oracle.cam.clip_feature_surgery(f, t)                                      # every column constant -> (x - min) / 0
+    got = host(ops.clip_feature_surgery(dev(f), dev(t))[0])
+    assert np.isnan(ref).all() and np.array_equal(np.isnan(got), np.isnan(ref))
+    # constant refined map -> eps-guarded min-max -> zeros, background 1
+    refined = np.full((1, 1, 36), 0.25, np.float32)
+    cams = host(ops.cam_upsample_bkg(dev(refined), dev(np.array([1]), torch.int32), 6, 12, 12))
+    assert np.allclose(cams[0, 0], 1.0) and np.allclose(cams[0, 1], 0.0)
+    # zero row -> NaN through the row/column normalisation, like the reference's plain divisions
+    a = (rs.rand(1, 36, 36).astype(np.float32) + 0.1)
+    a[0, 5, :] = 0
+    a[0, :, 5] = 0
+    with np.errstate(all="ignore"):
+        tref = oracle.aff.compute_trans_mat(a[0])
+    tgot = host(ops.compute_trans_mat(dev(a)))[0]
+    assert np.isnan(tref).any() and np.array_equal(np.isnan(tgot), np.isnan(tref))
