@@ -354,6 +354,10 @@ def test_split_batch_matches_single_stream(gpu, b16_model):
     p1 = TrainingFreePipeline(model, num_classes=21, smax=ds.max_k())
     p2 = TrainingFreePipeline(model, num_classes=21, smax=ds.max_k())
     ref = p1.run_batch(dev(imgs), dev(cls), dev(gts))
+    p3 = TrainingFreePipeline(model, num_classes=21, smax=ds.max_k())
+    lab3 = [p3.run_batch_overlapped(dev(imgs), dev(cls), dev(gts)) for _ in range(2)]       # two-stream ViT/PAR software pipeline
+    p3.drain()
+    assert np.array_equal(host(lab3[1]), host(ref)) and np.array_equal(host(p3.hist), 2 * host(p1.hist))
     for nsplit in (2, 4):
         p2.reset()
         for _ in range(2):                                   # twice: histograms accumulate across steps
