@@ -19,9 +19,18 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ T
     const int b = blockIdx.y, cl = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     const float* Tb = T + (long long)b * P * P;
-    float s = 0.f;
-    if (c < P)
-        for (int i = g; i < P; i += 4) s += Tb[(long long)i * P + c];
+    // 8 independent partial sums per thread: 8 loads in flight instead of a serial chain of P/4 dependent ones
+    // (the grid is only P/64 x B workgroups, so this kernel was latency-, not bandwidth-bound: 1.2 TB/s)
+    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c < P) {
+        int i = g;
+        for (; i + 28 < P; i += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a8[u] += Tb[(long long)(i + 4 * u) * P + c];
+        }
+        for (int u = 0; i < P; i += 4, ++u) a8[u] += Tb[(long long)i * P + c];
+    }
+    const float s = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
     part[g][cl] = s;
     __syncthreads();
     if (g == 0 && c < P) cs[(long long)b * P + c] = (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
