@@ -28,28 +28,37 @@ __global__ __launch_bounds__(256) void par_affinity_kernel(const float* __restri
     constexpr int NT = 8 * ND;
     const int b = blockIdx.z;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= W || y >= H) return;
+    // one wave = one image row: y and every tap row are wave-uniform -> scalar row bases, per-lane work is the x offset only
+    // (per-lane 64-bit address arithmetic for the 144 tap loads was most of this kernel's VALU work)
+    const int y = blockIdx.y * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (y >= H) return;
+    const bool in_x = x < W;
+    const int xc = min(x, W - 1);
     const long long HW = (long long)H * W;
+    int xo[ND][2];
+#pragma unroll
+    for (int di = 0; di < ND; ++di) { xo[di][0] = max(xc - dl.d[di], 0); xo[di][1] = min(xc + dl.d[di], W - 1); }
     float acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = 0.f;
 #pragma unroll 1
     for (int c = 0; c < 3; ++c) {
         const float* ch = img + ((long long)b * 3 + c) * HW;
-        const float ctr = ch[(long long)y * W + x];
+        const float* row0 = ch + (long long)y * W;
+        const float ctr = row0[xc];
         float nb[NT];
         float sum = 0.f;
 #pragma unroll
         for (int di = 0; di < ND; ++di) {
             const int d = dl.d[di];
+            const float* rup = ch + (long long)max(y - d, 0) * W;          // scalar
+            const float* rdn = ch + (long long)min(y + d, H - 1) * W;
+            // tap order of get_dilated_neighbors (PAR.py:39-52): (-1,-1) (-1,0) (-1,1) (0,-1) (0,1) (1,-1) (1,0) (1,1)
+            nb[di * 8 + 0] = rup[xo[di][0]]; nb[di * 8 + 1] = rup[xc]; nb[di * 8 + 2] = rup[xo[di][1]];
+            nb[di * 8 + 3] = row0[xo[di][0]]; nb[di * 8 + 4] = row0[xo[di][1]];
+            nb[di * 8 + 5] = rdn[xo[di][0]]; nb[di * 8 + 6] = rdn[xc]; nb[di * 8 + 7] = rdn[xo[di][1]];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int yy = min(max(y + TAP_DY[k] * d, 0), H - 1);
-                const int xx = min(max(x + TAP_DX[k] * d, 0), W - 1);
-                nb[di * 8 + k] = ch[(long long)yy * W + xx];
-                sum += nb[di * 8 + k];
-            }
+            for (int k = 0; k < 8; ++k) sum += nb[di * 8 + k];
         }
         const float mean = sum / (float)NT;
         float var = 0.f;
@@ -73,6 +82,7 @@ __global__ __launch_bounds__(256) void par_affinity_kernel(const float* __restri
 #pragma unroll
     for (int t = 0; t < NT; ++t) { acc[t] = __expf(acc[t] - m); s += acc[t]; }
     const float inv_s = 1.f / s;
+    if (!in_x) return;
     float* out = aff + (long long)b * NT * HW + (long long)y * W + x;
 #pragma unroll
     for (int t = 0; t < NT; ++t) out[(long long)t * HW] = fmaf(acc[t], inv_s, dl.pos_sm[t]);
