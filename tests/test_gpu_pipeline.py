@@ -713,3 +713,40 @@ def test_coco_config_full_width_properties(gpu):
     lam = multi_scale_lam(model, dev(imgs[:2]), scales=(1.0, 0.5, 0.75, 1.5))
     assert tuple(lam.shape) == (2, 80, S, S) and bool(torch.isfinite(lam).all())
     assert float(lam.min()) >= 0.0 and float(lam.max()) <= 1.0
+
+
+def test_validation_engine_with_decoder(gpu, golden):
+    """engine/validatation_engine.py:11-51 over the mirrored modules (decoder seg + seg_attn-gated pseudo labels), checked on one
+    sample against the oracle chain."""
+    from excel_amd.engine.validatation_engine import build_validation
+    from excel_amd.model import ExCEL_model
+    from excel_amd.utils.PAR import PAR
+    g = golden("decoder_tiny.npz")
+    w = make_vit_weights(TINY, seed=int(g["seed_w"]))
+    wo = oracle.vit.reload_self_attn(w, TINY, 4, "train")
+    dw = {k: g[k] for k in g.files if k.startswith(("fuse.", "dec."))}
+    rs = np.random.RandomState(6)
+    text = rs.standard_normal((9, 64)).astype(np.float32)
+    text /= np.linalg.norm(text, axis=1, keepdims=True)
+    model = ExCEL_model(clip_model="tiny", num_classes=5, img_size=64, mode="train", state_dict=w, vit_cfg=TINY_KW, text_attr=text.T.copy(),
+                        gemm_mode="f32", embedding_dim=32, in_channels=128, decoder_state_dict=_decoder_sd(g))
+    img = rs.standard_normal((1, 3, 80, 72)).astype(np.float32)
+    gt = rs.randint(0, 5, (1, 80, 72)).astype(np.uint8)
+    cls = np.array([[0, 1, 1, 0]], np.float32)
+    par = PAR(num_iter=20, dilations=[1, 2, 4, 8, 12, 24])
+    table, aff_score, seg_score = build_validation(model, par, [(["s0"], img, gt, cls)], "cuda", num_classes=5, resize_size=64)
+    assert "Attr_aff_Pseudo" in table and "Seg_Preds" in table
+    # oracle chain
+    x = oracle.interp.bilinear_resize(img, 64, 64, align_corners=False)
+    _, attn, feats = oracle.vit.vit_forward(x, wo, TINY, aliased_feats=True)
+    fts = oracle.decoder.segformer_fuse(feats, dw)
+    seg, _ = oracle.decoder.decoder_transformer(fts, dw, heads=8)
+    ap = oracle.cam.attn_pred(fts)
+    maps = oracle.cam.attr_maps_raw(x, wo, TINY, text.T.copy(), 4)[0]
+    refined, cls_lst = oracle.aff.refine_cams_with_aff(maps[0], attn[:, 0], cls[0], size=(64, 64), caa_thre=0.75, seg_attn=ap[0][None])
+    lab, _ = oracle.aff.refine_cams_with_bkg_weclip(refined, x[0], cls_lst, oracle.par.PAR([1, 2, 4, 8, 12, 24], 20), (80, 72))
+    ref_aff = oracle.evaluate.scores_from_hist(oracle.evaluate.fast_hist(gt[0].flatten(), lab[0].flatten(), 5))
+    seg_lab = oracle.interp.bilinear_resize(seg, 80, 72, align_corners=False).argmax(1)
+    ref_seg = oracle.evaluate.scores_from_hist(oracle.evaluate.fast_hist(gt[0].flatten(), seg_lab[0].flatten(), 5))
+    assert abs(aff_score["miou"] - ref_aff["miou"]) < 2e-3 and abs(seg_score["miou"] - ref_seg["miou"]) < 2e-3
+    assert abs(seg_score["pAcc"] - ref_seg["pAcc"]) < 2e-3
