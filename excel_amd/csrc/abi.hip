@@ -338,6 +338,12 @@ extern "C" int excel_vit_forward_ex(excel_vit_t h, const float* img, int B, int 
                             feats_out, ex_attn, flags, stream);
 }
 
+extern "C" int excel_denormalize_img(const float* img, int B, int H, int W, const float* mean3, const float* std3, unsigned char* out_u8,
+                                    float* out_f32, void* stream) {
+    EXCEL_CHECK_ARG(img && mean3 && std3 && (out_u8 || out_f32) && B > 0 && H > 0 && W > 0, "denormalize_img: bad argument");
+    return excel_launch_denormalize(img, out_u8, out_f32, B, (long long)H * W, mean3, std3, ST(stream));
+}
+
 extern "C" int excel_seg_scale_accumulate(const float* segs, float* acc, int B, int nc, int h, int w, int H, int W, int flip_mean,
                                          int init, float scale, void* stream) {
     EXCEL_CHECK_ARG(segs && acc && B > 0 && nc > 0 && h > 0 && w > 0 && H > 0 && W > 0, "seg_scale_accumulate: bad argument");

@@ -172,6 +172,28 @@ int excel_launch_seg_scale_accumulate(const float* segs, float* acc, int B, int 
     return EXCEL_OK;
 }
 
+// denormalize_img / denormalize_img2 (utils/imutils.py:11-25): v = img * std[c] + mean[c] -> truncate to uint8 (torch's
+// float -> uint8 cast: toward zero; values are inside [0,255] for real images) ; img2 = that / 255 as float
+__global__ __launch_bounds__(256) void denormalize_kernel(const float* __restrict__ img, unsigned char* __restrict__ out8, float* __restrict__ outf,
+                                                          long long HW, long long total, float m0, float m1, float m2, float s0, float s1, float s2) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)((i / HW) % 3);
+    const float v = img[i] * (c == 0 ? s0 : (c == 1 ? s1 : s2)) + (c == 0 ? m0 : (c == 1 ? m1 : m2));
+    const unsigned char q = (unsigned char)(int)fminf(fmaxf(v, 0.f), 255.f);
+    if (out8) out8[i] = q;
+    if (outf) outf[i] = (float)q / 255.0f;
+}
+
+int excel_launch_denormalize(const float* img, unsigned char* out8, float* outf, int B, long long HW, const float* mean, const float* stdv,
+                             hipStream_t st) {
+    const long long total = (long long)B * 3 * HW;
+    hipLaunchKernelGGL(denormalize_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, img, out8, outf, HW, total, mean[0], mean[1], mean[2],
+                       stdv[0], stdv[1], stdv[2]);
+    EXCEL_CHECK_LAUNCH("denormalize");
+    return EXCEL_OK;
+}
+
 // lam = lam - min_hw ; lam /= max_hw + 1e-5 per (b, f) plane (camutils.py:58-59), in place
 __global__ __launch_bounds__(256) void plane_minmax_normalize_kernel(float* __restrict__ lam, long long HW) {
     __shared__ float smn[4], smx[4];

@@ -87,6 +87,8 @@ int excel_launch_lam_scale_accumulate(const float* maps, float* acc, int B, int 
 int excel_launch_plane_minmax_normalize(float* lam, long long planes, long long HW, hipStream_t st);
 int excel_launch_seg_scale_accumulate(const float* segs, float* acc, int B, int nc, int h, int w, int H, int W, int flip_mean, int init,
                                       float scale, hipStream_t st);
+int excel_launch_denormalize(const float* img, unsigned char* out8, float* outf, int B, long long HW, const float* mean, const float* stdv,
+                             hipStream_t st);
 // LVC side (lvc.hip)
 size_t excel_feature_affinity_ws_bytes(int B, int C, int P);
 int excel_launch_feature_affinity(const float* feats, int B, int C, int P, float beta, float gamma, int mode, float* out, void* ws,

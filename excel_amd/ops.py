@@ -331,6 +331,18 @@ def prompt_ensemble(class_embeddings):
     return out
 
 
+def denormalize_img(imgs, mean=(123.675, 116.28, 103.53), std=(58.395, 57.12, 57.375), as_float=False):
+    """utils/imutils.py:11-25: [B,3,H,W] normalised f32 -> uint8 image (denormalize_img) or that / 255 as f32 (denormalize_img2)."""
+    imgs = f32c(imgs)
+    B, Cc, H, W = imgs.shape
+    assert Cc == 3
+    out = torch.empty((B, 3, H, W), dtype=torch.float32 if as_float else torch.uint8, device=imgs.device)
+    m, s = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    check(lib().excel_denormalize_img(_p(imgs), B, H, W, m, s, None if as_float else _p(out, torch.uint8), _p(out) if as_float else None,
+                                      _stream()), "excel_denormalize_img")
+    return out
+
+
 def seg_scale_accumulate(segs, acc, H, W, flip_mean, init, scale=1.0):
     """tools/infer_seg_voc.py:66-82 for one scale: segs [2B,nc,h,w] -> acc [B,nc,H,W] (allocated when None)."""
     segs = f32c(segs)

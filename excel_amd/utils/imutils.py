@@ -32,6 +32,18 @@ def encode_cmap(label):
     return colormap()[np.asarray(label).astype(np.int16), :]
 
 
+def denormalize_img(imgs=None, mean=(123.675, 116.28, 103.53), std=(58.395, 57.12, 57.375)):
+    """utils/imutils.py:11-19 (device tensor in, uint8 device tensor out; HIP kernel)."""
+    from .. import ops
+    return ops.denormalize_img(imgs, mean, std, as_float=False)
+
+
+def denormalize_img2(imgs=None):
+    """utils/imutils.py:21-25: denormalize_img(imgs) / 255.0 (the PAR guide image of the training loop, scripts/train_voc.py:181)."""
+    from .. import ops
+    return ops.denormalize_img(imgs, as_float=True)
+
+
 def save_logits(logits_dir, name, valid_lam, keys_gt):
     """tools/infer_lam.py:116-119."""
     os.makedirs(logits_dir, exist_ok=True)

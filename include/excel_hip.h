@@ -168,6 +168,11 @@ int excel_text_encode(excel_text_t h, const int32_t* tokens, int B, float* out, 
 /* encode_text_with_prompt_ensemble's reduction (clip/clip.py:262-266): emb [n,E] -> rows normalised, mean, normalised -> out [E]. */
 int excel_prompt_ensemble(const float* emb, int n, int E, float* out, void* stream);
 
+/* denormalize_img / denormalize_img2 (utils/imutils.py:11-25): img [B,3,H,W] f32 (normalised) -> v = img*std[c] + mean[c]
+ * truncated to uint8 (out_u8, optional) and/or that value / 255 as float (out_f32, optional).  mean3/std3: HOST pointers to 3 floats. */
+int excel_denormalize_img(const float* img, int B, int H, int W, const float* mean3, const float* std3, unsigned char* out_u8,
+                          float* out_f32, void* stream);
+
 /* Multi-scale / flip fuse of the segmentation logits (tools/infer_seg_voc.py:66-82): segs [2B,nc,h,w] of one scale (second
  * half from the x-flipped inputs) -> bilinear (align_corners=False) to (H,W) -> flip_mean ? (seg + flip_x(seg_flipped))/2 : seg
  * (scale 1.0 uses the un-flipped half alone, :69) -> acc [B,nc,H,W] = ((init ? 0 : acc) + .) * scale (mean over scales: pass

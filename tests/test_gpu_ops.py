@@ -538,3 +538,17 @@ def test_degenerate_inputs_follow_the_reference(ops):
         tref = oracle.aff.compute_trans_mat(a[0])
     tgot = host(ops.compute_trans_mat(dev(a)))[0]
     assert np.isnan(tref).any() and np.array_equal(np.isnan(tgot), np.isnan(tref))
+
+
+def test_denormalize_img(ops):
+    """utils/imutils.py:11-25 restated: v = img*std + mean, float -> uint8 truncation; img2 = that / 255."""
+    from excel_amd.utils import imutils
+    rs = np.random.RandomState(1)
+    mean, std = np.array([123.675, 116.28, 103.53], np.float32), np.array([58.395, 57.12, 57.375], np.float32)
+    u8 = rs.randint(0, 256, (2, 3, 9, 13)).astype(np.float32)
+    x = ((u8 + 0.4) - mean[None, :, None, None]) / std[None, :, None, None]          # decodes back to u8 + 0.4 -> truncates to u8
+    got = host(imutils.denormalize_img(dev(x.astype(np.float32))))
+    ref = (x.astype(np.float32) * std[None, :, None, None] + mean[None, :, None, None]).astype(np.uint8)
+    assert got.dtype == np.uint8 and np.array_equal(got, ref)
+    got2 = host(imutils.denormalize_img2(dev(x.astype(np.float32))))
+    assert np.allclose(got2, ref.astype(np.float32) / 255.0, atol=1e-7)
