@@ -338,6 +338,11 @@ extern "C" int excel_vit_forward_ex(excel_vit_t h, const float* img, int B, int 
                             feats_out, ex_attn, flags, stream);
 }
 
+extern "C" int excel_normalize_img_u8(const unsigned char* hwc, int B, int H, int W, const double* mean3, const double* std3, float* out, void* stream) {
+    EXCEL_CHECK_ARG(hwc && out && mean3 && std3 && B > 0 && H > 0 && W > 0, "normalize_img_u8: bad argument");
+    return excel_launch_normalize_u8(hwc, out, B, (long long)H * W, mean3, std3, ST(stream));
+}
+
 extern "C" int excel_denormalize_img(const float* img, int B, int H, int W, const float* mean3, const float* std3, unsigned char* out_u8,
                                     float* out_f32, void* stream) {
     EXCEL_CHECK_ARG(img && mean3 && std3 && (out_u8 || out_f32) && B > 0 && H > 0 && W > 0, "denormalize_img: bad argument");

@@ -185,6 +185,26 @@ __global__ __launch_bounds__(256) void denormalize_kernel(const float* __restric
     if (outf) outf[i] = (float)q / 255.0f;
 }
 
+// transforms.normalize_img + HWC->CHW (datasets/transforms.py, datasets/voc.py:115-116): u8 [B,H,W,3] -> f32 [B,3,H,W],
+// (u8 - mean[c]) / std[c] evaluated in double and rounded once, exactly like numpy's float64 intermediate
+__global__ __launch_bounds__(256) void normalize_u8_kernel(const unsigned char* __restrict__ hwc, float* __restrict__ out, long long HW, long long total,
+                                                           double m0, double m1, double m2, double s0, double s1, double s2) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;      // output index (b, c, pix)
+    if (i >= total) return;
+    const long long pix = i % HW;
+    const int c = (int)((i / HW) % 3);
+    const long long b = i / (3 * HW);
+    const double v = (double)hwc[(b * HW + pix) * 3 + c];
+    out[i] = (float)((v - (c == 0 ? m0 : (c == 1 ? m1 : m2))) / (c == 0 ? s0 : (c == 1 ? s1 : s2)));
+}
+
+int excel_launch_normalize_u8(const unsigned char* hwc, float* out, int B, long long HW, const double* mean, const double* stdv, hipStream_t st) {
+    const long long total = (long long)B * 3 * HW;
+    hipLaunchKernelGGL(normalize_u8_kernel, dim3((unsigned)cdivl(total, 256)), dim3(256), 0, st, hwc, out, HW, total, mean[0], mean[1], mean[2], stdv[0], stdv[1], stdv[2]);
+    EXCEL_CHECK_LAUNCH("normalize_u8");
+    return EXCEL_OK;
+}
+
 int excel_launch_denormalize(const float* img, unsigned char* out8, float* outf, int B, long long HW, const float* mean, const float* stdv,
                              hipStream_t st) {
     const long long total = (long long)B * 3 * HW;

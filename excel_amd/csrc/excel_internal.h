@@ -89,6 +89,7 @@ int excel_launch_seg_scale_accumulate(const float* segs, float* acc, int B, int 
                                       float scale, hipStream_t st);
 int excel_launch_denormalize(const float* img, unsigned char* out8, float* outf, int B, long long HW, const float* mean, const float* stdv,
                              hipStream_t st);
+int excel_launch_normalize_u8(const unsigned char* hwc, float* out, int B, long long HW, const double* mean, const double* stdv, hipStream_t st);
 // LVC side (lvc.hip)
 size_t excel_feature_affinity_ws_bytes(int B, int C, int P);
 int excel_launch_feature_affinity(const float* feats, int B, int C, int P, float beta, float gamma, int mode, float* out, void* ws,

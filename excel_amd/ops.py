@@ -331,6 +331,17 @@ def prompt_ensemble(class_embeddings):
     return out
 
 
+def normalize_img_u8(hwc_u8, mean=(123.675, 116.28, 103.53), std=(58.395, 57.12, 57.375)):
+    """datasets/transforms.normalize_img + HWC->CHW on the device: uint8 [B,H,W,3] -> f32 [B,3,H,W] (3 B/pixel over PCIe instead of 12)."""
+    x = hwc_u8.contiguous()
+    B, H, W, Cc = x.shape
+    assert Cc == 3 and x.dtype == torch.uint8
+    out = torch.empty((B, 3, H, W), dtype=torch.float32, device=x.device)
+    m, s = (C.c_double * 3)(*mean), (C.c_double * 3)(*std)
+    check(lib().excel_normalize_img_u8(_p(x, torch.uint8), B, H, W, m, s, _p(out), _stream()), "excel_normalize_img_u8")
+    return out
+
+
 def denormalize_img(imgs, mean=(123.675, 116.28, 103.53), std=(58.395, 57.12, 57.375), as_float=False):
     """utils/imutils.py:11-25: [B,3,H,W] normalised f32 -> uint8 image (denormalize_img) or that / 255 as f32 (denormalize_img2)."""
     imgs = f32c(imgs)

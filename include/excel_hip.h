@@ -168,6 +168,10 @@ int excel_text_encode(excel_text_t h, const int32_t* tokens, int B, float* out, 
 /* encode_text_with_prompt_ensemble's reduction (clip/clip.py:262-266): emb [n,E] -> rows normalised, mean, normalised -> out [E]. */
 int excel_prompt_ensemble(const float* emb, int n, int E, float* out, void* stream);
 
+/* transforms.normalize_img + the HWC->CHW transpose of the dataset (datasets/transforms.py; datasets/voc.py:115-116):
+ * hwc [B,H,W,3] uint8 (decoded image) -> out [B,3,H,W] f32 = (u8 - mean[c]) / std[c], double intermediate like numpy.  mean3/std3: HOST doubles. */
+int excel_normalize_img_u8(const unsigned char* hwc, int B, int H, int W, const double* mean3, const double* std3, float* out, void* stream);
+
 /* denormalize_img / denormalize_img2 (utils/imutils.py:11-25): img [B,3,H,W] f32 (normalised) -> v = img*std[c] + mean[c]
  * truncated to uint8 (out_u8, optional) and/or that value / 255 as float (out_f32, optional).  mean3/std3: HOST pointers to 3 floats. */
 int excel_denormalize_img(const float* img, int B, int H, int W, const float* mean3, const float* std3, unsigned char* out_u8,

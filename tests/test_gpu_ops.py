@@ -552,3 +552,16 @@ def test_denormalize_img(ops):
     assert got.dtype == np.uint8 and np.array_equal(got, ref)
     got2 = host(imutils.denormalize_img2(dev(x.astype(np.float32))))
     assert np.allclose(got2, ref.astype(np.float32) / 255.0, atol=1e-7)
+
+
+def test_normalize_img_u8(ops):
+    """datasets/transforms.normalize_img followed by the HWC->CHW transpose (datasets/voc.py:115-116), bit-exact vs numpy."""
+    rs = np.random.RandomState(2)
+    img = rs.randint(0, 256, (2, 11, 7, 3)).astype(np.uint8)
+    mean, std = [123.675, 116.28, 103.53], [58.395, 57.12, 57.375]
+    ref = np.empty(img.shape, np.float32)
+    for c in range(3):
+        ref[..., c] = (img[..., c] - mean[c]) / std[c]
+    ref = ref.transpose(0, 3, 1, 2)
+    got = host(ops.normalize_img_u8(dev(img)))
+    assert np.array_equal(got, ref)
