@@ -39,6 +39,7 @@ def get_parser():
     p.add_argument("--resize_size", default=448, type=int)
     p.add_argument("--infer_set", default="train", type=str)
     p.add_argument("--training_free", default=True, type=_bool)
+    p.add_argument("--u8_input", default=False, type=_bool, help="feed decoded uint8 HWC images and normalise on the device")
     p.add_argument("--crf_post", default=False, type=_bool, help="write the per-image logits record of tools/infer_lam.py:116-119 (api path)")
     p.add_argument("--logits_dir", default="./logits", type=str)
     p.add_argument("--num_classes", default=21, type=int)
@@ -106,6 +107,8 @@ def build_validation(model=None, par=None, dataset=None, indices=None, device="c
     for s in range(0, len(indices), bs):
         names, imgs, gts, cls = dataset.batch(indices[s:s + bs])
         inputs = torch.from_numpy(imgs).to(device, non_blocking=True)
+        if inputs.dtype == torch.uint8:                                                     # decoded images: normalise on the device
+            inputs = ops.normalize_img_u8(inputs)                                           # datasets/voc.py:115-116
         if inputs.shape[-2:] != (S, S):
             inputs = ops.bilinear_resize(inputs, S, S, align_corners=False)                 # :74
         cls_labels = torch.from_numpy(cls).to(device, non_blocking=True)
@@ -151,7 +154,7 @@ def validate(args=None):
         dist.init_process_group(backend=args.backend)                                       # :133
     device = torch.device("cuda", args.local_rank)
     dataset = synthetic.SyntheticSegDataset(args.synthetic, (args.resize_size, args.resize_size),
-                                            num_classes=args.num_classes, seed=args.seed)
+                                            num_classes=args.num_classes, seed=args.seed, u8_images=getattr(args, "u8_input", False))
     T = 45 if args.num_classes <= 21 else 103
     model = ExCEL_model(clip_model=args.model, embedding_dim=args.embedding_dim, in_channels=args.in_channels,
                         dataset_name=args.dataset_name, num_classes=args.num_classes, num_atrr_clusters=args.num_attri,

@@ -64,7 +64,10 @@ class SyntheticSegDataset:
     """Index -> (name, image [3,h,w] f32, label [H,W] u8, cls_label [F] f32), like VOC12SegDataset.__getitem__
     (datasets/voc.py:212-230).  Every sample is generated from its own seed, so shards are order independent."""
 
-    def __init__(self, n, image_hw=(448, 448), label_hw=None, num_classes=21, seed=1234, fixed_k=None):
+    def __init__(self, n, image_hw=(448, 448), label_hw=None, num_classes=21, seed=1234, fixed_k=None, u8_images=False):
+        """u8_images: samples carry the DECODED image (uint8 [h,w,3], what imageio.imread returns, datasets/voc.py:52) instead of
+        the normalised float tensor; the harness then normalises on the device (ops.normalize_img_u8)."""
+        self.u8_images = u8_images
         self.n = n
         self.image_hw = tuple(image_hw)
         self.label_hw = tuple(label_hw or image_hw)
@@ -82,6 +85,8 @@ class SyntheticSegDataset:
         rs = np.random.RandomState((self.seed * 1000003 + i) % (2 ** 31 - 1))
         F = self.num_classes - 1
         img = rs.standard_normal((3,) + self.image_hw).astype(np.float32)
+        if self.u8_images:
+            img = np.clip(img.transpose(1, 2, 0) * 58.0 + 116.0, 0, 255).astype(np.uint8)      # same stream of random numbers
         gt = rs.randint(0, self.num_classes, self.label_hw).astype(np.uint8)
         gt[rs.rand(*self.label_hw) < 0.02] = 255
         k = self.fixed_k or draw_k(rs)

@@ -242,6 +242,9 @@ def test_infer_lam_harness_single_rank(gpu):
     args2 = infer_lam.get_parser().parse_args(["--synthetic", "6", "--api_path", "true", "--resize_size", "448"])
     score2, total2 = infer_lam.validate(args2)
     assert np.abs(host(total) - host(total2)).sum() <= 1e-4 * host(total).sum()      # batched == per-image API path
+    args3 = infer_lam.get_parser().parse_args(["--synthetic", "4", "--batch_size", "4", "--resize_size", "448", "--u8_input", "true"])
+    score3, total3 = infer_lam.validate(args3)                                       # decoded uint8 images, normalised on the device
+    assert int(host(total3).sum()) > 0 and 0.0 <= score3["miou"] <= 1.0
 
 
 # ------------------------------------------------------------------ COCO-shaped config (BASELINE configs[4] shapes) and flip / multi-scale LAMs
