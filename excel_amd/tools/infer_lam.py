@@ -39,6 +39,8 @@ def get_parser():
     p.add_argument("--resize_size", default=448, type=int)
     p.add_argument("--infer_set", default="train", type=str)
     p.add_argument("--training_free", default=True, type=_bool)
+    p.add_argument("--data_folder", default=None, type=str, help="VOC2012 root (JPEGImages/, SegmentationClassAug/): real data instead of --synthetic")
+    p.add_argument("--list_folder", default=None, type=str, help="directory with <infer_set>.txt and cls_labels_onehot.npy")
     p.add_argument("--u8_input", default=False, type=_bool, help="feed decoded uint8 HWC images and normalise on the device")
     p.add_argument("--crf_post", default=False, type=_bool, help="write the per-image logits record of tools/infer_lam.py:116-119 (api path)")
     p.add_argument("--logits_dir", default="./logits", type=str)
@@ -153,8 +155,13 @@ def validate(args=None):
     if world > 1 and not dist.is_initialized():
         dist.init_process_group(backend=args.backend)                                       # :133
     device = torch.device("cuda", args.local_rank)
-    dataset = synthetic.SyntheticSegDataset(args.synthetic, (args.resize_size, args.resize_size),
-                                            num_classes=args.num_classes, seed=args.seed, u8_images=getattr(args, "u8_input", False))
+    if getattr(args, "data_folder", None):
+        from ..datasets import voc                                                          # :156-163 (variable image sizes -> batch 1, :167)
+        dataset = voc.VOC12SegDataset(root_dir=args.data_folder, name_list_dir=args.list_folder, split=args.infer_set, stage="val")
+        args.batch_size = 1
+    else:
+        dataset = synthetic.SyntheticSegDataset(args.synthetic, (args.resize_size, args.resize_size),
+                                                num_classes=args.num_classes, seed=args.seed, u8_images=getattr(args, "u8_input", False))
     T = 45 if args.num_classes <= 21 else 103
     model = ExCEL_model(clip_model=args.model, embedding_dim=args.embedding_dim, in_channels=args.in_channels,
                         dataset_name=args.dataset_name, num_classes=args.num_classes, num_atrr_clusters=args.num_attri,

@@ -753,3 +753,39 @@ def test_validation_engine_with_decoder(gpu, golden):
     ref_seg = oracle.evaluate.scores_from_hist(oracle.evaluate.fast_hist(gt[0].flatten(), seg_lab[0].flatten(), 5))
     assert abs(aff_score["miou"] - ref_aff["miou"]) < 2e-3 and abs(seg_score["miou"] - ref_seg["miou"]) < 2e-3
     assert abs(seg_score["pAcc"] - ref_seg["pAcc"]) < 2e-3
+
+
+def test_infer_lam_on_disk_voc(gpu, tmp_path):
+    """tools/infer_lam.py over an on-disk VOC-format tree (JPEG + palette PNG + id list + one-hot dict): decode on the host,
+    normalise / resize / everything else on the device; batched pipeline == per-image API path."""
+    from PIL import Image
+    from excel_amd.tools import infer_lam
+    from excel_amd.utils import imutils
+    root, lists = tmp_path / "VOC2012", tmp_path / "lists"
+    (root / "JPEGImages").mkdir(parents=True)
+    (root / "SegmentationClassAug").mkdir()
+    lists.mkdir()
+    rs = np.random.RandomState(3)
+    ids, onehot, npix = ["2008_000001", "2008_000002", "2008_000003"], {}, 0
+    for k, name in enumerate(ids):
+        h, w = 90 + 10 * k, 120 - 8 * k
+        Image.fromarray(rs.randint(0, 256, (h, w, 3)).astype(np.uint8)).save(root / "JPEGImages" / (name + ".jpg"), quality=90)
+        lab = rs.randint(0, 21, (h, w)).astype(np.uint8)
+        lab[:2] = 255
+        npix += int((lab < 21).sum())
+        im = Image.fromarray(lab, mode="P")
+        im.putpalette(imutils.colormap().flatten().tolist())
+        im.save(root / "SegmentationClassAug" / (name + ".png"))
+        oh = np.zeros(20, np.float32)
+        oh[[k, 11]] = 1
+        onehot[name] = oh
+    (lists / "val.txt").write_text("\n".join(ids) + "\n")
+    np.save(lists / "cls_labels_onehot.npy", onehot)
+    common = ["--data_folder", str(root), "--list_folder", str(lists), "--infer_set", "val", "--resize_size", "448"]
+    score, total = infer_lam.validate(infer_lam.get_parser().parse_args(common))
+    assert int(host(total).sum()) == npix and 0.0 <= score["miou"] <= 1.0
+    score2, total2 = infer_lam.validate(infer_lam.get_parser().parse_args(common + ["--api_path", "true", "--crf_post", "true",
+                                                                               "--logits_dir", str(tmp_path / "logits")]))
+    assert np.abs(host(total) - host(total2)).sum() <= 1e-3 * npix
+    lam, keys = imutils.load_logits(str(tmp_path / "logits" / (ids[2] + ".npy")))
+    assert lam.shape == (3, 110, 104) and list(keys) == [2, 11]

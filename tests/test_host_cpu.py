@@ -240,3 +240,44 @@ def test_bpe_tokenizer_matches_reference_ids(golden):
     with pytest.raises(RuntimeError):
         bpe.tokenize(["word " * 100], tk)
     assert bpe.tokenize(["word " * 100], tk, truncate=True)[0, -1] == 49407
+
+
+def test_voc_on_disk_dataset(tmp_path):
+    """datasets/voc.py input format: id list, JPEG image, palette PNG label, pickled one-hot dict."""
+    from PIL import Image
+    from excel_amd.datasets import voc
+    from excel_amd.utils import imutils
+    root, lists = tmp_path / "VOC2012", tmp_path / "lists"
+    (root / "JPEGImages").mkdir(parents=True)
+    (root / "SegmentationClassAug").mkdir()
+    lists.mkdir()
+    rs = np.random.RandomState(0)
+    ids, onehot = ["2007_000033", "2007_000042"], {}
+    pal = imutils.colormap().flatten().tolist()
+    for k, name in enumerate(ids):
+        img = rs.randint(0, 256, (20 + k, 24, 3)).astype(np.uint8)
+        Image.fromarray(img).save(root / "JPEGImages" / (name + ".jpg"), quality=95)
+        lab = rs.randint(0, 21, (20 + k, 24)).astype(np.uint8)
+        lab[0, :3] = 255
+        im = Image.fromarray(lab, mode="P")
+        im.putpalette(pal)
+        im.save(root / "SegmentationClassAug" / (name + ".png"))
+        oh = np.zeros(20, np.float32)
+        oh[[k, 7]] = 1
+        onehot[name] = oh
+        np.save(tmp_path / f"lab{k}.npy", lab)
+    (lists / "val.txt").write_text("\n".join(ids) + "\n")
+    np.save(lists / "cls_labels_onehot.npy", onehot)
+    ds = voc.VOC12SegDataset(str(root), str(lists), split="val", stage="val")
+    assert len(ds) == 2 and voc.class_list[15] == "person"
+    name, image, label, cls = ds[1]
+    assert name == ids[1] and image.shape == (21, 24, 3) and image.dtype == np.uint8
+    assert np.array_equal(label, np.load(tmp_path / "lab1.npy")) and label[0, 0] == 255        # palette PNG -> index map
+    assert np.array_equal(cls, onehot[ids[1]])
+    assert np.array_equal(image, np.asarray(Image.open(root / "JPEGImages" / (ids[1] + ".jpg"))))
+    names, imgs, gts, clss = ds.batch([0])
+    assert imgs.shape == (1, 20, 24, 3) and gts.shape == (1, 20, 24) and clss.shape == (1, 20)
+    with pytest.raises(ValueError):
+        ds.batch([0, 1])
+    t = voc.VOC12SegDataset(str(root), str(lists), split="val", stage="test")
+    assert t[0][3].sum() == 0
