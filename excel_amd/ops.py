@@ -331,6 +331,19 @@ def prompt_ensemble(class_embeddings):
     return out
 
 
+def train_losses(seg, attn_pred, pseudo_u8, radius=8, ignore_index=255, w_seg=1.0, w_diver=0.1):
+    """scripts/train_voc.py:202-215 -> (losses [2] = (seg_loss, diver_loss), d_seg, d_attn_pred)."""
+    seg, attn_pred = f32c(seg), f32c(attn_pred)
+    B, nc, gh, gw = seg.shape
+    H, W = pseudo_u8.shape[-2:]
+    losses = torch.empty((2,), dtype=torch.float32, device=seg.device)
+    d_seg, d_ap = torch.empty_like(seg), torch.empty_like(attn_pred)
+    ws = _ws(lib().excel_train_losses_workspace_bytes(B, nc, H, W), seg.device)
+    check(lib().excel_train_losses(_p(seg), _p(attn_pred), _p(pseudo_u8.contiguous(), torch.uint8), B, nc, gh, gw, H, W, radius, ignore_index,
+                                   float(w_seg), float(w_diver), _p(losses), _p(d_seg), _p(d_ap), _p(ws, torch.uint8), _stream()), "excel_train_losses")
+    return losses, d_seg, d_ap
+
+
 def normalize_img_u8(hwc_u8, mean=(123.675, 116.28, 103.53), std=(58.395, 57.12, 57.375)):
     """datasets/transforms.normalize_img + HWC->CHW on the device: uint8 [B,H,W,3] -> f32 [B,3,H,W] (3 B/pixel over PCIe instead of 12)."""
     x = hwc_u8.contiguous()

@@ -168,6 +168,18 @@ int excel_text_encode(excel_text_t h, const int32_t* tokens, int B, float* out, 
 /* encode_text_with_prompt_ensemble's reduction (clip/clip.py:262-266): emb [n,E] -> rows normalised, mean, normalised -> out [E]. */
 int excel_prompt_ensemble(const float* emb, int n, int E, float* out, void* stream);
 
+/* ------------------------------------------------------------------ training iteration of the decoder
+ * Losses of scripts/train_voc.py:202-215 and their gradients:
+ *   seg [B,nc,g_h,g_w] -> bilinear (align_corners=False) to (H,W) -> get_seg_loss (model/losses.py:4-18) against pseudo [B,H,W] u8
+ *   attn_pred [B,P,P] -> get_aff_loss (model/losses.py:20-31) against cams_to_affinity_label(pseudo, get_mask_by_radius(g,g,radius))
+ *                        (utils/camutils.py:438-476; nearest down-sampling by H/g_h, 255 outside the window / on ignored tokens)
+ *   losses[0] = seg_loss, losses[1] = aff ("diver") loss (device floats); d_seg, d_attn_pred = gradients of
+ *   w_seg*seg_loss + w_diver*aff_loss.  Fixed-order reductions: reproducible. */
+size_t excel_train_losses_workspace_bytes(int B, int nc, int H, int W);
+int excel_train_losses(const float* seg, const float* attn_pred, const unsigned char* pseudo, int B, int nc, int g_h, int g_w, int H, int W,
+                       int radius, int ignore_index, float w_seg, float w_diver, float* losses, float* d_seg, float* d_attn_pred,
+                       void* workspace, void* stream);
+
 /* transforms.normalize_img + the HWC->CHW transpose of the dataset (datasets/transforms.py; datasets/voc.py:115-116):
  * hwc [B,H,W,3] uint8 (decoded image) -> out [B,3,H,W] f32 = (u8 - mean[c]) / std[c], double intermediate like numpy.  mean3/std3: HOST doubles. */
 int excel_normalize_img_u8(const unsigned char* hwc, int B, int H, int W, const double* mean3, const double* std3, float* out, void* stream);

@@ -347,8 +347,84 @@ def gold_text():
     save("text_tiny.npz", tokens=tok, out=out, ensemble=ens, texts=np.array(texts), token_ids=ids, **sd)
 
 
+# ---------------------------------------------------------------- 8. one training iteration of the decoder
+def gold_train():
+    """scripts/train_voc.py:186-220 with the reference's own modules, losses, affinity labels and optimizer: losses, the
+    gradients autograd gives for every decoder parameter (and w.r.t. seg / attn_pred), and the parameters after two
+    PolyWarmupAdamW steps."""
+    mm, mc = types.ModuleType("mmcv"), types.ModuleType("mmcv.cnn")
+    mc.ConvModule = object
+    mm.cnn = mc
+    sys.modules.setdefault("mmcv", mm)
+    sys.modules.setdefault("mmcv.cnn", mc)
+    from model.segformer_head import SegFormerHead
+    from model.decoder.TransDecoder import DecoderTransformer
+    losses = _load_by_path("ref_losses", os.path.join(REF, "model/losses.py"))
+    glb = {"torch": torch, "F": F, "np": np}
+    cams_to_affinity_label, get_mask_by_radius = None, None
+    # camutils.py imports torchvision via imutils: take the two pure functions from the reference text (the LAST definition of
+    # cams_to_affinity_label, :438, is the one Python binds)
+    tree = ast.parse(open(os.path.join(REF, "utils/camutils.py")).read())
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("cams_to_affinity_label", "get_mask_by_radius")]
+    exec(compile(ast.Module(body=body, type_ignores=[]), "camutils", "exec"), glb)
+    cams_to_affinity_label, get_mask_by_radius = glb["cams_to_affinity_label"], glb["get_mask_by_radius"]
+    if not hasattr(np, "float"):
+        np.float = float                                       # utils/optimizer.py:12 predates numpy 1.24
+    ropt = _load_by_path("ref_optimizer", os.path.join(REF, "utils/optimizer.py"))
+
+    g = np.load(os.path.join(HERE, "decoder_tiny.npz"))
+    all_feats = torch.from_numpy(g["all_feats"])
+    torch.manual_seed(7)
+    fuse = SegFormerHead(in_channels=128, embedding_dim=32, num_classes=5, index=8)
+    dec = DecoderTransformer(width=32, layers=3, heads=8, output_dim=5)
+    fuse.eval(); dec.eval()                                    # dropout off: deterministic (the head has Dropout2d(0.1) in train mode)
+    rs = np.random.RandomState(77)
+    b, h, wd = 2, 96, 96
+    pseudo = rs.randint(0, 5, (b, h, wd)).astype(np.int64)
+    pseudo[rs.rand(b, h, wd) < 0.1] = 255
+    pseudo_t = torch.from_numpy(pseudo)
+    params = list(dec.parameters()) + list(fuse.parameters())  # model_excel.py:40-45 (group 3)
+    optim = ropt.PolyWarmupAdamW(params=[{"params": [], "lr": 1e-4, "weight_decay": 1e-2}, {"params": [], "lr": 1e-4, "weight_decay": 1e-2},
+                                         {"params": [], "lr": 1e-3, "weight_decay": 1e-2}, {"params": params, "lr": 1e-3, "weight_decay": 1e-2}],
+                                 lr=1e-4, weight_decay=1e-2, betas=(0.9, 0.999), warmup_iter=50, max_iter=1000, warmup_ratio=1e-6, power=1)
+    out = {}
+    torch.set_grad_enabled(True)                               # __main__ runs the generators under no_grad
+    for it in range(2):
+        tok = all_feats[:, :, 1:, ...].permute(0, 1, 3, 2).reshape(8, b, 128, h // 16, wd // 16)
+        fts = fuse(tok)
+        seg, _ = dec(fts)
+        fl = F.normalize(fts.reshape(b, 32, -1), dim=1)
+        ap = fl.transpose(2, 1).bmm(fl)
+        ap = torch.sigmoid((ap - torch.mean(ap) * 1.) * 3.0)
+        seg.retain_grad(); ap.retain_grad(); fts.retain_grad()
+        segs = F.interpolate(seg, size=(h, wd), mode="bilinear", align_corners=False)              # train_voc.py:202
+        seg_loss = losses.get_seg_loss(segs, pseudo_t, ignore_index=255)                           # :203
+        attn_mask = get_mask_by_radius(h=h // 16, w=wd // 16, radius=2)                             # :207-208
+        aff_mask = cams_to_affinity_label(pseudo_t, mask=attn_mask)                                 # :210
+        diver_loss, pos_c, neg_c = losses.get_aff_loss(ap, aff_mask)                                # :212
+        loss = 1.0 * seg_loss + 0.1 * diver_loss                                                   # :215
+        optim.zero_grad()
+        loss.backward()
+        if it == 0:
+            out.update(seg=seg.detach().clone(), attn_pred=ap.detach().clone(), seg_loss=seg_loss.detach(), diver_loss=diver_loss.detach(),
+                       aff_mask=aff_mask.numpy().astype(np.int16), attn_mask=attn_mask.astype(np.uint8), pos_count=int(pos_c), neg_count=int(neg_c),
+                       d_seg=seg.grad.clone(), d_attn_pred=ap.grad.clone(), d_fts=fts.grad.clone())
+            out.update({"w0.fuse." + k: v.detach().clone() for k, v in fuse.state_dict().items()})
+            out.update({"w0.dec." + k: v.detach().clone() for k, v in dec.state_dict().items()})
+            out.update({"g.fuse." + k: v.grad.clone() for k, v in fuse.named_parameters()})
+            out.update({"g.dec." + k: v.grad.clone() for k, v in dec.named_parameters()})
+        else:
+            out.update(seg_loss_it1=seg_loss.detach(), diver_loss_it1=diver_loss.detach())
+        optim.step()
+        out.update({f"w{it + 1}.fuse." + k: v.detach().clone() for k, v in fuse.state_dict().items()})
+        out.update({f"w{it + 1}.dec." + k: v.detach().clone() for k, v in dec.state_dict().items()})
+        out[f"lr_it{it}"] = optim.param_groups[3]["lr"]
+    torch.set_grad_enabled(False)
+    save("train_tiny.npz", pseudo=pseudo.astype(np.uint8), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["vit_cam", "ops", "attr", "pipeline", "lvc", "decoder", "text"]       # e.g. `make_goldens.py lvc` mints one file
+    which = sys.argv[1:] or ["vit_cam", "ops", "attr", "pipeline", "lvc", "decoder", "text", "train"]       # e.g. `make_goldens.py lvc` mints one file
     with torch.no_grad():
         for name in which:
             globals()["gold_" + name]()
