@@ -2,19 +2,7 @@
 // (model/decoder/TransDecoder.py:62-124) over the ViT's per-block features.  A small model (width 256, 3 layers, 8 heads of
 // 32): orchestration of the exact-fp32 matrix-core GEMM with a row softmax in between; scores are materialised
 // ([B*heads, P, P] fp32, 0.6 GB at B=32, 448^2) -- at ~7 % of the ViT's flops this head is not worth a fused kernel yet.
-#include <vector>
-#include "common.h"
-#include "excel_internal.h"
-#include "../../include/excel_hip.h"
-
-static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-
-struct excel_decoder {
-    excel_decoder_config cfg;
-    std::vector<excel_fuse_layer_weights> fuse;
-    std::vector<excel_decoder_block_weights> blocks;
-    excel_decoder_weights w;
-};
+#include "decoder_internal.h"
 
 // in-place softmax over rows of length P stored with pitch Pp (pad columns are zeroed: they are the K tail of P.V)
 // causal: row q (= row index modulo P) attends to keys 0..q only (the additive -inf mask of build_attention_mask,
@@ -35,8 +23,8 @@ __global__ __launch_bounds__(256) void dec_row_softmax_kernel(float* __restrict_
     for (int i = lane; i < Pp; i += 64) r[i] = i < n ? expf(r[i] - m) * inv : 0.f;
 }
 
-// [B, R, Cc] (pitch ld) -> [B, Cc, R]   (token-major -> channel-major maps)
-__global__ __launch_bounds__(256) void dec_transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cc, int ld) {
+// [B, R, Cc] (pitch ld) -> [B, Cc, Rp]   (token-major -> channel-major maps; columns r >= R of the output are zero-filled)
+__global__ __launch_bounds__(256) void dec_transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cc, int ld, int Rp) {
     __shared__ float tile[32][33];
     const int b = blockIdx.z, r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -47,19 +35,20 @@ __global__ __launch_bounds__(256) void dec_transpose_kernel(const float* __restr
     __syncthreads();
     for (int j = ty; j < 32; j += 8) {
         const int c = c0 + j, r = r0 + tx;
-        if (c < Cc && r < R) out[((long long)b * Cc + c) * R + r] = tile[tx][j];
+        if (c < Cc && r < Rp) out[((long long)b * Cc + c) * Rp + r] = tile[tx][j];
     }
 }
 
-static GemmArgs ga0(const float* A, const float* B, float* C, const float* bias, const float* res, int M, int N, int K, int lda, int ldb,
-                    int ldc, int ldr, int act) {
-    GemmArgs g;
-    memset(&g, 0, sizeof(g));
-    g.A = A; g.B = B; g.C = C; g.bias = bias; g.res = res;
-    g.M = M; g.N = N; g.K = K; g.Kld = (K + 3) / 4 * 4;
-    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldr = ldr;
-    g.act = act; g.out_mode = GEMM_OUT_PLAIN; g.alpha = 1.f; g.zdiv = 1;
-    return g;
+int excel_launch_dec_transpose(const float* in, float* out, int B, int R, int Cc, int ld, int Rp, hipStream_t st) {
+    hipLaunchKernelGGL(dec_transpose_kernel, dim3(cdiv(Rp, 32), cdiv(Cc, 32), B), dim3(256), 0, st, in, out, R, Cc, ld, Rp);
+    EXCEL_CHECK_LAUNCH("dec_transpose");
+    return EXCEL_OK;
+}
+
+int excel_launch_dec_softmax(float* s, long long rows, int P, int Pp, int causal, hipStream_t st) {
+    hipLaunchKernelGGL(dec_row_softmax_kernel, dim3((unsigned)cdivl(rows, 4)), dim3(256), 0, st, s, rows, P, Pp, causal);
+    EXCEL_CHECK_LAUNCH("dec_softmax");
+    return EXCEL_OK;
 }
 
 struct DecWs {
@@ -88,8 +77,6 @@ static DecWs dec_ws_layout(const excel_decoder_config& c, int B, int g, char* ba
     w.total = off;
     return w;
 }
-
-#define TRYD(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
 
 // Stack of pre-LN residual blocks (nn.MultiheadAttention + QuickGELU MLP): x [B*P, E] updated in place.
 // Shared by the decoder head (TransDecoder.py:62-84) and the CLIP text tower (clip_surgery_model.py:285-337 with the causal mask).
@@ -176,7 +163,7 @@ extern "C" int excel_decoder_forward(excel_decoder_t h, const float* all_feats, 
     GemmArgs fz = ga0(ws.cat, h->w.fuse_w, ws.x, h->w.fuse_b, nullptr, M, E, L * E, L * E, L * E, E, 0, GEMM_ACT_NONE);
     TRYD(excel_launch_gemm(fz, true, 1, st));                                   // :74 (dropout inactive in eval)
     if (attn_fts_out) {
-        hipLaunchKernelGGL(dec_transpose_kernel, dim3(cdiv(P, 32), cdiv(E, 32), B), dim3(256), 0, st, ws.x, attn_fts_out, P, E, E);
+        hipLaunchKernelGGL(dec_transpose_kernel, dim3(cdiv(P, 32), cdiv(E, 32), B), dim3(256), 0, st, ws.x, attn_fts_out, P, E, E, P);
         EXCEL_CHECK_LAUNCH("decoder/attn_fts");
     }
     if (!seg_out) return EXCEL_OK;
@@ -185,7 +172,7 @@ extern "C" int excel_decoder_forward(excel_decoder_t h, const float* all_feats, 
     TRYD(preln_blocks(h->blocks.data(), c.dec_layers, ws.x, ws.y, ws.qkv, ws.s, ws.ao, ws.hb, B, P, ws.Pp, E, H, 0, st));
     GemmArgs lp = ga0(ws.x, h->w.pred_w, ws.segt, h->w.pred_b, nullptr, M, nc, E, E, E, ws.ncp, 0, GEMM_ACT_NONE);   // linear_pred (:122)
     TRYD(excel_launch_gemm(lp, true, 1, st));
-    hipLaunchKernelGGL(dec_transpose_kernel, dim3(cdiv(P, 32), cdiv(nc, 32), B), dim3(256), 0, st, ws.segt, seg_out, P, nc, ws.ncp);
+    hipLaunchKernelGGL(dec_transpose_kernel, dim3(cdiv(P, 32), cdiv(nc, 32), B), dim3(256), 0, st, ws.segt, seg_out, P, nc, ws.ncp, P);
     EXCEL_CHECK_LAUNCH("decoder/seg");
     return EXCEL_OK;
 }

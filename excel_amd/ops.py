@@ -243,6 +243,61 @@ class DecoderHandle:
         except Exception:
             pass
 
+    # ------------------------------------------------------------------ training iteration
+    def _grad_table(self):
+        """Gradient tensors shaped like the parameters + the C table pointing at them (built once)."""
+        if getattr(self, "_grads", None) is None:
+            self._grads = {k: torch.zeros_like(v) for k, v in self.t.items()}
+            c = self.cfg
+            self._gfuse = (_lib.FuseLayerWeights * c["vit_layers"])()
+            for l in range(c["vit_layers"]):
+                for f in ("proj_w", "proj_b", "proj2_w", "proj2_b"):
+                    setattr(self._gfuse[l], f, self._grads[f"fuse{l}.{f}"].data_ptr())
+            self._gblocks = (_lib.DecoderBlockWeights * max(c["dec_layers"], 1))()
+            for l in range(c["dec_layers"]):
+                for f in _BLOCK_KEYS:
+                    setattr(self._gblocks[l], f, self._grads[f"blk{l}.{f}"].data_ptr())
+            g = _lib.DecoderWeights()
+            g.fuse, g.blocks = self._gfuse, self._gblocks
+            for f in ("fuse_w", "fuse_b", "pred_w", "pred_b"):
+                setattr(g, f, self._grads[f].data_ptr())
+            self._gtable = g
+        return self._grads, self._gtable
+
+    def forward_train(self, all_feats):
+        """-> (seg [B,nc,g,g], attn_pred [B,P,P], ctx) ; ctx goes to backward()."""
+        all_feats = f32c(all_feats)
+        L, B, N, D = all_feats.shape
+        g = int(round((N - 1) ** 0.5))
+        c = self.cfg
+        dev = all_feats.device
+        seg = torch.empty((B, c["num_classes"], g, g), dtype=torch.float32, device=dev)
+        ap = torch.empty((B, g * g, g * g), dtype=torch.float32, device=dev)
+        need = lib().excel_decoder_train_workspace_bytes(self._h, B, g)
+        ws = _ws(need, dev)
+        check(lib().excel_decoder_forward_train(self._h, _p(all_feats), B, g, _p(ws, torch.uint8), need, _p(seg), _p(ap), _stream()),
+              "excel_decoder_forward_train")
+        return seg, ap, (all_feats, B, g, ws, need)
+
+    def backward(self, ctx, d_seg, d_attn_pred=None):
+        """-> dict of gradients keyed like self.t (fuse{l}.proj_w ..., blk{l}.fc1_w ..., fuse_w, pred_w ...)."""
+        all_feats, B, g, ws, need = ctx
+        grads, table = self._grad_table()
+        check(lib().excel_decoder_backward(self._h, _p(all_feats), B, g, _p(ws, torch.uint8), need, _p(f32c(d_seg)),
+                                           _p(f32c(d_attn_pred)) if d_attn_pred is not None else None, C.byref(table), _stream()),
+              "excel_decoder_backward")
+        return grads
+
+    def adamw_step(self, lr, step, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        """torch.optim.AdamW over every parameter with the gradients of the last backward(); `step` counts from 1."""
+        grads, _ = self._grad_table()
+        if getattr(self, "_adam", None) is None:
+            self._adam = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in self.t.items()}
+        for k, p in self.t.items():
+            m, v = self._adam[k]
+            check(lib().excel_adamw_step(_p(p), _p(grads[k]), _p(m), _p(v), p.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                         float(weight_decay), int(step), _stream()), "excel_adamw_step")
+
     def forward(self, all_feats, want_seg=True):
         """all_feats [L,B,N,D] -> (attn_fts [B,E,g,g], seg [B,nc,g,g] | None)"""
         all_feats = f32c(all_feats)

@@ -180,6 +180,21 @@ int excel_train_losses(const float* seg, const float* attn_pred, const unsigned 
                        int radius, int ignore_index, float w_seg, float w_diver, float* losses, float* d_seg, float* d_attn_pred,
                        void* workspace, void* stream);
 
+/* The decoder head in training mode (SegFormerHead + DecoderTransformer + attn_pred, model/model_excel.py:60-76), exact fp32:
+ *   forward_train keeps the activations in `workspace` and returns seg [B,nc,g,g] and attn_pred [B,P,P];
+ *   backward (same all_feats / workspace) writes d loss / d parameter for every parameter into `grads`, a table with the layout
+ *   of the weights whose pointers are WRITTEN (device memory of each parameter's shape); d_attn_pred may be NULL.
+ *   The head's Dropout2d (segformer_head.py:66,75) is an identity (deterministic step).  g*g must be a multiple of 4.
+ * excel_adamw_step: torch.optim.AdamW update of one tensor (decoupled weight decay, bias correction with `step` >= 1), the
+ * arithmetic under utils/optimizer.py's PolyWarmupAdamW; the learning-rate schedule stays on the host. */
+size_t excel_decoder_train_workspace_bytes(excel_decoder_t h, int B, int g);
+int excel_decoder_forward_train(excel_decoder_t h, const float* all_feats, int B, int g, void* workspace, size_t workspace_bytes,
+                                float* seg_out, float* attn_pred_out, void* stream);
+int excel_decoder_backward(excel_decoder_t h, const float* all_feats, int B, int g, void* workspace, size_t workspace_bytes,
+                           const float* d_seg, const float* d_attn_pred, const excel_decoder_weights* grads, void* stream);
+int excel_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, int step, void* stream);
+
 /* transforms.normalize_img + the HWC->CHW transpose of the dataset (datasets/transforms.py; datasets/voc.py:115-116):
  * hwc [B,H,W,3] uint8 (decoded image) -> out [B,3,H,W] f32 = (u8 - mean[c]) / std[c], double intermediate like numpy.  mean3/std3: HOST doubles. */
 int excel_normalize_img_u8(const unsigned char* hwc, int B, int H, int W, const double* mean3, const double* std3, float* out, void* stream);
