@@ -247,7 +247,13 @@ class DecoderHandle:
     def _grad_table(self):
         """Gradient tensors shaped like the parameters + the C table pointing at them (built once)."""
         if getattr(self, "_grads", None) is None:
-            self._grads = {k: torch.zeros_like(v) for k, v in self.t.items()}
+            # one flat buffer (each parameter's gradient is a 16-byte aligned view): a data-parallel step is ONE all-reduce
+            offs, total = {}, 0
+            for k, v in self.t.items():
+                offs[k] = total
+                total += (v.numel() + 3) // 4 * 4
+            self.grad_flat = torch.zeros(total, dtype=torch.float32, device=self.device)
+            self._grads = {k: self.grad_flat[offs[k]:offs[k] + v.numel()].view(v.shape) for k, v in self.t.items()}
             c = self.cfg
             self._gfuse = (_lib.FuseLayerWeights * c["vit_layers"])()
             for l in range(c["vit_layers"]):

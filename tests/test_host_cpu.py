@@ -281,3 +281,45 @@ def test_voc_on_disk_dataset(tmp_path):
         ds.batch([0, 1])
     t = voc.VOC12SegDataset(str(root), str(lists), split="val", stage="test")
     assert t[0][3].sum() == 0
+
+
+# ------------------------------------------------------------------ training iteration: schedule + gradient averaging (N > 1 on gloo)
+def test_poly_warmup_schedule_known_answers():
+    """utils/optimizer.py PolyWarmupAdamW.step: warm-up lr_mult = 1 - (1 - s/W)(1 - ratio), then (1 - s/max)^power."""
+    from excel_amd.scripts.train_voc import poly_warmup_lr
+    base = 1e-3
+    assert abs(poly_warmup_lr(base, 0, 50, 1000, 1e-6, 1) - 1e-9) < 1e-15
+    assert abs(poly_warmup_lr(base, 1, 50, 1000, 1e-6, 1) - 2.000098e-05) < 1e-12          # value logged by the reference optimizer
+    assert abs(poly_warmup_lr(base, 25, 50, 1000, 1e-6, 1) - base * (1 - 0.5 * (1 - 1e-6))) < 1e-15
+    assert abs(poly_warmup_lr(base, 50, 50, 1000, 1e-6, 1) - base * 0.95) < 1e-15
+    assert abs(poly_warmup_lr(base, 500, 50, 1000, 1e-6, 2) - base * 0.25) < 1e-15
+
+
+def _grad_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from excel_amd.scripts.train_voc import allreduce_mean_
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    flat = torch.arange(10, dtype=torch.float32) * (rank + 1)
+    allreduce_mean_(flat)
+    q.put((rank, flat.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_mean_world2():
+    """The one collective of a data-parallel training step: DistributedDataParallel's mean over the flat gradient buffer."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for _, flat in res:
+        assert np.allclose(flat, np.arange(10, dtype=np.float32) * 1.5)
