@@ -340,11 +340,11 @@ extern "C" int excel_vit_forward_ex(excel_vit_t h, const float* img, int B, int 
 
 extern "C" size_t excel_train_losses_workspace_bytes(int B, int nc, int H, int W) { return excel_train_losses_ws_bytes(B, nc, H, W); }
 
-extern "C" int excel_train_losses(const float* seg, const float* attn_pred, const unsigned char* pseudo, int B, int nc, int g_h, int g_w, int H, int W,
-                                  int radius, int ignore_index, float w_seg, float w_diver, float* losses, float* d_seg, float* d_attn_pred,
-                                  void* workspace, void* stream) {
-    return excel_launch_train_losses(seg, attn_pred, pseudo, B, nc, g_h, g_w, H, W, radius, ignore_index, w_seg, w_diver, losses, d_seg, d_attn_pred,
-                                     workspace, ST(stream));
+extern "C" int excel_train_losses(const float* seg, const float* attn_pred, const unsigned char* pseudo, const unsigned char* aff_labels, int B, int nc,
+                                  int g_h, int g_w, int H, int W, int radius, int ignore_index, float w_seg, float w_diver, float* losses,
+                                  float* d_seg, float* d_attn_pred, void* workspace, void* stream) {
+    return excel_launch_train_losses(seg, attn_pred, pseudo, aff_labels, B, nc, g_h, g_w, H, W, radius, ignore_index, w_seg, w_diver, losses, d_seg,
+                                     d_attn_pred, workspace, ST(stream));
 }
 
 extern "C" int excel_normalize_img_u8(const unsigned char* hwc, int B, int H, int W, const double* mean3, const double* std3, float* out, void* stream) {

@@ -92,9 +92,9 @@ int excel_launch_denormalize(const float* img, unsigned char* out8, float* outf,
 int excel_launch_normalize_u8(const unsigned char* hwc, float* out, int B, long long HW, const double* mean, const double* stdv, hipStream_t st);
 // training step (train.hip)
 size_t excel_train_losses_ws_bytes(int B, int nc, int H, int W);
-int excel_launch_train_losses(const float* seg, const float* attn_pred, const unsigned char* pseudo, int B, int nc, int g_h, int g_w, int H, int W,
-                              int radius, int ignore, float w_seg, float w_diver, float* losses, float* d_seg, float* d_attn_pred, void* ws,
-                              hipStream_t st);
+int excel_launch_train_losses(const float* seg, const float* attn_pred, const unsigned char* pseudo, const unsigned char* aff_labels, int B, int nc,
+                              int g_h, int g_w, int H, int W, int radius, int ignore, float w_seg, float w_diver, float* losses, float* d_seg,
+                              float* d_attn_pred, void* ws, hipStream_t st);
 // LVC side (lvc.hip)
 size_t excel_feature_affinity_ws_bytes(int B, int C, int P);
 int excel_launch_feature_affinity(const float* feats, int B, int C, int P, float beta, float gamma, int mode, float* out, void* ws,

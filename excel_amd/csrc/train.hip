@@ -180,9 +180,10 @@ size_t excel_train_losses_ws_bytes(int B, int nc, int H, int W) {
     return align_up((size_t)B * nc * H * W * sizeof(float), 256) + align_up((size_t)TR_NPART * 4 * sizeof(double), 256) + 256;
 }
 
-int excel_launch_train_losses(const float* seg, const float* attn_pred, const unsigned char* pseudo, int B, int nc, int g_h, int g_w, int H, int W,
-                              int radius, int ignore, float w_seg, float w_diver, float* losses, float* d_seg, float* d_attn_pred, void* ws,
-                              hipStream_t st) {
+int excel_launch_train_losses(const float* seg, const float* attn_pred, const unsigned char* pseudo, const unsigned char* aff_labels, int B, int nc,
+                              int g_h, int g_w, int H, int W, int radius, int ignore, float w_seg, float w_diver, float* losses, float* d_seg,
+                              float* d_attn_pred, void* ws, hipStream_t st) {
+    if (!aff_labels) aff_labels = pseudo;
     ProfScope prof__(PROF_OTHER, st);
     EXCEL_CHECK_ARG(seg && attn_pred && pseudo && losses && d_seg && d_attn_pred && ws, "train_losses: null argument");
     EXCEL_CHECK_ARG(B > 0 && nc > 1 && g_h > 0 && g_w > 0 && H % g_h == 0 && W % g_w == 0 && H / g_h == W / g_w, "train_losses: label size must be a multiple of the token grid");
@@ -202,9 +203,9 @@ int excel_launch_train_losses(const float* seg, const float* attn_pred, const un
     hipLaunchKernelGGL(tr_bilinear_adjoint_kernel, dim3(g_h * g_w, B * nc), dim3(64), 0, st, up, d_seg, g_h, g_w, H, W);
     const long long na = (long long)B * g_h * g_w * g_h * g_w;
     const int np2 = (int)min((long long)TR_NPART, cdivl(na, 1024));
-    hipLaunchKernelGGL(tr_aff_reduce_kernel, dim3(np2), dim3(256), 0, st, attn_pred, pseudo, B, g_h, g_w, H, W, radius, ignore, partial);
+    hipLaunchKernelGGL(tr_aff_reduce_kernel, dim3(np2), dim3(256), 0, st, attn_pred, aff_labels, B, g_h, g_w, H, W, radius, ignore, partial);
     hipLaunchKernelGGL(tr_aff_finish_kernel, dim3(1), dim3(64), 0, st, partial, np2, stats, losses);
-    hipLaunchKernelGGL(tr_aff_grad_kernel, dim3((unsigned)cdivl(na, 256)), dim3(256), 0, st, pseudo, B, g_h, g_w, H, W, radius, ignore, stats, w_diver,
+    hipLaunchKernelGGL(tr_aff_grad_kernel, dim3((unsigned)cdivl(na, 256)), dim3(256), 0, st, aff_labels, B, g_h, g_w, H, W, radius, ignore, stats, w_diver,
                        d_attn_pred);
     EXCEL_CHECK_LAUNCH("train_losses");
     return EXCEL_OK;
@@ -215,7 +216,7 @@ int excel_launch_train_losses(const float* seg, const float* attn_pred, const un
 // every parameter (same struct layout as the weights), AdamW.  Token-major [M = B*P, E] activations throughout.
 // (SegFormerHead: model/segformer_head.py:47-77; DecoderTransformer: model/decoder/TransDecoder.py:62-124; attn_pred:
 // model/model_excel.py:70-76.)  Dropout2d of the head (segformer_head.py:66,75) is an identity here: the reference trains
-// with it (p = 0.1); deterministic training needs a counter-based mask and is left to the next step.
+// with it (p = 0.1): a counter-based mask (tr_dropout2d_kernel) keeps a step reproducible.
 
 // ---- elementwise / row kernels
 __global__ __launch_bounds__(256) void tr_act_kernel(const float* __restrict__ z, float* __restrict__ h, long long n, int gelu) {
@@ -422,6 +423,23 @@ extern "C" int excel_adamw_step(float* param, const float* grad, float* exp_avg,
     return EXCEL_OK;
 }
 
+// Dropout2d (segformer_head.py:66,75): whole channels of a sample are zeroed with probability p, the rest scaled by 1/(1-p).
+// Counter-based: keep(b, c) is a pure function of (seed, b, c), so forward and backward regenerate the same mask and a step is
+// reproducible (the reference draws from torch's generator; no parity is possible or claimed for the mask itself).
+__device__ __forceinline__ unsigned tr_hash(unsigned a, unsigned b, unsigned c) {
+    unsigned x = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA6Bu ^ (c + 0x165667B1u) * 0xC2B2AE35u;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+__global__ __launch_bounds__(256) void tr_dropout2d_kernel(float* __restrict__ x, int B, int P, int E, float p, unsigned seed) {
+    const long long n = (long long)B * P * E;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % E), b = (int)(i / ((long long)P * E));
+    const float u = (float)(tr_hash(seed, (unsigned)b, (unsigned)c) >> 8) * (1.f / 16777216.f);
+    x[i] = u < p ? 0.f : x[i] * (1.f / (1.f - p));
+}
+
 // ---- workspace of one training iteration
 struct TrainWs {
     // forward cache
@@ -476,7 +494,8 @@ static int tr_launch_act(const float* z, float* hh, long long n, int gelu, hipSt
 
 // forward in training mode: seg [B,nc,g,g], attn_pred [B,P,P]; `workspace` keeps the activations for excel_decoder_backward
 extern "C" int excel_decoder_forward_train(excel_decoder_t h, const float* all_feats, int B, int g, void* workspace, size_t workspace_bytes,
-                                           float* seg_out, float* attn_pred_out, void* stream) {
+                                           float* seg_out, float* attn_pred_out, float dropout_p, unsigned dropout_seed, void* stream) {
+    EXCEL_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "excel_decoder_forward_train: dropout_p must be in [0,1)");
     EXCEL_CHECK_ARG(h && all_feats && workspace && seg_out && attn_pred_out && B > 0 && g > 0 && (g * g) % 4 == 0,
                     "excel_decoder_forward_train: bad argument (the token count g*g must be a multiple of 4)");
     const excel_decoder_config& c = h->cfg;
@@ -497,6 +516,8 @@ extern "C" int excel_decoder_forward_train(excel_decoder_t h, const float* all_f
     }
     GemmArgs fz = ga0(ws.cat, h->w.fuse_w, ws.fts, h->w.fuse_b, nullptr, M, E, L * E, L * E, L * E, E, 0, GEMM_ACT_NONE);
     TRYD(excel_launch_gemm(fz, true, 1, st));                                                    // :74
+    if (dropout_p > 0.f)                                                                         // :75
+        hipLaunchKernelGGL(tr_dropout2d_kernel, dim3((unsigned)cdivl((long long)ME, 256)), dim3(256), 0, st, ws.fts, B, P, E, dropout_p, dropout_seed);
     // attn_pred (model_excel.py:70-76)
     hipLaunchKernelGGL(tr_row_normalize_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, ws.fts, ws.fn, ws.inv, M, E);
     GemmArgs sm = ga0(ws.fn, ws.fn, ws.ap, nullptr, nullptr, P, P, E, E, E, P, 0, GEMM_ACT_NONE);
@@ -578,7 +599,8 @@ static int tr_linear_bwd(const float* dY, int ldy, const float* X, int ldx, cons
 // Backward of excel_decoder_forward_train (same all_feats / workspace).  `grads` has the layout of the weights; every
 // pointer in it is WRITTEN (device memory of the parameter's shape).
 extern "C" int excel_decoder_backward(excel_decoder_t h, const float* all_feats, int B, int g, void* workspace, size_t workspace_bytes,
-                                      const float* d_seg, const float* d_attn_pred, const excel_decoder_weights* grads, void* stream) {
+                                      const float* d_seg, const float* d_attn_pred, const excel_decoder_weights* grads, float dropout_p,
+                                      unsigned dropout_seed, void* stream) {
     EXCEL_CHECK_ARG(h && all_feats && workspace && d_seg && grads && grads->fuse && grads->blocks && B > 0 && g > 0, "excel_decoder_backward: bad argument");
     const excel_decoder_config& c = h->cfg;
     const int P = g * g, N = P + 1, D = c.vit_width, E = c.embed, L = c.vit_layers, H = c.heads, hd = E / H, nc = c.num_classes, nl = c.dec_layers;
@@ -675,6 +697,8 @@ extern "C" int excel_decoder_backward(excel_decoder_t h, const float* all_feats,
         hipLaunchKernelGGL(tr_row_normalize_bwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, ws.fn, ws.dfn, ws.inv, ws.dx, M, E);
         EXCEL_CHECK_LAUNCH("train/attn_pred_bwd");
     }
+    if (dropout_p > 0.f)         // the same mask as the forward (a pure function of seed, image, channel)
+        hipLaunchKernelGGL(tr_dropout2d_kernel, dim3((unsigned)cdivl((long long)ME, 256)), dim3(256), 0, st, ws.dx, B, P, E, dropout_p, dropout_seed);
     // linear_fuse: fts = cat . Wf^T + bf  ->  dcat [M, L*E] in dt4?  (dt4 holds M*4E floats; dcat needs M*L*E) -> use tr-free buffers: z1 area is still needed, so dcat goes to hq[0..] (free now)
     float* dcat = ws.hq;                                       // nl*M*4E floats >= M*L*E is not guaranteed: checked below
     EXCEL_CHECK_ARG((size_t)nl * 4 >= (size_t)L, "excel_decoder_backward: scratch for d(cat) too small (need dec_layers*4 >= vit_layers)");

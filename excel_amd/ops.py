@@ -270,8 +270,8 @@ class DecoderHandle:
             self._gtable = g
         return self._grads, self._gtable
 
-    def forward_train(self, all_feats):
-        """-> (seg [B,nc,g,g], attn_pred [B,P,P], ctx) ; ctx goes to backward()."""
+    def forward_train(self, all_feats, dropout_p=0.0, dropout_seed=0):
+        """-> (seg [B,nc,g,g], attn_pred [B,P,P], ctx) ; ctx goes to backward().  dropout_p: the head's Dropout2d (0.1 in the reference)."""
         all_feats = f32c(all_feats)
         L, B, N, D = all_feats.shape
         g = int(round((N - 1) ** 0.5))
@@ -281,16 +281,16 @@ class DecoderHandle:
         ap = torch.empty((B, g * g, g * g), dtype=torch.float32, device=dev)
         need = lib().excel_decoder_train_workspace_bytes(self._h, B, g)
         ws = _ws(need, dev)
-        check(lib().excel_decoder_forward_train(self._h, _p(all_feats), B, g, _p(ws, torch.uint8), need, _p(seg), _p(ap), _stream()),
-              "excel_decoder_forward_train")
-        return seg, ap, (all_feats, B, g, ws, need)
+        check(lib().excel_decoder_forward_train(self._h, _p(all_feats), B, g, _p(ws, torch.uint8), need, _p(seg), _p(ap), float(dropout_p),
+                                                int(dropout_seed) & 0xFFFFFFFF, _stream()), "excel_decoder_forward_train")
+        return seg, ap, (all_feats, B, g, ws, need, float(dropout_p), int(dropout_seed) & 0xFFFFFFFF)
 
     def backward(self, ctx, d_seg, d_attn_pred=None):
         """-> dict of gradients keyed like self.t (fuse{l}.proj_w ..., blk{l}.fc1_w ..., fuse_w, pred_w ...)."""
-        all_feats, B, g, ws, need = ctx
+        all_feats, B, g, ws, need, dp, dseed = ctx
         grads, table = self._grad_table()
         check(lib().excel_decoder_backward(self._h, _p(all_feats), B, g, _p(ws, torch.uint8), need, _p(f32c(d_seg)),
-                                           _p(f32c(d_attn_pred)) if d_attn_pred is not None else None, C.byref(table), _stream()),
+                                           _p(f32c(d_attn_pred)) if d_attn_pred is not None else None, C.byref(table), dp, dseed, _stream()),
               "excel_decoder_backward")
         return grads
 
@@ -392,15 +392,17 @@ def prompt_ensemble(class_embeddings):
     return out
 
 
-def train_losses(seg, attn_pred, pseudo_u8, radius=8, ignore_index=255, w_seg=1.0, w_diver=0.1):
-    """scripts/train_voc.py:202-215 -> (losses [2] = (seg_loss, diver_loss), d_seg, d_attn_pred)."""
+def train_losses(seg, attn_pred, pseudo_u8, radius=8, ignore_index=255, w_seg=1.0, w_diver=0.1, aff_labels_u8=None):
+    """scripts/train_voc.py:202-215 -> (losses [2] = (seg_loss, diver_loss), d_seg, d_attn_pred).
+    aff_labels_u8: the map the affinity labels come from (default: the pseudo labels; :210 switches to the seg arg-max later on)."""
     seg, attn_pred = f32c(seg), f32c(attn_pred)
     B, nc, gh, gw = seg.shape
     H, W = pseudo_u8.shape[-2:]
     losses = torch.empty((2,), dtype=torch.float32, device=seg.device)
     d_seg, d_ap = torch.empty_like(seg), torch.empty_like(attn_pred)
     ws = _ws(lib().excel_train_losses_workspace_bytes(B, nc, H, W), seg.device)
-    check(lib().excel_train_losses(_p(seg), _p(attn_pred), _p(pseudo_u8.contiguous(), torch.uint8), B, nc, gh, gw, H, W, radius, ignore_index,
+    check(lib().excel_train_losses(_p(seg), _p(attn_pred), _p(pseudo_u8.contiguous(), torch.uint8),
+                                   _p(aff_labels_u8.contiguous(), torch.uint8) if aff_labels_u8 is not None else None, B, nc, gh, gw, H, W, radius, ignore_index,
                                    float(w_seg), float(w_diver), _p(losses), _p(d_seg), _p(d_ap), _p(ws, torch.uint8), _stream()), "excel_train_losses")
     return losses, d_seg, d_ap
 

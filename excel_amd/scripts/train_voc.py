@@ -38,7 +38,7 @@ def allreduce_mean_(flat, group=None):
 
 class DecoderTrainer:
     def __init__(self, model, par, lr=1e-4, wt_decay=1e-2, betas=(0.9, 0.999), warmup_iters=50, max_iters=30000, warmup_lr=1e-6, power=1,
-                 w_diver=0.1, radius=8, ignore_index=255, lvc_iter=14000):
+                 w_diver=0.1, radius=8, ignore_index=255, lvc_iter=14000, seg_aff_iter=24000, dropout_p=0.1, seed=0):
         """Defaults = scripts/train_voc.py:36-80.  The head's parameters sit in param group 3 (model_excel.py:40-45): lr x 10."""
         if model._dec is None:
             raise RuntimeError("DecoderTrainer needs a model built with decoder_state_dict= (initial head weights)")
@@ -47,6 +47,7 @@ class DecoderTrainer:
         self.wt_decay, self.betas = wt_decay, betas
         self.warmup_iters, self.max_iters, self.warmup_lr, self.power = warmup_iters, max_iters, warmup_lr, power
         self.w_diver, self.radius, self.ignore_index, self.lvc_iter = w_diver, radius, ignore_index, lvc_iter
+        self.seg_aff_iter, self.dropout_p, self.seed = seg_aff_iter, dropout_p, seed
         self.global_step = 0
 
     @torch.no_grad()
@@ -71,13 +72,16 @@ class DecoderTrainer:
                 inputs, model.encoder, return_weights=True, n_attn_out=6 if n_iter >= self.lvc_iter else 0, want_feats=True,
                 feats_as_reference=True)                                                                             # model_excel.py:56
             attr_maps_raw = ops.clip_feature_surgery(image_features, model._text_rows, num_fg=model.num_classes - 1, want_full=False)[1]
-            segs, attn_pred, ctx = dec.forward_train(all_feats)                                                      # :60-76
+            segs, attn_pred, ctx = dec.forward_train(all_feats, dropout_p=self.dropout_p,
+                                                     dropout_seed=self.seed * 1000003 + self.global_step)            # :60-76 (Dropout2d active: model.train())
             if n_iter >= self.lvc_iter:                                                                              # fts_diver = attn_fts of this forward
                 attr_maps_raw = cure_attr_map(model, inputs, ex_feats=dec.forward(all_feats, want_seg=False)[0])      # :188-189
             aff_pseudos = self.pseudo_labels(inputs, cls_labels, attr_maps_raw, attn_weights, attn_pred, n_iter)
-            # the reference switches the affinity target to the seg prediction after 24000 iterations (:210); pseudo labels before
+            aff_src = None
+            if n_iter >= self.seg_aff_iter:                                                                          # :204, :210
+                aff_src = ops.argmax_label(ops.bilinear_resize(segs, inputs.shape[2], inputs.shape[3], align_corners=False))
             losses, d_seg, d_ap = ops.train_losses(segs, attn_pred, aff_pseudos, radius=self.radius, ignore_index=self.ignore_index,
-                                                   w_seg=1.0, w_diver=self.w_diver)                                  # :202-215
+                                                   w_seg=1.0, w_diver=self.w_diver, aff_labels_u8=aff_src)           # :202-215
             dec.backward(ctx, d_seg, d_ap)                                                                           # :218
             allreduce_mean_(dec.grad_flat)
             lr = poly_warmup_lr(self.base_lr, self.global_step, self.warmup_iters, self.max_iters, self.warmup_lr, self.power)

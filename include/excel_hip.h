@@ -174,24 +174,27 @@ int excel_prompt_ensemble(const float* emb, int n, int E, float* out, void* stre
  *   attn_pred [B,P,P] -> get_aff_loss (model/losses.py:20-31) against cams_to_affinity_label(pseudo, get_mask_by_radius(g,g,radius))
  *                        (utils/camutils.py:438-476; nearest down-sampling by H/g_h, 255 outside the window / on ignored tokens)
  *   losses[0] = seg_loss, losses[1] = aff ("diver") loss (device floats); d_seg, d_attn_pred = gradients of
- *   w_seg*seg_loss + w_diver*aff_loss.  Fixed-order reductions: reproducible. */
+ *   w_seg*seg_loss + w_diver*aff_loss.  aff_labels (NULL = pseudo): the map the affinity labels are built from -- the reference
+ *   switches it to the arg-max of the up-sampled seg logits after 24 000 iterations (train_voc.py:210).  Fixed-order reductions. */
 size_t excel_train_losses_workspace_bytes(int B, int nc, int H, int W);
-int excel_train_losses(const float* seg, const float* attn_pred, const unsigned char* pseudo, int B, int nc, int g_h, int g_w, int H, int W,
-                       int radius, int ignore_index, float w_seg, float w_diver, float* losses, float* d_seg, float* d_attn_pred,
-                       void* workspace, void* stream);
+int excel_train_losses(const float* seg, const float* attn_pred, const unsigned char* pseudo, const unsigned char* aff_labels, int B, int nc,
+                       int g_h, int g_w, int H, int W, int radius, int ignore_index, float w_seg, float w_diver, float* losses,
+                       float* d_seg, float* d_attn_pred, void* workspace, void* stream);
 
 /* The decoder head in training mode (SegFormerHead + DecoderTransformer + attn_pred, model/model_excel.py:60-76), exact fp32:
  *   forward_train keeps the activations in `workspace` and returns seg [B,nc,g,g] and attn_pred [B,P,P];
  *   backward (same all_feats / workspace) writes d loss / d parameter for every parameter into `grads`, a table with the layout
  *   of the weights whose pointers are WRITTEN (device memory of each parameter's shape); d_attn_pred may be NULL.
- *   The head's Dropout2d (segformer_head.py:66,75) is an identity (deterministic step).  g*g must be a multiple of 4.
+ *   dropout_p / dropout_seed: the head's Dropout2d (segformer_head.py:66,75; the reference trains with p = 0.1) as a counter-based
+ *   channel mask, a pure function of (seed, image, channel): pass the same pair to forward_train and backward.  g*g % 4 == 0.
  * excel_adamw_step: torch.optim.AdamW update of one tensor (decoupled weight decay, bias correction with `step` >= 1), the
  * arithmetic under utils/optimizer.py's PolyWarmupAdamW; the learning-rate schedule stays on the host. */
 size_t excel_decoder_train_workspace_bytes(excel_decoder_t h, int B, int g);
 int excel_decoder_forward_train(excel_decoder_t h, const float* all_feats, int B, int g, void* workspace, size_t workspace_bytes,
-                                float* seg_out, float* attn_pred_out, void* stream);
+                                float* seg_out, float* attn_pred_out, float dropout_p, unsigned dropout_seed, void* stream);
 int excel_decoder_backward(excel_decoder_t h, const float* all_feats, int B, int g, void* workspace, size_t workspace_bytes,
-                           const float* d_seg, const float* d_attn_pred, const excel_decoder_weights* grads, void* stream);
+                           const float* d_seg, const float* d_attn_pred, const excel_decoder_weights* grads, float dropout_p,
+                           unsigned dropout_seed, void* stream);
 int excel_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1, float beta2,
                      float eps, float weight_decay, int step, void* stream);
 

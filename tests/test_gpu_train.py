@@ -109,10 +109,10 @@ def test_train_step_end_to_end(ops, golden):
     sd = {"decoder_fts_fuse." + k[8:]: g[k] for k in g.files if k.startswith("w0.fuse.")}
     sd.update({"decoder." + k[7:]: g[k] for k in g.files if k.startswith("w0.dec.")})
 
-    def run(lvc_iter):
+    def run(lvc_iter, dropout_p=0.0, seg_aff_iter=10 ** 9):
         model = ExCEL_model(clip_model="tiny", num_classes=5, img_size=96, mode="train", state_dict=w, vit_cfg=kw, text_attr=text.T.copy(),
                             gemm_mode="f32", embedding_dim=32, in_channels=128, decoder_state_dict=sd)
-        tr = DecoderTrainer(model, PAR(num_iter=10, dilations=[1, 2, 4, 8, 12, 24]), lr=1e-3, warmup_iters=2, max_iters=100, radius=2, lvc_iter=lvc_iter)
+        tr = DecoderTrainer(model, PAR(num_iter=10, dilations=[1, 2, 4, 8, 12, 24]), lr=1e-3, warmup_iters=2, max_iters=100, radius=2, lvc_iter=lvc_iter, dropout_p=dropout_p, seg_aff_iter=seg_aff_iter)
         x = dev(rs.standard_normal((2, 3, 96, 96)).astype(np.float32) * 0 + np.random.RandomState(5).standard_normal((2, 3, 96, 96)).astype(np.float32))
         cls = dev(np.array([[1, 0, 1, 0], [0, 1, 0, 0]], np.float32))
         return [tr.train_step(x, cls) for _ in range(6)], model
@@ -125,3 +125,7 @@ def test_train_step_end_to_end(ops, golden):
     hist3, _ = run(lvc_iter=2)                                                     # LVC regime from iteration 2 on (ex_feats CAMs + seg_attn)
     assert all(np.isfinite(h["seg_loss"]) for h in hist3) and hist3[0]["seg_loss"] == hist[0]["seg_loss"]
     assert tuple(hist3[-1]["aff_pseudos"].shape) == (2, 96, 96)
+    hist4, _ = run(lvc_iter=10 ** 9, dropout_p=0.1, seg_aff_iter=3)                # Dropout2d on, affinity target = seg arg-max from iteration 3
+    hist5, _ = run(lvc_iter=10 ** 9, dropout_p=0.1, seg_aff_iter=3)
+    assert [h["seg_loss"] for h in hist4] == [h["seg_loss"] for h in hist5]        # the counter-based mask keeps it reproducible
+    assert hist4[0]["seg_loss"] != hist[0]["seg_loss"] and all(np.isfinite(h["diver_loss"]) for h in hist4)
