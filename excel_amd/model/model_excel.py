@@ -64,6 +64,16 @@ class ExCEL_model:
     def train(self):
         return self
 
+    def state_dict(self):
+        """The trainable part, keyed like the reference model's state_dict ("decoder_fts_fuse.*", "decoder.*"): what the
+        training script checkpoints (scripts/train_voc.py torch.save(model.state_dict(), ...))."""
+        if self._dec is None:
+            return {}
+        fuse, dec = self._dec.state_dicts()
+        out = {"decoder_fts_fuse." + k: v for k, v in fuse.items()}
+        out.update({"decoder." + k: v for k, v in dec.items()})
+        return out
+
     def to(self, *a, **k):
         return self
 

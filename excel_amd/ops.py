@@ -243,6 +243,23 @@ class DecoderHandle:
         except Exception:
             pass
 
+    def state_dicts(self):
+        """-> (fuse_sd, dec_sd) with the reference modules' state_dict keys and shapes (1x1 conv weights as [out,in,1,1]): what
+        torch.save(model.state_dict()) of the reference holds for the head, so a head trained here loads back there."""
+        c = self.cfg
+        fuse, dec = {}, {}
+        for l in range(c["vit_layers"]):
+            for f, k in (("proj_w", "proj.weight"), ("proj_b", "proj.bias"), ("proj2_w", "proj_2.weight"), ("proj2_b", "proj_2.bias")):
+                fuse[f"linears_modulelist.{l}.{k}"] = self.t[f"fuse{l}.{f}"].detach().clone()
+        fuse["linear_fuse.weight"] = self.t["fuse_w"].detach().clone()[:, :, None, None]
+        fuse["linear_fuse.bias"] = self.t["fuse_b"].detach().clone()
+        for l in range(c["dec_layers"]):
+            for f, k in _BLOCK_KEYS.items():
+                dec[f"transformer.resblocks.{l}.{k}"] = self.t[f"blk{l}.{f}"].detach().clone()
+        dec["linear_pred.weight"] = self.t["pred_w"].detach().clone()[:, :, None, None]
+        dec["linear_pred.bias"] = self.t["pred_b"].detach().clone()
+        return fuse, dec
+
     # ------------------------------------------------------------------ training iteration (SURVEY 8f #4)
     def _grad_table(self):
         """Gradient tensors shaped like the parameters + the C table pointing at them (built once)."""

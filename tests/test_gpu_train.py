@@ -90,6 +90,14 @@ def test_two_adamw_steps_match_reference_optimizer(ops, golden):
             ref = g[f"w{it + 1}." + suffix].reshape(host(h.t[k]).shape)
             assert float(np.max(np.abs(host(h.t[k]) - ref))) < 2e-6 * max(1.0, float(np.abs(ref).max())), (it, k)
     assert abs(float(losses[0]) - float(g["seg_loss_it1"])) < 1e-5
+    # checkpoint round trip in the reference's key/shape convention
+    fuse_sd, dec_sd = h.state_dicts()
+    assert tuple(fuse_sd["linear_fuse.weight"].shape) == g["w2.fuse.linear_fuse.weight"].shape
+    assert tuple(dec_sd["linear_pred.weight"].shape) == g["w2.dec.linear_pred.weight"].shape
+    h2 = ops.DecoderHandle({k: host(v) for k, v in fuse_sd.items()}, {k: host(v) for k, v in dec_sd.items()}, heads=8)
+    s1, _, _ = h.forward_train(dev(gd["all_feats"]))
+    s2, _, _ = h2.forward_train(dev(gd["all_feats"]))
+    assert torch.equal(s1, s2)
 
 
 def test_train_step_end_to_end(ops, golden):
