@@ -323,3 +323,27 @@ def test_gradient_allreduce_mean_world2():
         assert p.exitcode == 0
     for _, flat in res:
         assert np.allclose(flat, np.arange(10, dtype=np.float32) * 1.5)
+
+
+def test_coco_on_disk_dataset(tmp_path):
+    """datasets/coco.py layout: train/val sub-directories, prefix-stripped label names, grey-scale JPEG replication."""
+    from PIL import Image
+    from excel_amd.datasets import coco
+    root, lists = tmp_path / "COCO", tmp_path / "lists"
+    for d in ("JPEGImages/val", "SegmentationClass/val"):
+        (root / d).mkdir(parents=True)
+    lists.mkdir()
+    rs = np.random.RandomState(1)
+    name = "COCO_val2014_000000000042"
+    Image.fromarray(rs.randint(0, 256, (18, 22)).astype(np.uint8)).save(root / "JPEGImages/val" / (name + ".jpg"))      # grey-scale
+    lab = rs.randint(0, 81, (18, 22)).astype(np.uint8)
+    Image.fromarray(lab).save(root / "SegmentationClass/val" / "000000000042.png")
+    oh = np.zeros(80, np.float32)
+    oh[[0, 79]] = 1
+    (lists / "val.txt").write_text(name + "\n")
+    np.save(lists / "cls_labels_onehot.npy", {name: oh})
+    ds = coco.CocoSegDataset(str(root), str(lists), split="val", stage="val")
+    n, image, label, cls = ds[0]
+    assert n == name and image.shape == (18, 22, 3) and np.array_equal(image[..., 0], image[..., 2])
+    assert np.array_equal(label, lab) and np.array_equal(cls, oh)
+    assert len(coco.class_list) == 81 and coco.class_list[1] == "person" and coco.class_list[80] == "toothbrush"
