@@ -94,6 +94,7 @@ SIGNATURES = {
     "excel_adamw_step": (c_i, [c_f, c_f, c_f, c_f, c_ll, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, c_i, c_f]),
     "excel_train_losses_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
     "excel_train_losses": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, C.c_float, C.c_float, c_f, c_f, c_f, c_f, c_f]),
+    "excel_lam_to_label": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, C.c_float, C.c_float, C.c_float, c_i, c_i, c_f, c_f, c_f]),
     "excel_normalize_img_u8": (c_i, [c_f, c_i, c_i, c_i, C.POINTER(C.c_double), C.POINTER(C.c_double), c_f, c_f]),
     "excel_denormalize_img": (c_i, [c_f, c_i, c_i, c_i, C.POINTER(C.c_float), C.POINTER(C.c_float), c_f, c_f, c_f]),
     "excel_seg_scale_accumulate": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, C.c_float, c_f]),

@@ -347,6 +347,14 @@ extern "C" int excel_train_losses(const float* seg, const float* attn_pred, cons
                                      d_attn_pred, workspace, ST(stream));
 }
 
+extern "C" int excel_lam_to_label(const float* cam, const float* cls_label, const int32_t* img_box, int B, int F, int H, int W, float bkg_thre,
+                                 float high_thre, float low_thre, int ignore_mid, int ignore_index, float* valid_cam, unsigned char* label,
+                                 void* stream) {
+    EXCEL_CHECK_ARG(cam && cls_label && label && B > 0 && F > 0 && H > 0 && W > 0, "lam_to_label: bad argument");
+    return excel_launch_lam_to_label(cam, cls_label, img_box, B, F, H, W, bkg_thre, high_thre, low_thre, ignore_mid, ignore_index, valid_cam, label,
+                                     ST(stream));
+}
+
 extern "C" int excel_normalize_img_u8(const unsigned char* hwc, int B, int H, int W, const double* mean3, const double* std3, float* out, void* stream) {
     EXCEL_CHECK_ARG(hwc && out && mean3 && std3 && B > 0 && H > 0 && W > 0, "normalize_img_u8: bad argument");
     return excel_launch_normalize_u8(hwc, out, B, (long long)H * W, mean3, std3, ST(stream));

@@ -185,6 +185,46 @@ __global__ __launch_bounds__(256) void denormalize_kernel(const float* __restric
     if (outf) outf[i] = (float)q / 255.0f;
 }
 
+// lam_to_label (utils/camutils.py:123-145): valid = cls_label * cam; (value, arg) = max over classes (first maximum); label = arg + 1;
+// ignore_mid: value <= high -> ignore, then value <= low -> 0 ; else value <= bkg -> 0.  img_box [B,4] (y0,y1,x0,x1): outside -> ignore.
+__global__ __launch_bounds__(256) void lam_to_label_kernel(const float* __restrict__ cam, const float* __restrict__ cls, const int* __restrict__ box,
+                                                           int B, int F, int H, int W, float bkg, float high, float low, int ignore_mid, int ignore,
+                                                           float* __restrict__ valid, unsigned char* __restrict__ lab) {
+    const long long HW = (long long)H * W;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * HW) return;
+    const int b = (int)(i / HW);
+    const long long px = i - (long long)b * HW;
+    float best = 0.f;
+    int bi = 0;
+    for (int f = 0; f < F; ++f) {
+        const float v = cls[(long long)b * F + f] * cam[((long long)b * F + f) * HW + px];
+        if (valid) valid[((long long)b * F + f) * HW + px] = v;
+        if (f == 0 || v > best) { best = v; bi = f; }
+    }
+    int l = bi + 1;
+    if (ignore_mid) {
+        if (best <= high) l = ignore;
+        if (best <= low) l = 0;
+    } else if (best <= bkg) {
+        l = 0;
+    }
+    if (box) {
+        const int y = (int)(px / W), x = (int)(px % W);
+        const int* bx = box + b * 4;
+        if (!(y >= bx[0] && y < bx[1] && x >= bx[2] && x < bx[3])) l = ignore;
+    }
+    lab[i] = (unsigned char)l;
+}
+
+int excel_launch_lam_to_label(const float* cam, const float* cls, const int* box, int B, int F, int H, int W, float bkg, float high, float low,
+                              int ignore_mid, int ignore, float* valid, unsigned char* lab, hipStream_t st) {
+    hipLaunchKernelGGL(lam_to_label_kernel, dim3((unsigned)cdivl((long long)B * H * W, 256)), dim3(256), 0, st, cam, cls, box, B, F, H, W, bkg, high, low,
+                       ignore_mid, ignore, valid, lab);
+    EXCEL_CHECK_LAUNCH("lam_to_label");
+    return EXCEL_OK;
+}
+
 // transforms.normalize_img + HWC->CHW (datasets/transforms.py, datasets/voc.py:115-116): u8 [B,H,W,3] -> f32 [B,3,H,W],
 // (u8 - mean[c]) / std[c] evaluated in double and rounded once, exactly like numpy's float64 intermediate
 __global__ __launch_bounds__(256) void normalize_u8_kernel(const unsigned char* __restrict__ hwc, float* __restrict__ out, long long HW, long long total,

@@ -90,6 +90,8 @@ int excel_launch_seg_scale_accumulate(const float* segs, float* acc, int B, int 
 int excel_launch_denormalize(const float* img, unsigned char* out8, float* outf, int B, long long HW, const float* mean, const float* stdv,
                              hipStream_t st);
 int excel_launch_normalize_u8(const unsigned char* hwc, float* out, int B, long long HW, const double* mean, const double* stdv, hipStream_t st);
+int excel_launch_lam_to_label(const float* cam, const float* cls, const int* box, int B, int F, int H, int W, float bkg, float high, float low,
+                              int ignore_mid, int ignore, float* valid, unsigned char* lab, hipStream_t st);
 // training step (train.hip)
 size_t excel_train_losses_ws_bytes(int B, int nc, int H, int W);
 int excel_launch_train_losses(const float* seg, const float* attn_pred, const unsigned char* pseudo, const unsigned char* aff_labels, int B, int nc,

@@ -424,6 +424,19 @@ def train_losses(seg, attn_pred, pseudo_u8, radius=8, ignore_index=255, w_seg=1.
     return losses, d_seg, d_ap
 
 
+def lam_to_label(cam, cls_label, img_box=None, bkg_thre=0.5, high_thre=None, low_thre=None, ignore_mid=False, ignore_index=255):
+    """utils/camutils.py:123-145 -> (valid_cam [B,F,H,W], pseudo_label uint8 [B,H,W])."""
+    cam, cls_label = f32c(cam), f32c(cls_label)
+    B, F_, H, W = cam.shape
+    valid = torch.empty_like(cam)
+    lab = torch.empty((B, H, W), dtype=torch.uint8, device=cam.device)
+    box = None if img_box is None else torch.as_tensor(img_box).to(device=cam.device, dtype=torch.int32).contiguous()
+    check(lib().excel_lam_to_label(_p(cam), _p(cls_label), _p(box, torch.int32), B, F_, H, W, float(bkg_thre), float(high_thre or 0.0),
+                                   float(low_thre or 0.0), 1 if ignore_mid else 0, int(ignore_index), _p(valid), _p(lab, torch.uint8), _stream()),
+          "excel_lam_to_label")
+    return valid, lab
+
+
 def normalize_img_u8(hwc_u8, mean=(123.675, 116.28, 103.53), std=(58.395, 57.12, 57.375)):
     """datasets/transforms.normalize_img + HWC->CHW on the device: uint8 [B,H,W,3] -> f32 [B,3,H,W] (3 B/pixel over PCIe instead of 12)."""
     x = hwc_u8.contiguous()

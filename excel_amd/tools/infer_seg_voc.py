@@ -12,8 +12,9 @@ from .. import ops
 
 
 @torch.no_grad()
-def multi_scale_seg(model, inputs, resize_size, scales=(1.0, 0.5, 0.75, 1.5)):
-    """inputs [B,3,h,w] -> msc_seg [B,nc,h,w] (the tensor the reference stores as {"msc_seg": ...}, :89)."""
+def multi_scale_seg(model, inputs, resize_size, scales=(1.0, 0.5, 0.75, 1.5), flip_first=False):
+    """inputs [B,3,h,w] -> msc_seg [B,nc,h,w] (the tensor the reference stores as {"msc_seg": ...}, :89).
+    flip_first=True: the variant of tools/test_msc_flip_voc.py:89-107, where scale 1.0 is flip-averaged as well."""
     if model._dec is None:
         raise RuntimeError("multi_scale_seg needs the decoder head: build ExCEL_model with decoder_state_dict=")
     B, _, h, w = inputs.shape
@@ -23,7 +24,7 @@ def multi_scale_seg(model, inputs, resize_size, scales=(1.0, 0.5, 0.75, 1.5)):
         S = resize_size if sc == 1.0 else int(resize_size * sc)       # :64 / :74
         x = ops.bilinear_resize(inputs, S, S, align_corners=False)    # :65 / :75
         segs = model(torch.cat([x, x.flip(-1)], dim=0))[0]            # :66-67 / :76-77
-        acc = ops.seg_scale_accumulate(segs, acc, h, w, flip_mean=(sc != 1.0), init=(i == 0),
+        acc = ops.seg_scale_accumulate(segs, acc, h, w, flip_mean=(sc != 1.0 or flip_first), init=(i == 0),
                                        scale=(1.0 / len(todo)) if i == len(todo) - 1 else 1.0)     # :68-70 / :78-80, :82
     return acc
 

@@ -46,3 +46,9 @@ def multi_scale_lam(model, inputs, scales=(1.0, 0.5, 0.75, 1.5)):
         maps = model(x2)[2]                                                                                  # :53-54
         acc = ops.lam_scale_accumulate(maps, acc, hs // 16, h, w, init=acc is None)                         # :56-59 resize, flip-max, sum
     return ops.plane_minmax_normalize_(acc)                                                                  # :61-63
+
+
+@torch.no_grad()
+def lam_to_label(cam, cls_label, img_box=None, bkg_thre=0.5, high_thre=None, low_thre=None, ignore_mid=False, ignore_index=None):
+    """utils/camutils.py:123-145 (labels come back as uint8; 255 = ignore)."""
+    return ops.lam_to_label(cam, cls_label, img_box, bkg_thre, high_thre, low_thre, ignore_mid, 255 if ignore_index is None else ignore_index)

@@ -198,6 +198,13 @@ int excel_decoder_backward(excel_decoder_t h, const float* all_feats, int B, int
 int excel_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1, float beta2,
                      float eps, float weight_decay, int step, void* stream);
 
+/* lam_to_label (utils/camutils.py:123-145): cam [B,F,H,W], cls_label [B,F] -> valid_cam = cls*cam (optional) and label u8 [B,H,W] =
+ * argmax+1, thresholded (ignore_mid: value <= high -> ignore_index, value <= low -> 0; else value <= bkg -> 0); img_box [B,4] int32
+ * (y0,y1,x0,x1; optional): pixels outside the box -> ignore_index. */
+int excel_lam_to_label(const float* cam, const float* cls_label, const int32_t* img_box, int B, int F, int H, int W, float bkg_thre,
+                       float high_thre, float low_thre, int ignore_mid, int ignore_index, float* valid_cam, unsigned char* label,
+                       void* stream);
+
 /* transforms.normalize_img + the HWC->CHW transpose of the dataset (datasets/transforms.py; datasets/voc.py:115-116):
  * hwc [B,H,W,3] uint8 (decoded image) -> out [B,3,H,W] f32 = (u8 - mean[c]) / std[c], double intermediate like numpy.  mean3/std3: HOST doubles. */
 int excel_normalize_img_u8(const unsigned char* hwc, int B, int H, int W, const double* mean3, const double* std3, float* out, void* stream);

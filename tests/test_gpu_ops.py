@@ -565,3 +565,30 @@ def test_normalize_img_u8(ops):
     ref = ref.transpose(0, 3, 1, 2)
     got = host(ops.normalize_img_u8(dev(img)))
     assert np.array_equal(got, ref)
+
+
+def test_lam_to_label(ops):
+    """utils/camutils.py:123-145 restated in numpy (both threshold modes, image boxes)."""
+    rs = np.random.RandomState(4)
+    B, F_, H, W = 3, 5, 9, 11
+    cam = rs.rand(B, F_, H, W).astype(np.float32)
+    cls = (rs.rand(B, F_) < 0.5).astype(np.float32)
+    cls[0] = 0
+    box = np.array([[0, 9, 0, 11], [2, 7, 1, 9], [0, 4, 5, 11]], np.int32)
+    for ignore_mid in (False, True):
+        valid = cls[:, :, None, None] * cam
+        val, arg = valid.max(1), valid.argmax(1)
+        lab = arg + 1
+        if ignore_mid:
+            lab[val <= 0.7] = 255
+            lab[val <= 0.25] = 0
+        else:
+            lab[val <= 0.5] = 0
+        ref = np.full_like(lab, 255)
+        for b in range(B):
+            y0, y1, x0, x1 = box[b]
+            ref[b, y0:y1, x0:x1] = lab[b, y0:y1, x0:x1]
+        v, l = ops.lam_to_label(dev(cam), dev(cls), img_box=box, bkg_thre=0.5, high_thre=0.7, low_thre=0.25, ignore_mid=ignore_mid)
+        assert np.array_equal(host(l), ref.astype(np.uint8)) and np.array_equal(host(v), valid)
+        _, l2 = ops.lam_to_label(dev(cam), dev(cls), bkg_thre=0.5, high_thre=0.7, low_thre=0.25, ignore_mid=ignore_mid)
+        assert np.array_equal(host(l2), lab.astype(np.uint8))
