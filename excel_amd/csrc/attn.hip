@@ -334,6 +334,7 @@ __device__ __forceinline__ void rowpass_body_bf(const RowpassArgs& p, float* sme
         }
         __builtin_amdgcn_s_barrier();
         if (kt + 2 < nkt) issue(kt + 2, stage == 0 ? 2 : stage - 1);
+        if (q0 >= N) { stage = (stage == 2) ? 0 : stage + 1; continue; }      // wave-uniform: all 32 query rows are padding -> only keep the ring moving
         const u16* kr = ring + stage * STAGE_EL + r * 128;
         f32x16 s;
 #pragma unroll
@@ -719,8 +720,11 @@ __global__ __launch_bounds__(512, 2) void attn_accum_bf_kernel(AccumArgs p) {
     const float c2 = p.scale * 1.4426950408889634f;               // row stats are in log2 units (rowpass_body_bf)
     const bool last_kt = kt * 64 + wk * 32 + 32 > N;              // wave-uniform: only the last key tile holds keys >= N
 
+    // wave-uniform: this wave's 32 x 32 tile lies entirely in the padding (N = 785 leaves 3 of the 4 query sub-tiles of the last
+    // query tile and half of the last key tile empty): nothing to score, the wave only keeps the staging and barriers going
+    const bool tile_oob = (qt * 128 + wq * 32 >= N) || (kt * 64 + wk * 32 >= N);
     auto score = [&](int offY, int offX, int type, int h, f32x16& acc) {
-        if (p.dbg & 1) return;
+        if ((p.dbg & 1) || tile_oob) return;
         const float2 ml = lstats[((h & 1) * NTYPE + type) * 128 + wq * 32 + r];
         const u16* y16 = tiles + offY + (wk * 32 + r) * 128;
         const u16* x16 = tiles + offX + (wq * 32 + r) * 128;
