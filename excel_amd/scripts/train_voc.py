@@ -37,7 +37,7 @@ def allreduce_mean_(flat, group=None):
 
 
 class DecoderTrainer:
-    def __init__(self, model, par, lr=1e-4, wt_decay=1e-2, betas=(0.9, 0.999), warmup_iters=50, max_iters=30000, warmup_lr=1e-6, power=1,
+    def __init__(self, model, par, lr=1e-4, wt_decay=1e-2, betas=(0.9, 0.999), warmup_iters=50, max_iters=30000, warmup_lr=1e-6, power=1, caa_thre=0.79,
                  w_diver=0.1, radius=8, ignore_index=255, lvc_iter=14000, seg_aff_iter=24000, dropout_p=0.1, seed=0):
         """Defaults = scripts/train_voc.py:36-80.  The head's parameters sit in param group 3 (model_excel.py:40-45): lr x 10."""
         if model._dec is None:
@@ -47,6 +47,7 @@ class DecoderTrainer:
         self.wt_decay, self.betas = wt_decay, betas
         self.warmup_iters, self.max_iters, self.warmup_lr, self.power = warmup_iters, max_iters, warmup_lr, power
         self.w_diver, self.radius, self.ignore_index, self.lvc_iter = w_diver, radius, ignore_index, lvc_iter
+        self.caa_thre = caa_thre                                       # 0.79 VOC (train_voc.py:195), 0.88 COCO (train_coco.py:193)
         self.seg_aff_iter, self.dropout_p, self.seed = seg_aff_iter, dropout_p, seed
         self.global_step = 0
 
@@ -58,7 +59,7 @@ class DecoderTrainer:
         for i, attr_map in enumerate(attr_maps_raw):
             seg_attn = attn_pred[i][None] if n_iter >= self.lvc_iter else None                                        # :194
             refined, cls_lst = refine_cams_with_aff(attr_map, attn_weights[:, i, ...], cls_labels[i], size=inputs.shape[2:],
-                                                    seg_attn=seg_attn, caa_thre=0.79)                              # :195
+                                                    seg_attn=seg_attn, caa_thre=self.caa_thre)                     # :195
             lab, _ = refine_cams_with_bkg_weclip(refined, guide[i], cls_lst, self.par, size=inputs.shape[2:])     # :196
             out.append(lab)
         return torch.cat(out, dim=0).to(torch.uint8)                                                               # :198
