@@ -257,7 +257,7 @@ def test_coco_shaped_512_pipeline_vs_oracle(gpu, gemm_mode):
     """512x512 (N = 1025: exercises the K/N paddings 1028/1056), T = 103 text rows, F = 80 classes, up to 5 present
     classes per image (PAR with 6 channels), COCO-style caa threshold; small-width ViT so the oracle stays fast.
 
-    scoremap2bbox thresholds a uint8-truncated map (affutils.py:96-101), so the path is discontinuous in its input:
+    scoremap2bbox thresholds a uint8-truncated map (affutils.py:28-33), so the path is discontinuous in its input:
     a 1e-5 difference in a CAM can move a box.  In exact-fp32 mode the whole path is compared end to end; in bf16x3 mode
     (CAM error ~1e-5, inside the 1e-3 gate) the CAM stage is gated on its own and the discontinuous stages are compared
     stage-wise: the oracle continues from the GPU's own CAMs and mean attention and must then agree tightly."""
