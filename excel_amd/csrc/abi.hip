@@ -474,7 +474,7 @@ static int vit_forward_impl(excel_vit_t h, const float* img, int B, int S, void*
         // needed for the cls rows alone (the reference computes all rows; all_feats consumers still get them on request)
         const bool cls_only = surgery && l == L - 1 && !feats_out;
         if (bf)   // V^T in split format: B operand of the bf16x3 P.V (all blocks) and of A_sum.V (surgery blocks)
-            TRY(excel_launch_vt_split(ws.qkvh + (size_t)2 * H * N * 64, (unsigned short*)ws.vt, B, H, N, ws.KP, (long long)3 * H * N * 64, st));
+            TRY(excel_launch_vt_from_planes(qkvs, (unsigned short*)ws.vt, B, H, N, ws.KP, st));
         TRY(excel_launch_attn_rowpass(ws.qkvh, ws.ao, ws.stats, B, H, N, 64, scale, surgery ? 4 : 1, st, bf, qkvs, cls_only ? 1 : (1 << 30),
                                       bf ? (const unsigned short*)ws.vt : nullptr, ws.KP));
         const bool in_aff = w_aff && l >= L - aff_layers;

@@ -73,7 +73,7 @@ __device__ __forceinline__ void bf_epilogue(const GemmBfArgs& p, const f32x16 (&
                     int n = qn + dr, b = qb;
                     while (n >= p.tokN) { n -= p.tokN; ++b; }
                     const long long off = qcol_off + ((long long)b * 3 * p.heads * p.tokN + n) * p.hd;
-                    if (!p.qkv_split || col >= 2 * p.heads * p.hd) p.C[off] = v;
+                    if (!p.qkv_split) p.C[off] = v;
                     if (p.qkv_split) {     // same (b,type,head,n) row, [hi hd | lo hd] bf16: operand of the bf16x3 attention scores
                         __bf16* o = reinterpret_cast<__bf16*>(p.qkv_split) + (off - qd) * 2 + qd;
                         const __bf16 hi = (__bf16)v;
@@ -141,8 +141,8 @@ __device__ __forceinline__ void bf_epilogue_lds(const GemmBfArgs& p, const f32x1
                 } else {   // q|k|v head-major: fp32 for P.V / A.V, and [hi hd | lo hd] bf16 for the bf16x3 scores
                     const int b = row / p.tokN, n = row - b * p.tokN;
                     const long long rowidx = (((long long)b * 3 + qt) * p.heads + qh) * p.tokN + n;
-                    // fp32 q and k are not consumed when the split copy exists (bf16x3 attention): write only v in fp32
-                    if (!p.qkv_split || qt == 2) *reinterpret_cast<f32x4*>(p.C + rowidx * p.hd + qd) = v;
+                    // the fp32 copy is not consumed when the split copy exists (bf16x3 attention; V^T is cut from the split planes)
+                    if (!p.qkv_split) *reinterpret_cast<f32x4*>(p.C + rowidx * p.hd + qd) = v;
                     if (p.qkv_split) {
                         __bf16* o = reinterpret_cast<__bf16*>(p.qkv_split) + rowidx * 2 * p.hd + qd;
                         *reinterpret_cast<uint2*>(o) = *reinterpret_cast<const uint2*>(hi);
@@ -374,6 +374,42 @@ __global__ __launch_bounds__(256) void vt_split_kernel(const float* __restrict__
         *reinterpret_cast<uint2*>(o) = *reinterpret_cast<const uint2*>(hi);
         *reinterpret_cast<uint2*>(o + 32) = *reinterpret_cast<const uint2*>(lo);
     }
+}
+
+// Same V^T, cut from the split q|k|v the QKV epilogue already wrote (rows [hi 64 | lo 64] of v): the planes are produced by the
+// same rounding, so this is a pure 16-bit transpose -- bit-identical to vt_split_kernel on the fp32 v, which need not exist.
+__global__ __launch_bounds__(256) void vt_from_planes_kernel(const u16* __restrict__ qkvs, u16* __restrict__ vt, int H, int N, int KP) {
+    __shared__ u16 t[64][136];
+    const int mt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const u16* src = qkvs + ((((long long)b * 3 + 2) * H + h) * (long long)N) * 128;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 64 * 16; i += 256) {              // 64 tokens x 16 chunks of 8 u16
+        const int m = i >> 4, c8 = i & 15;
+        const int gm = mt * 64 + m;
+        uint4 x = {0u, 0u, 0u, 0u};
+        if (gm < N) x = *reinterpret_cast<const uint4*>(src + (long long)gm * 128 + c8 * 8);
+        *reinterpret_cast<uint4*>(&t[m][c8 * 8]) = x;
+    }
+    __syncthreads();
+    for (int i = tid; i < 64 * 16; i += 256) {              // thread -> (d, 4 consecutive tokens)
+        const int d = i >> 4, g4 = i & 15;
+        const int m0 = mt * 64 + g4 * 4;
+        if (m0 >= KP) continue;
+        u16 hi[4], lo[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { hi[j] = t[g4 * 4 + j][d]; lo[j] = t[g4 * 4 + j][64 + d]; }
+        u16* o = vt + (((long long)b * H + h) * 64 + d) * 2 * KP + split_off(m0, 0);
+        *reinterpret_cast<uint2*>(o) = *reinterpret_cast<const uint2*>(hi);
+        *reinterpret_cast<uint2*>(o + 32) = *reinterpret_cast<const uint2*>(lo);
+    }
+}
+
+int excel_launch_vt_from_planes(const unsigned short* qkvs, unsigned short* vt, int B, int H, int N, int KP, hipStream_t st) {
+    ProfScope prof__(PROF_OTHER, st);
+    EXCEL_CHECK_ARG((KP % 32) == 0 && KP >= N, "vt_from_planes: KP must be a multiple of 32 and >= N");
+    hipLaunchKernelGGL(vt_from_planes_kernel, dim3(cdiv(KP, 64), H, B), dim3(256), 0, st, qkvs, vt, H, N, KP);
+    EXCEL_CHECK_LAUNCH("vt_from_planes");
+    return EXCEL_OK;
 }
 
 int excel_launch_vt_split(const float* v, unsigned short* vt, int B, int H, int N, int KP, long long v_batch_stride, hipStream_t st) {
