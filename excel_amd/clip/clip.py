@@ -60,12 +60,21 @@ def clip_feature_surgery(image_features, text_features, redundant_feats=None, t=
     return full
 
 
-def load(name, device="cuda", state_dict=None, width=768, layers=12, heads=12, patch=16, output_dim=512,
-         input_resolution=224, gemm_mode=None):
+def infer_vit_config(sd):
+    """Architecture from a visual-tower state_dict (keys without the "visual." prefix), as clip/build_model.py:33-38 reads it."""
+    width = int(sd["conv1.weight"].shape[0])
+    layers = len([k for k in sd if k.endswith(".attn.in_proj_weight") or k.endswith(".attn.qkv.weight")])
+    patch = int(sd["conv1.weight"].shape[-1])
+    grid = round((int(sd["positional_embedding"].shape[0]) - 1) ** 0.5)
+    return dict(width=width, layers=layers, heads=width // 64, patch=patch, output_dim=int(sd["proj"].shape[1]), input_resolution=patch * grid)
+
+
+def load(name, device="cuda", state_dict=None, width=None, layers=None, heads=None, patch=None, output_dim=None,
+         input_resolution=None, gemm_mode=None):
     """clip.load("ExCEL_ViT-B/16") counterpart (clip/clip.py:104-154).  `state_dict`: the CLIP checkpoint's state_dict
     ("visual.conv1.weight" ... or a bare visual-tower dict); alternatively `name` may be the path of a local CLIP
     TorchScript/state-dict file (there is no network: nothing is downloaded).  The text tower is kept when its keys are
-    present.  Returns (model, None)."""
+    present; the architecture is read off the tensors like clip/build_model.py:30-50 unless given.  Returns (model, None)."""
     if state_dict is None:
         import os
         if isinstance(name, str) and os.path.isfile(name):
@@ -84,8 +93,12 @@ def load(name, device="cuda", state_dict=None, width=768, layers=12, heads=12, p
             text_sd[k] = v
         elif not has_prefix:
             sd[k] = v
-    vis = VisionTransformer(input_resolution, patch, width, layers, heads, output_dim, state_dict=sd, device=device,
-                            gemm_mode=gemm_mode)
+    cfg = infer_vit_config(sd)                                    # build_model.py:33-38; explicit arguments override
+    for k, v in dict(width=width, layers=layers, heads=heads, patch=patch, output_dim=output_dim, input_resolution=input_resolution).items():
+        if v is not None:
+            cfg[k] = v
+    vis = VisionTransformer(cfg["input_resolution"], cfg["patch"], cfg["width"], cfg["layers"], cfg["heads"], cfg["output_dim"], state_dict=sd,
+                            device=device, gemm_mode=gemm_mode)
     return ExCEL_CLIP(vis, text_sd if "text_projection" in text_sd else None), None
 
 

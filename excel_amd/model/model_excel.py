@@ -24,10 +24,9 @@ class ExCEL_model:
         self.embedding_dim = embedding_dim
         self.in_channels = in_channels
         self.device = device
-        cfg = dict(width=768, layers=12, heads=12, patch=16, output_dim=512, input_resolution=224)
-        cfg.update(vit_cfg or {})
-        self.encoder, _ = clip.load(clip_model, device=device, state_dict=state_dict, gemm_mode=gemm_mode, **cfg)   # :25
-        self.encoder.visual.reload_self_attn(layers=6, feat_size=img_size // cfg["patch"], mode=mode)   # :26
+        # the tower's shape is read off the checkpoint (clip/build_model.py:33-38); `vit_cfg` overrides individual fields
+        self.encoder, _ = clip.load(clip_model, device=device, state_dict=state_dict, gemm_mode=gemm_mode, **(vit_cfg or {}))   # :25
+        self.encoder.visual.reload_self_attn(layers=6, feat_size=img_size // self.encoder.visual.patch_size, mode=mode)   # :26
         if text_attr is not None:          # a pre-aggregated [C,T] bank (tests / cached banks)
             self.integral_text_features, self.attr_flag = None, None
             self.text_attr = torch.as_tensor(text_attr).float().to(device)

@@ -347,3 +347,12 @@ def test_coco_on_disk_dataset(tmp_path):
     assert n == name and image.shape == (18, 22, 3) and np.array_equal(image[..., 0], image[..., 2])
     assert np.array_equal(label, lab) and np.array_equal(cls, oh)
     assert len(coco.class_list) == 81 and coco.class_list[1] == "person" and coco.class_list[80] == "toothbrush"
+
+
+def test_infer_vit_config_from_state_dict():
+    """clip/build_model.py:33-38: width / layers / patch / grid / output_dim read off the checkpoint tensors."""
+    from excel_amd.clip.clip import infer_vit_config
+    from oracle.vit import VitConfig, make_vit_weights
+    cfg = VitConfig(width=128, layers=8, heads=2, patch=16, out_dim=64, input_resolution=64, n_surgery=5)
+    got = infer_vit_config(make_vit_weights(cfg, seed=1))
+    assert got == dict(width=128, layers=8, heads=2, patch=16, output_dim=64, input_resolution=64)
