@@ -31,6 +31,22 @@ GEMM_GFLOP_PER_IMG = 0.925 + 12 * (2.778 + 0.926 + 7.408) + 5 * (0.926 + 0.947) 
 VIT_CAM_GFLOP_PER_IMG = 181.2  # the reference algorithm's ViT + CAM work
 
 
+def gemm_bytes_per_step(B, N=785, D=768, L=12, n_surgery=5, C=512, patch_k=768):
+    """Algorithmic operand + result bytes of the bf16x3 GEMM launches of one step (each matrix touched once; a split-bf16 matrix
+    has the byte size of its fp32 source): -> (bytes per step, launches per step).  Compared with `traffic` in the roofline block.
+    (The last block's original-path proj/MLP run on the cls rows only, so this over-counts by ~4 %.)"""
+    M, f = B * N, 4
+    qkv = (M * D + 3 * D * D + 3 * M * D) * f                     # A, W, q|k|v split
+    proj = (M * D + D * D + 2 * M * D) * f                        # A, W, residual in, result
+    fc1 = (M * D + 4 * D * D + 4 * M * D) * f
+    fc2 = (4 * M * D + 4 * D * D + 2 * M * D) * f
+    asv = B * (N * 800 + D * 800 + N * D) * f                     # A_sum . V per image (K padded to 800)
+    embed = (B * (N - 1) * patch_k + D * patch_k + B * (N - 1) * D) * f
+    final = (M * D + D * C + M * C) * f
+    std, sur = qkv + proj + fc1 + fc2, qkv + 2 * proj + fc1 + fc2 + asv
+    return (L - n_surgery) * std + n_surgery * sur + embed + final, (L - n_surgery) * 4 + n_surgery * 6 + 2
+
+
 def par_bytes_per_image(C, H=448, W=448):
     """20 x (48 + 2C) * H*W*4  +  aff build (3 + 48) * H*W*4."""
     return 20 * (48 + 2 * C) * H * W * 4 + (3 + 48) * H * W * 4
@@ -206,6 +222,7 @@ def main():
                 "launches_per_step": prof_all[cat]["launches"] // steps,
                 "algorithmic_gflop_per_image": round(prof_all[cat]["work"] / steps / B / 1e9, 3),
                 "survey_gflop_per_image": round(GEMM_GFLOP_PER_IMG, 3),
+                "algorithmic_bytes_per_launch": int(gemm_bytes_per_step(B)[0] / gemm_bytes_per_step(B)[1]) if mode == "bf16x3" else None,
             }
             if mode == "bf16x3":
                 # the kernel issues 3 bf16 MFMAs per algorithmic product: matrix-pipe utilisation is 3x the algorithmic fraction
