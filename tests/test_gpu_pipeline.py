@@ -789,3 +789,39 @@ def test_infer_lam_on_disk_voc(gpu, tmp_path):
     assert np.abs(host(total) - host(total2)).sum() <= 1e-3 * npix
     lam, keys = imutils.load_logits(str(tmp_path / "logits" / (ids[2] + ".npy")))
     assert lam.shape == (3, 110, 104) and list(keys) == [2, 11]
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_random_shapes_soak_vs_oracle(gpu, case):
+    """Random network size / batch / class set / label size / caa threshold through the batched pipeline (exact-fp32 mode):
+    labels agree with the oracle and the device histogram equals fast_hist of those labels (tools_dev/soak.py runs more cases)."""
+    from excel_amd.model import ExCEL_model
+    from excel_amd.pipeline import TrainingFreePipeline
+    rs = np.random.RandomState(2000 + case)
+    S = int(rs.choice([64, 96, 128, 160]))
+    B = int(rs.randint(1, 5))
+    F_ = int(rs.randint(2, 7))
+    T = F_ + int(rs.randint(1, 6))
+    H, W = int(rs.randint(20, 150)), int(rs.randint(20, 150))
+    w = make_vit_weights(TINY, seed=int(rs.randint(0, 100)))
+    text = rs.standard_normal((T, 64)).astype(np.float32)
+    text /= np.linalg.norm(text, axis=1, keepdims=True)
+    model = ExCEL_model(clip_model="tiny", num_classes=F_ + 1, img_size=S, mode="train", state_dict=w, vit_cfg=TINY_KW, text_attr=text.T.copy(),
+                        gemm_mode="f32")
+    wo = oracle.vit.reload_self_attn(w, TINY, S // 16, "train")
+    imgs = rs.standard_normal((B, 3, S, S)).astype(np.float32)
+    gts = rs.randint(0, F_ + 1, (B, H, W)).astype(np.uint8)
+    gts[rs.rand(B, H, W) < 0.03] = 255
+    cls = np.zeros((B, F_), np.float32)
+    for b in range(B):
+        cls[b, rs.choice(F_, size=int(rs.randint(1, min(F_, 4) + 1)), replace=False)] = 1
+    thr = float(rs.choice([0.79, 0.88, 0.5]))
+    pipe = TrainingFreePipeline(model, num_classes=F_ + 1, smax=int(cls.sum(1).max()), caa_thre=thr)
+    lab = host(pipe.run_batch(dev(imgs), dev(cls), dev(gts)))
+    par = oracle.par.PAR([1, 2, 4, 8, 12, 24], 20)
+    ref_hist = np.zeros((F_ + 1, F_ + 1), np.int64)
+    for b in range(B):
+        r = oracle.pipeline.run_sample(imgs[b], cls[b], (H, W), wo, TINY, text.T.copy(), F_, par, S, caa_thre=thr)
+        assert float(np.mean(lab[b] == r)) >= 0.995
+        ref_hist += oracle.evaluate.fast_hist(gts[b].flatten(), lab[b].flatten(), F_ + 1)
+    assert np.array_equal(host(pipe.hist), ref_hist)
