@@ -791,10 +791,12 @@ def test_infer_lam_on_disk_voc(gpu, tmp_path):
     assert lam.shape == (3, 110, 104) and list(keys) == [2, 11]
 
 
+@pytest.mark.parametrize("gemm_mode,min_agree", [("f32", 0.9995), ("bf16x3", 0.999)])
 @pytest.mark.parametrize("case", range(6))
-def test_random_shapes_soak_vs_oracle(gpu, case):
-    """Random network size / batch / class set / label size / caa threshold through the batched pipeline (exact-fp32 mode):
-    labels agree with the oracle and the device histogram equals fast_hist of those labels (tools_dev/soak.py runs more cases)."""
+def test_random_shapes_soak_vs_oracle(gpu, case, gemm_mode, min_agree):
+    """Random network size / batch / class set / label size / caa threshold through the batched pipeline, both matrix-core modes:
+    labels agree with the oracle (>= 99.9 %, the north-star bar; exact mode is at 100 %) and the device histogram equals fast_hist
+    of those labels (tools_dev/soak.py runs more cases)."""
     from excel_amd.model import ExCEL_model
     from excel_amd.pipeline import TrainingFreePipeline
     rs = np.random.RandomState(2000 + case)
@@ -807,7 +809,7 @@ def test_random_shapes_soak_vs_oracle(gpu, case):
     text = rs.standard_normal((T, 64)).astype(np.float32)
     text /= np.linalg.norm(text, axis=1, keepdims=True)
     model = ExCEL_model(clip_model="tiny", num_classes=F_ + 1, img_size=S, mode="train", state_dict=w, vit_cfg=TINY_KW, text_attr=text.T.copy(),
-                        gemm_mode="f32")
+                        gemm_mode=gemm_mode)
     wo = oracle.vit.reload_self_attn(w, TINY, S // 16, "train")
     imgs = rs.standard_normal((B, 3, S, S)).astype(np.float32)
     gts = rs.randint(0, F_ + 1, (B, H, W)).astype(np.uint8)
@@ -822,6 +824,6 @@ def test_random_shapes_soak_vs_oracle(gpu, case):
     ref_hist = np.zeros((F_ + 1, F_ + 1), np.int64)
     for b in range(B):
         r = oracle.pipeline.run_sample(imgs[b], cls[b], (H, W), wo, TINY, text.T.copy(), F_, par, S, caa_thre=thr)
-        assert float(np.mean(lab[b] == r)) >= 0.995
+        assert float(np.mean(lab[b] == r)) >= min_agree
         ref_hist += oracle.evaluate.fast_hist(gts[b].flatten(), lab[b].flatten(), F_ + 1)
     assert np.array_equal(host(pipe.hist), ref_hist)

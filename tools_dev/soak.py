@@ -17,7 +17,7 @@ for case in range(int(sys.argv[1]) if len(sys.argv) > 1 else 16):
     H, W = int(rs.randint(20, 150)), int(rs.randint(20, 150))
     w = make_vit_weights(TINY, seed=int(rs.randint(0, 100)))
     text = rs.standard_normal((T, 64)).astype(np.float32); text /= np.linalg.norm(text, axis=1, keepdims=True)
-    model = ExCEL_model(clip_model="tiny", num_classes=F_ + 1, img_size=S, mode="train", state_dict=w, vit_cfg=KW, text_attr=text.T.copy(), gemm_mode="f32")
+    model = ExCEL_model(clip_model="tiny", num_classes=F_ + 1, img_size=S, mode="train", state_dict=w, vit_cfg=KW, text_attr=text.T.copy(), gemm_mode=os.environ.get("SOAK_MODE", "f32"))
     wo = oracle.vit.reload_self_attn(w, TINY, S // 16, "train")
     imgs = rs.standard_normal((B, 3, S, S)).astype(np.float32)
     gts = rs.randint(0, F_ + 1, (B, H, W)).astype(np.uint8); gts[rs.rand(B, H, W) < 0.03] = 255
