@@ -69,21 +69,53 @@ def infer_vit_config(sd):
     return dict(width=width, layers=layers, heads=width // 64, patch=patch, output_dim=int(sd["proj"].shape[1]), input_resolution=patch * grid)
 
 
+# checkpoint file names of the published CLIP archives (the table of clip/clip.py:32-52 maps a model name to a download URL whose
+# last path component is this file; the reference's downloader stores it under ~/.cache/clip, :120)
+_MODEL_FILES = {"ViT-B/16": "ViT-B-16.pt", "CS-ViT-B/16": "ViT-B-16.pt", "ExCEL_ViT-B/16": "ViT-B-16.pt",
+                "ViT-B/32": "ViT-B-32.pt", "CS-ViT-B/32": "ViT-B-32.pt", "ViT-L/14": "ViT-L-14.pt", "CS-ViT-L/14": "ViT-L-14.pt",
+                "ViT-L/14@336px": "ViT-L-14-336px.pt", "CS-ViT-L/14@336px": "ViT-L-14-336px.pt"}
+
+
+def available_models():
+    return list(_MODEL_FILES)
+
+
+def find_checkpoint(name, download_root=None):
+    """Path of the CLIP checkpoint `name` denotes, or None: a file path as is (clip/clip.py:122-123); a model name is looked up where
+    the reference's downloader would have put it (`download_root`, $EXCEL_CLIP_ROOT, ~/.cache/clip; :120).  Nothing is downloaded."""
+    import os
+    if not isinstance(name, str):
+        return None
+    if os.path.isfile(name):
+        return name
+    if name in _MODEL_FILES:
+        for root in (download_root, os.environ.get("EXCEL_CLIP_ROOT"), os.path.expanduser("~/.cache/clip")):
+            if root and os.path.isfile(os.path.join(root, _MODEL_FILES[name])):
+                return os.path.join(root, _MODEL_FILES[name])
+    return None
+
+
+def read_checkpoint(path):
+    """JIT archive (:138-141, the published files) or plain state_dict (:147) -> state_dict on the CPU."""
+    try:
+        return torch.jit.load(path, map_location="cpu").state_dict()
+    except RuntimeError:
+        return torch.load(path, map_location="cpu")
+
+
 def load(name, device="cuda", state_dict=None, width=None, layers=None, heads=None, patch=None, output_dim=None,
-         input_resolution=None, gemm_mode=None):
+         input_resolution=None, gemm_mode=None, download_root=None):
     """clip.load("ExCEL_ViT-B/16") counterpart (clip/clip.py:104-154).  `state_dict`: the CLIP checkpoint's state_dict
-    ("visual.conv1.weight" ... or a bare visual-tower dict); alternatively `name` may be the path of a local CLIP
-    TorchScript/state-dict file (there is no network: nothing is downloaded).  The text tower is kept when its keys are
+    ("visual.conv1.weight" ... or a bare visual-tower dict); otherwise `name` is a local checkpoint path or a model name resolved
+    by find_checkpoint (there is no network: nothing is downloaded).  The text tower is kept when its keys are
     present; the architecture is read off the tensors like clip/build_model.py:30-50 unless given.  Returns (model, None)."""
     if state_dict is None:
-        import os
-        if isinstance(name, str) and os.path.isfile(name):
-            try:
-                state_dict = torch.jit.load(name, map_location="cpu").state_dict()          # :138-141 the published archives
-            except RuntimeError:
-                state_dict = torch.load(name, map_location="cpu")                           # :147 plain state_dict
-        else:
-            raise RuntimeError("excel_amd.clip.load needs state_dict= or a local checkpoint path (no network: nothing is downloaded)")
+        path = find_checkpoint(name, download_root)
+        if path is None:
+            raise RuntimeError(f"Model {name} not found: excel_amd.clip.load needs state_dict=, a local checkpoint path, or the published "
+                               f"archive under download_root / $EXCEL_CLIP_ROOT / ~/.cache/clip (no network: nothing is downloaded); "
+                               f"known names = {available_models()}")
+        state_dict = read_checkpoint(path)
     sd, text_sd = {}, {}
     has_prefix = any(k.startswith("visual.") for k in state_dict)
     for k, v in state_dict.items():

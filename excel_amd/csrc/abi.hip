@@ -475,14 +475,23 @@ static int vit_forward_impl(excel_vit_t h, const float* img, int B, int S, void*
         const bool cls_only = surgery && l == L - 1 && !feats_out;
         if (bf)   // V^T in split format: B operand of the bf16x3 P.V (all blocks) and of A_sum.V (surgery blocks)
             TRY(excel_launch_vt_from_planes(qkvs, (unsigned short*)ws.vt, B, H, N, ws.KP, st));
-        TRY(excel_launch_attn_rowpass(ws.qkvh, ws.ao, ws.stats, B, H, N, 64, scale, surgery ? 4 : 1, st, bf, qkvs, cls_only ? 1 : (1 << 30),
-                                      bf ? (const unsigned short*)ws.vt : nullptr, ws.KP));
         const bool in_aff = w_aff && l >= L - aff_layers;
         float* attn_l = (n_attn_out && l >= L - n_attn_out) ? attn_out + (size_t)(l - (L - n_attn_out)) * B * N * N : nullptr;
+        // bf16x3 mode: the strip-resident kernel (attn_strip.hip) owns the softmax statistics of q.q / k.k / v.v and of the
+        // q.k weights, so the row pass only runs its flash part (attention output of the original path)
+        const bool strip = bf && N <= 40 * 32;
+        TRY(excel_launch_attn_rowpass(ws.qkvh, ws.ao, ws.stats, B, H, N, 64, scale, (surgery && !strip) ? 4 : 1, st, bf, qkvs,
+                                      cls_only ? 1 : (1 << 30), bf ? (const unsigned short*)ws.vt : nullptr, ws.KP));
         if (surgery || in_aff || attn_l) {
-            TRY(excel_launch_attn_accum(ws.qkvh, ws.stats, surgery ? ws.a_sum : nullptr, in_aff ? w_aff : nullptr, attn_l, B, H, N,
-                                        bf ? ws.KP : ws.NP, 64, scale, surgery ? 1 : 0, surgery ? 1.f : 1.f / (float)H,
-                                        1.f / (float)aff_layers, (l == L - aff_layers) ? 1 : 0, st, qkvs, bf ? 1 : 0, ex_attn));
+            if (strip) {
+                TRY(excel_launch_attn_strip(qkvs, surgery ? (unsigned short*)ws.a_sum : nullptr, in_aff ? w_aff : nullptr, attn_l, B, H, N, ws.KP,
+                                            64, scale, surgery ? 1 : 0, surgery ? 1.f : 1.f / (float)H, 1.f / (float)aff_layers,
+                                            (l == L - aff_layers) ? 1 : 0, ex_attn, st));
+            } else {
+                TRY(excel_launch_attn_accum(ws.qkvh, ws.stats, surgery ? ws.a_sum : nullptr, in_aff ? w_aff : nullptr, attn_l, B, H, N,
+                                            bf ? ws.KP : ws.NP, 64, scale, surgery ? 1 : 0, surgery ? 1.f : 1.f / (float)H,
+                                            1.f / (float)aff_layers, (l == L - aff_layers) ? 1 : 0, st, qkvs, bf ? 1 : 0, ex_attn));
+            }
         }
         if (!surgery) {
             TRY(linear(ws.ao, bw.out_proj_w, sw.out_proj, bw.out_proj_b, ws.x, ws.x, D, D, GEMM_ACT_NONE, GEMM_OUT_PLAIN));   // x += out_proj(attn)

@@ -38,7 +38,10 @@ class ExCEL_model:
                 text_features = clip.encode_text_with_prompt_ensemble(self.encoder, list(class_names), device,
                                                                       prompt_templates=["a clean origami {}."], tokenizer=tokenizer)
             if text_features is None:
-                raise RuntimeError("ExCEL_model needs text_features= or class_names= (+ the CLIP text tower weights and BPE merges file)")
+                # the reference's own default (:31-33): the dataset's class + background prompt lists
+                from ..datasets.clip_text import text_prompts
+                text_features = clip.encode_text_with_prompt_ensemble(self.encoder, text_prompts(num_classes), device,
+                                                                      prompt_templates=["a clean origami {}."], tokenizer=tokenizer)
             self.integral_text_features = torch.as_tensor(text_features).float().to(device)
             self.text_attr, self.attr_flag = attr_aggregate(self.integral_text_features, dataset_name, num_classes - 1,
                                                             num_atrr_clusters, json_file, bank=attr_bank, device=device)   # :34
@@ -76,9 +79,9 @@ class ExCEL_model:
     def to(self, *a, **k):
         return self
 
-    # The learned decoder (decoder_fts_fuse + SegFormerHead, :60-68) is outside this library.  A caller that
-    # owns one plugs it in here: feature_head(all_feats [L,B,N,D]) -> attn_fts [B,C,g,g]; forward then also returns
-    # attn_fts and attn_pred like the reference.
+    # The learned decoder (decoder_fts_fuse + SegFormerHead, :60-68) runs inside the library when `decoder_state_dict` is given
+    # (excel_decoder_forward).  A caller that owns a different head can still plug it in here:
+    # feature_head(all_feats [L,B,N,D]) -> attn_fts [B,C,g,g]; forward then also returns attn_fts and attn_pred like the reference.
     feature_head = None
 
     @staticmethod

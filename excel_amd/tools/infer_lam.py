@@ -5,8 +5,12 @@ Differences from the reference, all deliberate:
     per-class host round trips); `--api_path` runs the reference's per-image call sequence instead;
   * ranks take images r, r+R, ... exactly like :166, accumulate a device-side [nc,nc] int64 confusion matrix and
     exchange it ONCE with an all_gather over RCCL (the reference scores each shard separately and never aggregates);
-  * `--synthetic N` feeds seeded synthetic samples (no VOC / CLIP checkpoint offline); `--model_path` is optional
-    when `--training_free` (the reference loads and then ignores it, :150-152).
+  * weights: `--model` is a CLIP checkpoint path or a model name found under --clip_root / $EXCEL_CLIP_ROOT / ~/.cache/clip
+    (clip.load, model/model_excel.py:25); the class + background prompts are encoded with the checkpoint's text tower
+    (model/model_excel.py:31-33; needs CLIP's BPE merges file: --bpe_path / $EXCEL_BPE_VOCAB).  `--model_path` = the trained
+    decoder checkpoint, required only with `--training_free false` (the reference loads and then ignores it otherwise, :150-152);
+  * `--synthetic N` (no --data_folder) feeds seeded synthetic samples; seeded random weights are used ONLY in that mode and only
+    when no checkpoint can be resolved (logged).  `--data_folder` without a resolvable checkpoint is an error.
 Launch: python -m torch.distributed.run --nproc-per-node R -m excel_amd.tools.infer_lam --synthetic 64 ...
 """
 import argparse
@@ -53,6 +57,9 @@ def get_parser():
     p.add_argument("--synthetic", default=64, type=int, help="number of seeded synthetic samples")
     p.add_argument("--seed", default=1234, type=int)
     p.add_argument("--api_path", default=False, type=_bool, help="per-image reference call sequence instead of the batched pipeline")
+    p.add_argument("--clip_root", default=None, type=str, help="directory holding the published CLIP archive (ViT-B-16.pt); default $EXCEL_CLIP_ROOT, ~/.cache/clip")
+    p.add_argument("--bpe_path", default=None, type=str, help="CLIP's bpe_simple_vocab_16e6.txt.gz (default $EXCEL_BPE_VOCAB)")
+    p.add_argument("--gemm_mode", default=None, type=str, help="bf16x3 (default) | f32")
     return p
 
 
@@ -144,6 +151,54 @@ def build_validation(model=None, par=None, dataset=None, indices=None, device="c
     return hist, nimg, time.time() - t0
 
 
+def resolve_model_inputs(args):
+    """What ExCEL_model is built from (tools/infer_lam.py:144-162, model/model_excel.py:25-34) -> keyword arguments:
+      state_dict          the CLIP checkpoint --model denotes (path, or model name under --clip_root / $EXCEL_CLIP_ROOT / ~/.cache/clip)
+      tokenizer           CLIP's BPE tokenizer (the class/background prompts are encoded by the checkpoint's text tower)
+      decoder_state_dict  --model_path (trained head, `module.` prefixes stripped, positional embedding skipped: :153-160)
+                          when --training_free false
+    Seeded random weights + random unit-norm text features are returned ONLY for --synthetic runs without a resolvable
+    checkpoint; real data without weights raises."""
+    from .. import clip
+    from . import synthetic
+    kw = {}
+    ckpt = clip.clip.find_checkpoint(args.model, getattr(args, "clip_root", None))
+    if ckpt is not None:
+        sd = clip.clip.read_checkpoint(ckpt)
+        kw["state_dict"] = sd
+        if not any(k in sd for k in ("text_projection", "visual.proj")) and "proj" not in sd:
+            raise RuntimeError(f"{ckpt}: not a CLIP checkpoint (no visual.proj / text_projection)")
+        if "text_projection" not in sd:
+            raise RuntimeError(f"{ckpt}: the checkpoint has no text tower (text_projection ...): the class / background prompts of "
+                               "model/model_excel.py:31-33 cannot be encoded")
+        from ..clip import bpe
+        kw["tokenizer"] = bpe.BPETokenizer(getattr(args, "bpe_path", None))            # raises FileNotFoundError with the remedy
+        logging.info(f"CLIP weights: {ckpt}")
+    elif getattr(args, "data_folder", None):
+        raise RuntimeError(f"--data_folder given but no CLIP checkpoint found for --model {args.model!r}: pass a checkpoint path, or put "
+                           "the published archive (ViT-B-16.pt) under --clip_root / $EXCEL_CLIP_ROOT / ~/.cache/clip. "
+                           "Refusing to score real data with random weights.")
+    else:
+        T = 45 if args.num_classes <= 21 else 103
+        kw["state_dict"] = synthetic.make_vit_state_dict(seed=0)
+        kw["text_features"] = synthetic.make_text_features(T)
+        logging.warning("SYNTHETIC run: seeded random ViT-B/16 weights and random text features (no CLIP checkpoint resolved); "
+                        "the mIoU below is a throughput / plumbing check, not a result")
+    if not bool(getattr(args, "training_free", True)):
+        if not args.model_path or not os.path.isfile(args.model_path):
+            raise RuntimeError("--training_free false needs --model_path (the trained decoder checkpoint, tools/infer_lam.py:150-160)")
+        trained = torch.load(args.model_path, map_location="cpu")
+        dec = {}
+        for k, v in trained.items():                                                        # :153-160
+            k = k.replace("module.", "")
+            if "encoder.visual.positional_embedding" not in k and k.startswith(("decoder_fts_fuse.", "decoder.")):
+                dec[k] = v
+        if not dec:
+            raise RuntimeError(f"{args.model_path}: no decoder_fts_fuse.* / decoder.* tensors")
+        kw["decoder_state_dict"] = dec
+    return kw
+
+
 def validate(args=None):
     from ..model.model_excel import ExCEL_model
     from ..utils import evaluate
@@ -162,14 +217,14 @@ def validate(args=None):
     else:
         dataset = synthetic.SyntheticSegDataset(args.synthetic, (args.resize_size, args.resize_size),
                                                 num_classes=args.num_classes, seed=args.seed, u8_images=getattr(args, "u8_input", False))
-    T = 45 if args.num_classes <= 21 else 103
     model = ExCEL_model(clip_model=args.model, embedding_dim=args.embedding_dim, in_channels=args.in_channels,
                         dataset_name=args.dataset_name, num_classes=args.num_classes, num_atrr_clusters=args.num_attri,
                         json_file=args.attr_json, img_size=args.resize_size, mode=args.infer_set, device=device,
-                        state_dict=synthetic.make_vit_state_dict(seed=0), text_features=synthetic.make_text_features(T))
+                        gemm_mode=getattr(args, "gemm_mode", None), **resolve_model_inputs(args))
     par = PAR(num_iter=20, dilations=[1, 2, 4, 8, 12, 24])                                  # :168
     idx = shard_indices(len(dataset), rank, world)                                          # :166
     hist, nimg, secs = build_validation(model, par, dataset, idx, device, args)
+    validate.last_model = model                                                             # handle for callers / tests
     per_rank, total = gather_hists(hist)
     score = evaluate.scores_from_hist(total)
     if rank == 0:
