@@ -30,7 +30,10 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=True):
+    """EXCEL_DEV=1 in the environment adds -DEXCEL_DEV: ablation / experiment switches read from environment variables are compiled
+    in (development only; the shipped library has none)."""
     hipcc = _hipcc()
+    flags = FLAGS + (["-DEXCEL_DEV"] if os.environ.get("EXCEL_DEV") == "1" else [])
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs, jobs = [], []
     for s in SOURCES:
@@ -38,7 +41,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([hipcc] + flags + ["-c", src, "-o", obj])
     if jobs:
         with cf.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             for cmd, res in zip(jobs, ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs)):

@@ -38,7 +38,6 @@ struct RowpassArgs {
     int vt_kp;
 };
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 
 // BF = true: the score products run as bf16x3 (3 x v_mfma_f32_32x32x16_bf16 on split-bf16 q/k/v, see gemm_bf16x3.hip);
@@ -276,6 +275,7 @@ __device__ __forceinline__ void rowpass_body_bf(const RowpassArgs& p, float* sme
     const u16* Ysp = p.qkvs + (((long long)b * 3 + ty) * p.H + h) * (long long)N * 128;
     const u16* VT = FLASH ? p.vt + (((long long)b * p.H + h) * 64) * 2 * p.vt_kp : nullptr;
     u16* ring = reinterpret_cast<u16*>(smem);            // [3][K tile | V^T tile]
+    const unsigned ring_b = lds_addr(ring);
 
     const int q0 = qblk * 128 + wave * 32;
     const int qrow = min(q0 + r, N - 1);
@@ -286,6 +286,9 @@ __device__ __forceinline__ void rowpass_body_bf(const RowpassArgs& p, float* sme
         xl[s4] = *reinterpret_cast<const bf16x8*>(Xsp + (long long)qrow * 128 + 64 + s4 * 16 + kh * 8);
     }
 
+    // consume the query fragments once BEFORE any LDS-DMA is in flight: the compiler then places its wait for these ordinary loads
+    // here and not (as vmcnt(0), draining the DMA queue) in front of their first use inside the key loop
+    asm volatile("" : "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]), "+v"(xl[0]), "+v"(xl[1]), "+v"(xl[2]), "+v"(xl[3]));
     // per-lane source offsets of this wave's loads: K rows 8w..8w+7 (2 instr x 4 rows), V^T rows 16w..16w+15 (2 instr x 8 rows)
     int koff[2], krow[2];
 #pragma unroll
@@ -335,17 +338,26 @@ __device__ __forceinline__ void rowpass_body_bf(const RowpassArgs& p, float* sme
         __builtin_amdgcn_s_barrier();
         if (kt + 2 < nkt) issue(kt + 2, stage == 0 ? 2 : stage - 1);
         if (q0 >= N) { stage = (stage == 2) ? 0 : stage + 1; continue; }      // wave-uniform: all 32 query rows are padding -> only keep the ring moving
-        const u16* kr = ring + stage * STAGE_EL + r * 128;
+        // LDS reads as inline asm (common.h): a compiler-visible ds_read behind pending LDS-DMA gets an s_waitcnt vmcnt(0) in front of
+        // it, which drained the two key tiles in flight on every step
+        const unsigned kr = ring_b + (stage * STAGE_EL + r * 128) * 2;
         f32x16 s;
 #pragma unroll
         for (int e = 0; e < 16; ++e) s[e] = 0.f;
+        {
+            bf16x8 yh[4], yl[4];
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            const bf16x8 yh = *reinterpret_cast<const bf16x8*>(kr + (((s4 * 2 + kh) ^ (r & 15)) * 8));
-            const bf16x8 yl = *reinterpret_cast<const bf16x8*>(kr + (((8 + s4 * 2 + kh) ^ (r & 15)) * 8));
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl, xh[s4], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh, xl[s4], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh, xh[s4], s, 0, 0, 0);
+            for (int s4 = 0; s4 < 4; ++s4) {
+                yh[s4] = lds_read16(kr + (((s4 * 2 + kh) ^ (r & 15)) * 16));
+                yl[s4] = lds_read16(kr + (((8 + s4 * 2 + kh) ^ (r & 15)) * 16));
+            }
+            lds_wait8(yh, yl);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl[s4], xh[s4], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[s4], xl[s4], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[s4], xh[s4], s, 0, 0, 0);
+            }
         }
         // softmax bookkeeping in log2 units: p = exp2(s*c2 - m2), c2 = scale*log2(e)  (one fma + one v_exp per element);
         // only the last key tile can contain keys >= N, so the mask lives in a uniform branch.
@@ -385,18 +397,23 @@ __device__ __forceinline__ void rowpass_body_bf(const RowpassArgs& p, float* sme
                 ph[e >> 3][e & 7] = (__bf16)hf;
                 pl[e >> 3][e & 7] = (__bf16)(s[e] - hf);
             }
-            const u16* vt16 = ring + stage * STAGE_EL + KT_EL;
+            const unsigned vt16 = ring_b + (stage * STAGE_EL + KT_EL) * 2;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
                 const int d = dt * 32 + r, msk = (d >> 1) & 7;
-                const u16* rowp = vt16 + d * 64 + kh * 4;
+                const unsigned rowp = vt16 + (d * 64 + kh * 4) * 2;
+                bf16x4 vq[8];                                   // [ks][h0 h1 l0 l1]
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-                    const bf16x4 h0 = *reinterpret_cast<const bf16x4*>(rowp + (((2 * ks) ^ msk) * 8));
-                    const bf16x4 h1 = *reinterpret_cast<const bf16x4*>(rowp + (((2 * ks + 1) ^ msk) * 8));
-                    const bf16x4 l0 = *reinterpret_cast<const bf16x4*>(rowp + (((4 + 2 * ks) ^ msk) * 8));
-                    const bf16x4 l1 = *reinterpret_cast<const bf16x4*>(rowp + (((5 + 2 * ks) ^ msk) * 8));
+                    vq[ks * 4 + 0] = lds_read8h(rowp + (((2 * ks) ^ msk) * 16));
+                    vq[ks * 4 + 1] = lds_read8h(rowp + (((2 * ks + 1) ^ msk) * 16));
+                    vq[ks * 4 + 2] = lds_read8h(rowp + (((4 + 2 * ks) ^ msk) * 16));
+                    vq[ks * 4 + 3] = lds_read8h(rowp + (((5 + 2 * ks) ^ msk) * 16));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vq[0]), "+v"(vq[1]), "+v"(vq[2]), "+v"(vq[3]), "+v"(vq[4]), "+v"(vq[5]), "+v"(vq[6]), "+v"(vq[7])::"memory");
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf16x4 h0 = vq[ks * 4], h1 = vq[ks * 4 + 1], l0 = vq[ks * 4 + 2], l1 = vq[ks * 4 + 3];
                     const bf16x8 vh = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
                     const bf16x8 vl = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
                     oT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph[ks], oT[dt], 0, 0, 0);

@@ -19,30 +19,9 @@
 #include "common.h"
 #include "excel_internal.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 
 #define GLDS(src, dst) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
-
-// LDS accesses of the streaming loop are written as inline asm: the compiler's wait-count pass treats every ds_read as a
-// possible reader of a pending global_load_lds and drains the whole DMA queue (s_waitcnt vmcnt(0)) in front of it, which
-// serialises the tile stream (that is what held attn_accum_bf_kernel at ~20 % matrix-core busy).  The waits here are explicit.
-__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)p; }
-__device__ __forceinline__ bf16x8 lds_read16(unsigned addr) {
-    f32x4 v;
-    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
-    return __builtin_bit_cast(bf16x8, v);
-}
-__device__ __forceinline__ float2 lds_read8(unsigned addr) {
-    float2 v;
-    asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr) : "memory");
-    return v;
-}
-__device__ __forceinline__ void lds_write8(unsigned addr, float2 v) { asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
-// s_waitcnt lgkmcnt(0) that the consumers of the eight fragments depend on (keeps the MFMAs behind the wait)
-__device__ __forceinline__ void lds_wait8(bf16x8 (&a)[4], bf16x8 (&b)[4]) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])::"memory");
-}
 
 struct StripArgs {
     const u16* qkvs;      // split-bf16 q|k|v head-major [B,3,H,N][hi 64 | lo 64]
@@ -60,13 +39,13 @@ struct StripArgs {
     int surgery;          // 1: sweep A + sweep W, 0: sweep W only
 };
 
-template <int NTW>
+template <int NTW, int DBG>
 __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
     constexpr int TILE_EL = 32 * 128;                                    // u16 elements of a 32-row operand tile (8 KB)
     // one LDS object: [wave][slot] key tiles (128 KB) | [parity] query strip of a phase (16 KB)
     __shared__ __attribute__((aligned(1024))) u16 ring[(8 * 2 + 2) * TILE_EL];
     u16* const xs = ring + 8 * 2 * TILE_EL;
-    __shared__ float2 lstat[2 * 8 * 32];                                 // [parity][wave][q] {local max (log2), local sum}
+    __shared__ float2 lstat[2 * 8 * 32];                                 // [parity][wave][q] {row max over the wave's keys (log2), sum}
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nw = blockDim.x >> 6;
@@ -77,75 +56,90 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
     const int b = id / p.nstrips, strip = id - b * p.nstrips;
     const int q0 = strip * 32;
 
-    // this wave's key tiles [first, first + cnt)
+    // this wave's key tiles [first, first + cnt); cnt is NTW or NTW - 1 (host guarantees it)
     const int tb_ = p.ntiles / nw, tr_ = p.ntiles - tb_ * nw;
     const int cnt = tb_ + (wave < tr_ ? 1 : 0);
     const int first = wave * tb_ + min(wave, tr_);
+    const bool full = cnt == NTW;
 
     u16* myring = ring + wave * 2 * TILE_EL;
     const unsigned ring_addr = lds_addr(myring), xs_addr = lds_addr(xs), lstat_addr = lds_addr(lstat);
-    // staging map of one 1-KB wave instruction: 4 rows x 16 chunks of 16 B; chunk c of row rr sits at slot c ^ (rr & 15)
-    const int srow = lane >> 4;                                  // row within the 4-row piece
-    const int sbase = (lane & 15) ^ srow;                        // (lane&15) ^ ((4i + srow) & 15) = sbase ^ (4 (i & 3))
 
-    auto phase_desc = [&](int t, int& h, int& tx, int& ty) {
-        if (t < 3 * H) { h = t / 3; const int ty3 = t - 3 * h; tx = ty3; ty = ty3; }   // q.q, k.k, v.v
-        else { h = t - 3 * H; tx = 0; ty = 1; }                                          // q.k
-    };
-    auto plane = [&](int typ, int h) { return p.qkvs + (((long long)b * 3 + typ) * H + h) * (long long)N * 128; };
-
-    // ---- issue cursor over (phase, tile) in consumption order
-    int it_t, it_j, it_g, it_t1;
-    auto issue_next = [&]() -> bool {
-        if (it_t >= it_t1) return false;
-        int h, tx, ty;
-        phase_desc(it_t, h, tx, ty);
-        const u16* Y = plane(ty, h);
-        const int key0 = (first + it_j) * 32;
-        u16* dst = myring + (it_g & 1) * TILE_EL;
+    // LDS-DMA through a buffer descriptor over this image's q|k|v planes: per-lane byte offsets are loop invariant (4 VGPRs), the
+    // tile / plane position goes into the scalar offset.  One 1-KB wave instruction = 4 rows x 16 chunks of 16 B; chunk c of row rr
+    // lands at slot c ^ (rr & 15) (swizzle on the SOURCE address, the LDS image is lane-linear).  Rows past the end of a plane read
+    // the next plane (finite data, masked below) or, at the end of the image, the descriptor's out-of-range zeros.
+    const long long img_el = 3LL * H * N * 128;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.qkvs + (long long)b * img_el), 0, (int)(img_el * 2), 0x00020000);
+    int voff[4];
+    {
+        const int srow = lane >> 4, sbase = (lane & 15) ^ srow;      // (lane&15) ^ ((4i + srow) & 15) = sbase ^ 4(i & 3)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int key = min(key0 + 4 * i + srow, N - 1);
-            GLDS(Y + (long long)key * 128 + ((sbase ^ (4 * (i & 3))) * 8), dst + i * 512);
-        }
+        for (int i = 0; i < 4; ++i) voff[i] = (4 * i + srow) * 256 + ((sbase ^ (4 * i)) * 16);
+    }
+    auto plane_off = [&](int t, bool xside) -> int {                // byte offset of the (type, head) plane a phase reads
+        int typ, h;
+        if (t < 3 * H) { h = t / 3; typ = t - 3 * h; }              // q.q, k.k, v.v
+        else { h = t - 3 * H; typ = xside ? 0 : 1; }                // q (rows) . k (keys)
+        return (typ * H + h) * N * 256;
+    };
+    typedef __attribute__((address_space(3))) unsigned char* lds_bptr;
+    auto dma_tile = [&](int soff, unsigned dst_byte) {
+        // opaque to the optimiser: otherwise the 16 per-instruction LDS destinations (m0 values) are hoisted out of the loop
+        // into SGPRs that spill (v_readlane + hazard nops inside the loop); recomputed here they are one s_add each
+        asm volatile("" : "+s"(dst_byte));
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_bptr)(unsigned long long)(dst_byte + i * 1024), 16, voff[i & 3], soff + (i >> 2) * 4096, 0, 0);
+    };
+
+    // ---- issue cursor over (phase, tile) in consumption order.  Past the end of a sweep it keeps re-loading the last tile into
+    // the slot just freed (never read again), so every wait in the loop is the same counted vmcnt(8): no end-of-stream branches.
+    int it_t, it_j, it_g, it_t1, it_poff;
+    auto issue_next = [&]() {
+        dma_tile(it_poff + (first + it_j) * 8192, ring_addr + (it_g & 1) * (TILE_EL * 2));
         ++it_g;
-        if (++it_j == cnt) { it_j = 0; ++it_t; }
-        return true;
+        if (it_t < it_t1 - 1 || it_j < cnt - 1) {
+            if (++it_j == cnt) { it_j = 0; ++it_t; it_poff = plane_off(it_t, false); }
+        }
     };
     auto issue_x = [&](int t, int par) {
-        int h, tx, ty;
-        phase_desc(t, h, tx, ty);
-        const u16* X = plane(tx, h);
-        for (int pi = wave; pi < 8; pi += nw) {
-            const int q = min(q0 + 4 * pi + srow, N - 1);
-            GLDS(X + (long long)q * 128 + ((sbase ^ (4 * (pi & 3))) * 8), xs + par * TILE_EL + pi * 512);
-        }
+        const int soff = plane_off(t, true) + q0 * 256;
+        unsigned xb = xs_addr + par * (TILE_EL * 2);
+        asm volatile("" : "+s"(xb));
+        for (int pi = wave; pi < 8; pi += nw)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_bptr)(unsigned long long)(xb + pi * 1024), 16, voff[pi & 3], soff + (pi >> 2) * 4096, 0, 0);
     };
 
     const float c2 = p.scale * 1.4426950408889634f;              // scores enter the softmax in log2 units
     const int last_tile = p.ntiles - 1;
     const bool ragged = (N & 31) != 0;
+    const int nvalid_last = N - last_tile * 32 - 4 * kh;         // accumulator row (e&3)+8(e>>2) of the last tile is a real key iff < this
 
     f32x16 acc[NTW];
 
+    // One sweep over phases [t0, t1).  Program order per phase (the softmax block written after a tile's MFMAs works on the PREVIOUS
+    // tile, so it issues in their shadow: an MFMA occupies the matrix pipe for 32 cycles, a few VALU issue slots):
+    //     X fragments | tile j: MFMA || softmax(tile j-1) | softmax(last tile) | stats -> barrier | factors, accumulate
+    // Softmax is "online" per LANE (a lane owns 16 keys of every tile of its query row): tile j is exponentiated against the running
+    // maximum m_j of tiles 0..j (kept per tile), the lane's sum is rescaled when the maximum moves; the two lane halves of a row
+    // merge, every wave publishes (m, l) and the factor of tile j becomes 2^(m_j - M) / L with the global M, L: exact, single pass.
+    // Measured (profiles/): the waves of a strip run in lock step and are bound by their own in-order instruction streams, so the
+    // VALU work is written with packed fp32 operations (v_pk_fma_f32, v_pk_add_f32) and the statistics exchange is one LDS batch.
     auto run_sweep = [&](int t0, int t1) {
 #pragma unroll
         for (int j = 0; j < NTW; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-        it_t = t0; it_j = 0; it_g = 0; it_t1 = t1;
-        const int total = (t1 - t0) * cnt;
+        it_t = t0; it_j = 0; it_g = 0; it_t1 = t1; it_poff = plane_off(t0, false);
         issue_x(t0, 0);
-        if (t0 + 1 < t1) issue_x(t0 + 1, 1);
-        int ntile_issued = 0;
-        if (issue_next()) ++ntile_issued;
-        if (issue_next()) ++ntile_issued;
-        if (ntile_issued == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if (ntile_issued == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                              // both query strips visible to every wave
-
+        issue_x(min(t0 + 1, t1 - 1), 1);
+        issue_next();
+        issue_next();
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");         // both query strips landed (the two key tiles may be in flight)
+        __builtin_amdgcn_s_barrier();                              // ... and are visible to every wave
         int gc = 0;
+
         for (int t = t0; t < t1; ++t) {
             const int par = (t - t0) & 1;
             // query-strip fragments (B operand): row r, k-step s4 -> chunk (2 s4 + kh) of hi, 8 + (2 s4 + kh) of lo
@@ -160,12 +154,33 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
                 lds_wait8(xh, xl);
             }
             f32x16 s[NTW];
-            bool issued_here = false;
+            float mref[NTW];                                       // running maximum (log2 units) tile j was exponentiated against
+            // finite "minus infinity": a lane whose 16 keys of the (ragged) last tile are all padding must not form (-inf) - (-inf)
+            float m_run = -1e30f, l_run = 0.f;
+            auto softmax_tile = [&](int j) {
+                float tm = fmaxf(s[j][0], s[j][1]);
+#pragma unroll
+                for (int e = 2; e < 16; e += 2) tm = fmaxf(fmaxf(tm, s[j][e]), s[j][e + 1]);       // v_max3_f32
+                const float m_new = fmaxf(m_run, tm * c2);
+                l_run *= __builtin_amdgcn_exp2f(m_run - m_new);    // first tile: 2^(-inf) = 0
+                const f32x2 c22 = {c2, c2}, nm2 = {-m_new, -m_new};
+                f32x2 ps2 = {0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const f32x2 a = __builtin_elementwise_fma(f32x2{s[j][e], s[j][e + 1]}, c22, nm2);
+                    const f32x2 pe = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+                    s[j][e] = pe[0];
+                    s[j][e + 1] = pe[1];
+                    ps2 += pe;
+                }
+                l_run += ps2[0] + ps2[1];
+                m_run = m_new;
+                mref[j] = m_new;
+            };
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
-                if (j < cnt) {
-                    if (gc + 1 < total) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile gc landed (gc+1 may be in flight)
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (j < NTW - 1 || full) {
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                        // tile gc landed (gc+1 may be in flight)
                     const unsigned kr = ring_addr + ((gc & 1) * TILE_EL + r * 128) * 2;
                     bf16x8 yh[4], yl[4];
 #pragma unroll
@@ -174,68 +189,87 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
                         yl[s4] = lds_read16(kr + (((8 + s4 * 2 + kh) ^ (r & 15)) * 16));
                     }
                     lds_wait8(yh, yl);                                                      // fragments in registers: the slot is free
-                    issued_here |= issue_next();                                            // tile gc+2 -> this slot
+                    if (!(DBG & 2)) issue_next();                                           // tile gc+2 -> this slot
                     ++gc;
                     f32x16 sj;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) sj[e] = 0.f;
+                    if (!(DBG & 1)) {
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) {
-                        sj = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl[s4], xh[s4], sj, 0, 0, 0);
-                        sj = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[s4], xl[s4], sj, 0, 0, 0);
-                        sj = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[s4], xh[s4], sj, 0, 0, 0);
+                        for (int s4 = 0; s4 < 4; ++s4) {
+                            sj = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl[s4], xh[s4], sj, 0, 0, 0);
+                            sj = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[s4], xl[s4], sj, 0, 0, 0);
+                            sj = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[s4], xh[s4], sj, 0, 0, 0);
+                        }
+                    } else {
+                        sj[0] = (float)yl[0][0] + (float)yh[3][1] + (float)xh[0][0] + (float)xl[3][1];
+                    }
+                    if (NTW < 5) {                                                          // (at 5 tiles per wave the register file has no room for the overlap)
+                        if (j > 0 && !(DBG & 4)) softmax_tile(j - 1);                       // in the shadow of these MFMAs
                     }
                     if (ragged && first + j == last_tile) {                                 // wave-uniform: keys >= N only here
+                        int lim = nvalid_last;                    // opaque: the 16 lane masks must not be hoisted into (spilled) SGPR pairs
+                        asm volatile("" : "+v"(lim));
 #pragma unroll
                         for (int e = 0; e < 16; ++e)
-                            if (last_tile * 32 + c32_row(e, lane) >= N) sj[e] = -INFINITY;
+                            if ((e & 3) + 8 * (e >> 2) >= lim) sj[e] = -INFINITY;
                     }
                     s[j] = sj;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) s[j][e] = -INFINITY;
                 }
             }
-            // local softmax statistics over this wave's keys (query r lives in lanes r and r+32)
-            float mx = s[0][0];
+            if (!(DBG & 4)) {
+                if (NTW < 5) {
+                    if (full) softmax_tile(NTW - 1);
+                    else if (NTW > 1) softmax_tile(NTW > 1 ? NTW - 2 : 0);
+                } else {
 #pragma unroll
-            for (int j = 0; j < NTW; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[j][e]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c2;
-            float ps = 0.f;
-#pragma unroll
-            for (int j = 0; j < NTW; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    s[j][e] = __builtin_amdgcn_exp2f(fmaf(s[j][e], c2, -mx));
-                    ps += s[j][e];
+                    for (int j = 0; j < NTW; ++j)
+                        if (j < NTW - 1 || full) softmax_tile(j);
                 }
-            ps += __shfl_xor(ps, 32, 64);
-            const unsigned ls = lstat_addr + (t & 1) * 8 * 32 * 8;
-            if (kh == 0) lds_write8(ls + (wave * 32 + r) * 8, make_float2(mx, ps));
+            } else {
+                m_run = 0.f; l_run = 1.f;
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) mref[j] = 0.f;
+            }
+            // the two lane halves of a query row merge their (m, l); one entry per wave goes to the exchange
+            {
+                const float m_o = __shfl_xor(m_run, 32, 64), l_o = __shfl_xor(l_run, 32, 64);
+                const float m_w = fmaxf(m_run, m_o);
+                l_run = l_run * __builtin_amdgcn_exp2f(m_run - m_w) + l_o * __builtin_amdgcn_exp2f(m_o - m_w);
+                m_run = m_w;
+            }
+            const unsigned ls = lstat_addr + (t & 1) * (8 * 32 * 8);
+            if (kh == 0) lds_write8(ls + (wave * 32 + r) * 8, make_float2(m_run, l_run));
             // the query strip of phase t+1 (issued one phase ago) must have landed before the barrier publishes it
-            if (issued_here) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                    // (a key tile was issued after it)
             __builtin_amdgcn_s_barrier();                                                   // raw: no vmcnt(0) drain of the tile stream
-            if (t + 2 < t1) issue_x(t + 2, par);                                            // slot of phase t: every wave has its fragments
-            float2 st8[8];
+            if (!(DBG & 2)) issue_x(min(t + 2, t1 - 1), par);                               // slot of phase t: every wave has its fragments
+            // (m, l) of all waves -> this lane's per-tile factors 2^(m_j - M) / L
+            float M, L = 0.f;
+            {
+                float2 st[8];
 #pragma unroll
-            for (int w2 = 0; w2 < 8; ++w2) st8[w2] = lds_read8(ls + ((w2 < nw ? w2 : 0) * 32 + r) * 8);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(st8[0]), "+v"(st8[1]), "+v"(st8[2]), "+v"(st8[3]), "+v"(st8[4]), "+v"(st8[5]), "+v"(st8[6]), "+v"(st8[7])::"memory");
-            float M = st8[0].x;
+                for (int w2 = 0; w2 < 8; ++w2) st[w2] = lds_read8(ls + r * 8 + (w2 < nw ? w2 : 0) * (32 * 8));
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(st[0]), "+v"(st[1]), "+v"(st[2]), "+v"(st[3]), "+v"(st[4]), "+v"(st[5]), "+v"(st[6]), "+v"(st[7])::"memory");
+                M = fmaxf(fmaxf(st[0].x, st[1].x), st[2].x);                              // slots >= nw repeat slot 0
+                M = fmaxf(fmaxf(M, st[3].x), st[4].x);
+                M = fmaxf(fmaxf(M, st[5].x), fmaxf(st[6].x, st[7].x));
 #pragma unroll
-            for (int w2 = 1; w2 < 8; ++w2) M = fmaxf(M, st8[w2].x);          // slots >= nw repeat wave 0
-            float L = 0.f;
-#pragma unroll
-            for (int w2 = 0; w2 < 8; ++w2)
-                if (w2 < nw) L += st8[w2].y * __builtin_amdgcn_exp2f(st8[w2].x - M);
-            const float f = __builtin_amdgcn_exp2f(mx - M) / L;
+                for (int w2 = 0; w2 < 8; ++w2)
+                    if (w2 < nw) L = fmaf(st[w2].y, __builtin_amdgcn_exp2f(st[w2].x - M), L);
+            }
+            const float rl = 1.f / L;
 #pragma unroll
             for (int j = 0; j < NTW; ++j)
-                if (j < cnt) {
+                if (j < NTW - 1 || full) {
+                    const float f = __builtin_amdgcn_exp2f(mref[j] - M) * rl;
+                    const f32x2 f2 = {f, f};
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[j][e] = fmaf(s[j][e], f, acc[j][e]);
+                    for (int e = 0; e < 16; e += 2) {
+                        const f32x2 a = __builtin_elementwise_fma(f32x2{s[j][e], s[j][e + 1]}, f2, f32x2{acc[j][e], acc[j][e + 1]});
+                        acc[j][e] = a[0];
+                        acc[j][e + 1] = a[1];
+                    }
                 }
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -327,18 +361,36 @@ int excel_launch_attn_strip(const unsigned short* qkvs, unsigned short* a_sum, f
     const int ntiles = cdiv(N, 32);
     if (ntiles > 40) return 1;                                  // > 8 waves x 5 tiles: not resident, use the two-pass kernels
     ProfScope prof__(PROF_ATTN_ACCUM, st);
-    int ntw = cdiv(ntiles, 8);
-    // prefer 7 waves when that keeps the per-SIMD tile load as even (25 tiles: 4,4,4,4,3,3,3)
-    int nw = cdiv(ntiles, ntw);
+    const int ntw = cdiv(ntiles, 8);
+    const int nw = cdiv(ntiles, ntw);                          // 25 tiles: 7 waves x (4,4,4,4,3,3,3)
+    EXCEL_CHECK_ARG(ntiles / nw >= ntw - 1 && (long long)3 * H * N * 256 < (1LL << 31), "attn_strip: unsupported shape");
     StripArgs a{qkvs, a_sum, w_aff, attn_out, surgery ? ex_attn : nullptr, B, H, N, KP, ntiles, cdiv(N, 32), scale, w_scale, aff_scale, (float)H,
                 aff_init, surgery};
     const dim3 grid(B * a.nstrips), block(nw * 64);
+#ifdef EXCEL_DEV
+    // dev build only: ablation variants (bit0 no MFMA, bit1 no DMA in the loop, bit2 no softmax, bit3 no schedule groups)
+    static const int dbg = getenv("EXCEL_STRIP_DBG") ? atoi(getenv("EXCEL_STRIP_DBG")) : 0;
+    if (dbg && ntw == 4) {
+        switch (dbg) {
+            case 1: hipLaunchKernelGGL((attn_strip_kernel<4, 1>), grid, block, 0, st, a); break;
+            case 2: hipLaunchKernelGGL((attn_strip_kernel<4, 2>), grid, block, 0, st, a); break;
+            case 3: hipLaunchKernelGGL((attn_strip_kernel<4, 3>), grid, block, 0, st, a); break;
+            case 4: hipLaunchKernelGGL((attn_strip_kernel<4, 4>), grid, block, 0, st, a); break;
+            case 5: hipLaunchKernelGGL((attn_strip_kernel<4, 5>), grid, block, 0, st, a); break;
+            case 6: hipLaunchKernelGGL((attn_strip_kernel<4, 6>), grid, block, 0, st, a); break;
+            case 7: hipLaunchKernelGGL((attn_strip_kernel<4, 7>), grid, block, 0, st, a); break;
+            default: hipLaunchKernelGGL((attn_strip_kernel<4, 8>), grid, block, 0, st, a); break;
+        }
+        EXCEL_CHECK_LAUNCH("attn_strip");
+        return EXCEL_OK;
+    }
+#endif
     switch (ntw) {
-        case 1: hipLaunchKernelGGL((attn_strip_kernel<1>), grid, block, 0, st, a); break;
-        case 2: hipLaunchKernelGGL((attn_strip_kernel<2>), grid, block, 0, st, a); break;
-        case 3: hipLaunchKernelGGL((attn_strip_kernel<3>), grid, block, 0, st, a); break;
-        case 4: hipLaunchKernelGGL((attn_strip_kernel<4>), grid, block, 0, st, a); break;
-        default: hipLaunchKernelGGL((attn_strip_kernel<5>), grid, block, 0, st, a); break;
+        case 1: hipLaunchKernelGGL((attn_strip_kernel<1, 0>), grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((attn_strip_kernel<2, 0>), grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL((attn_strip_kernel<3, 0>), grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL((attn_strip_kernel<4, 0>), grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL((attn_strip_kernel<5, 0>), grid, block, 0, st, a); break;
     }
     EXCEL_CHECK_LAUNCH("attn_strip");
     return EXCEL_OK;

@@ -85,6 +85,37 @@ struct ProfScope {
     ~ProfScope() { if (on) excel_prof_end(cat, st); }
 };
 
+
+// ---------------------------------------------------------------- LDS reads that the compiler's wait-count pass does not see
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// LDS accesses of the streaming loop are written as inline asm: the compiler's wait-count pass treats every ds_read as a
+// possible reader of a pending global_load_lds and drains the whole DMA queue (s_waitcnt vmcnt(0)) in front of it, which
+// serialises the tile stream (that is what held attn_accum_bf_kernel at ~20 % matrix-core busy).  The waits here are explicit.
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)p; }
+__device__ __forceinline__ bf16x8 lds_read16(unsigned addr) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ float2 lds_read8(unsigned addr) {
+    float2 v;
+    asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_write8(unsigned addr, float2 v) { asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+// s_waitcnt lgkmcnt(0) that the consumers of the eight fragments depend on (keeps the MFMAs behind the wait)
+__device__ __forceinline__ bf16x4 lds_read8h(unsigned addr) {
+    f32x2 v;
+    asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return __builtin_bit_cast(bf16x4, v);
+}
+__device__ __forceinline__ void lds_wait8(bf16x8 (&a)[4], bf16x8 (&b)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])::"memory");
+}
+
+
 // ---------------------------------------------------------------- split-bf16 operand layout
 // A "split" row of K fp32 values is 2K bf16: for every block of 32 k the 32 hi values then the 32 lo values, so that the
 // 128 bytes a bf16x3 GEMM k-step (BK = 32) needs from a row are ONE contiguous, 128-B aligned cache line.

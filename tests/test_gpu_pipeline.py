@@ -756,9 +756,12 @@ def test_validation_engine_with_decoder(gpu, golden):
 
 
 def test_infer_lam_on_disk_voc(gpu, tmp_path):
-    """tools/infer_lam.py over an on-disk VOC-format tree (JPEG + palette PNG + id list + one-hot dict): decode on the host,
-    normalise / resize / everything else on the device; batched pipeline == per-image API path."""
+    """tools/infer_lam.py over an on-disk VOC-format tree (JPEG + palette PNG + id list + one-hot dict) AND an on-disk CLIP checkpoint
+    (visual + text tower) + BPE merges file: the tower is built from the file's weights, the 45 class/background prompts go through
+    the file's text tower and the shipped VOC attribute bank; decode on the host, normalise / resize / everything else on the
+    device; batched pipeline == per-image API path; real data without weights is refused."""
     from PIL import Image
+    from _clip_files import write_tiny_clip
     from excel_amd.tools import infer_lam
     from excel_amd.utils import imutils
     root, lists = tmp_path / "VOC2012", tmp_path / "lists"
@@ -781,8 +784,26 @@ def test_infer_lam_on_disk_voc(gpu, tmp_path):
         onehot[name] = oh
     (lists / "val.txt").write_text("\n".join(ids) + "\n")
     np.save(lists / "cls_labels_onehot.npy", onehot)
-    common = ["--data_folder", str(root), "--list_folder", str(lists), "--infer_set", "val", "--resize_size", "448"]
+    data = ["--data_folder", str(root), "--list_folder", str(lists), "--infer_set", "val", "--resize_size", "448"]
+    with pytest.raises(RuntimeError, match="Refusing to score real data"):
+        infer_lam.validate(infer_lam.get_parser().parse_args(data + ["--clip_root", str(tmp_path / "empty")]))
+    ckpt, bpe_path, full = write_tiny_clip(tmp_path)
+    common = data + ["--model", ckpt, "--bpe_path", bpe_path]
     score, total = infer_lam.validate(infer_lam.get_parser().parse_args(common))
+    model = infer_lam.validate.last_model
+    vis = model.encoder.visual
+    assert np.array_equal(host(torch.as_tensor(vis.state_dict()["conv1.weight"])), full["visual.conv1.weight"])     # the checkpoint's weights
+    assert (vis.embed_dim, vis.layers, vis.output_dim) == (128, 8, 512)                                              # ... and its architecture
+    assert tuple(model.integral_text_features.shape) == (45, 512) and tuple(model.text_attr.shape) == (512, 45)      # 20 classes + 25 background prompts
+    # the prompt features are what the oracle's text tower gives for the same token ids
+    from excel_amd import clip as xclip
+    from excel_amd.clip import bpe
+    from excel_amd.datasets.clip_text import text_prompts
+    tk = bpe.BPETokenizer(bpe_path)
+    tw = {k: v for k, v in full.items() if not k.startswith("visual.")}
+    for i in (0, 14, 44):
+        e = oracle.text.encode_text(bpe.tokenize(["a clean origami {}.".format(text_prompts(21)[i])], tk), tw, heads=1)
+        assert maxabs(host(model.integral_text_features)[i], oracle.text.prompt_ensemble(e)) < 1e-4
     assert int(host(total).sum()) == npix and 0.0 <= score["miou"] <= 1.0
     score2, total2 = infer_lam.validate(infer_lam.get_parser().parse_args(common + ["--api_path", "true", "--crf_post", "true",
                                                                                "--logits_dir", str(tmp_path / "logits")]))

@@ -356,3 +356,52 @@ def test_infer_vit_config_from_state_dict():
     cfg = VitConfig(width=128, layers=8, heads=2, patch=16, out_dim=64, input_resolution=64, n_surgery=5)
     got = infer_vit_config(make_vit_weights(cfg, seed=1))
     assert got == dict(width=128, layers=8, heads=2, patch=16, output_dim=64, input_resolution=64)
+
+
+def test_infer_lam_resolves_real_inputs_or_refuses(tmp_path, monkeypatch):
+    """tools/infer_lam.py:144-160 / model/model_excel.py:25-34: --model (a checkpoint path, or the model name under --clip_root) is what
+    the tower is built from; the class + background prompts go through the checkpoint's text tower with CLIP's BPE; the decoder
+    checkpoint is read only for --training_free false; real data without weights is refused (never scored with random weights)."""
+    import torch
+    from _clip_files import write_tiny_clip, MERGES
+    from excel_amd.tools import infer_lam
+    from excel_amd import clip as xclip
+    monkeypatch.delenv("EXCEL_CLIP_ROOT", raising=False)
+    monkeypatch.delenv("EXCEL_BPE_VOCAB", raising=False)
+    monkeypatch.setenv("HOME", str(tmp_path / "nohome"))
+    ckpt, bpe_path, full = write_tiny_clip(tmp_path)
+    P = infer_lam.get_parser().parse_args
+    # real data, no weights anywhere -> loud failure
+    with pytest.raises(RuntimeError, match="Refusing to score real data"):
+        infer_lam.resolve_model_inputs(P(["--data_folder", str(tmp_path)]))
+    # explicit path
+    kw = infer_lam.resolve_model_inputs(P(["--data_folder", str(tmp_path), "--model", ckpt, "--bpe_path", bpe_path]))
+    assert np.array_equal(kw["state_dict"]["visual.conv1.weight"].numpy(), full["visual.conv1.weight"]) and "text_features" not in kw
+    assert len(kw["tokenizer"].encoder) == 512 + len(MERGES) + 2
+    ids = xclip.tokenize(["a clean origami the cat."], tokenizer=kw["tokenizer"])
+    assert ids.shape == (1, 77) and int(ids[0, 0]) == 512 + len(MERGES) and int(ids.max()) == 512 + len(MERGES) + 1
+    # model NAME resolved under --clip_root (where the reference's downloader would have stored ViT-B-16.pt)
+    kw2 = infer_lam.resolve_model_inputs(P(["--data_folder", str(tmp_path), "--clip_root", str(tmp_path), "--bpe_path", bpe_path]))
+    assert np.array_equal(kw2["state_dict"]["visual.proj"].numpy(), full["visual.proj"])
+    # weights but no merges file -> the tokenizer's error, not a silent fallback
+    with pytest.raises(FileNotFoundError):
+        infer_lam.resolve_model_inputs(P(["--data_folder", str(tmp_path), "--model", ckpt]))
+    # synthetic mode is explicit and only without a checkpoint
+    kw3 = infer_lam.resolve_model_inputs(P(["--synthetic", "4"]))
+    assert set(kw3) == {"state_dict", "text_features"} and kw3["text_features"].shape == (45, 512)
+    # --training_free false: decoder checkpoint required, DDP prefixes stripped, encoder tensors left out
+    with pytest.raises(RuntimeError, match="--model_path"):
+        infer_lam.resolve_model_inputs(P(["--synthetic", "4", "--training_free", "false"]))
+    dec = {"module.decoder.linear_pred.bias": torch.zeros(21), "module.decoder_fts_fuse.linear_fuse.bias": torch.ones(256),
+           "module.encoder.visual.positional_embedding": torch.zeros(3, 3), "module.encoder.visual.proj": torch.zeros(2, 2)}
+    torch.save(dec, tmp_path / "head.pth")
+    kw4 = infer_lam.resolve_model_inputs(P(["--synthetic", "4", "--training_free", "false", "--model_path", str(tmp_path / "head.pth")]))
+    assert sorted(kw4["decoder_state_dict"]) == ["decoder.linear_pred.bias", "decoder_fts_fuse.linear_fuse.bias"]
+
+
+def test_clip_text_prompt_lists():
+    """model/model_excel.py:31: 20 + 25 prompts for VOC, 80 + 23 for COCO (datasets/clip_text.py lists, shipped as data)."""
+    from excel_amd.datasets import clip_text
+    voc, coco = clip_text.text_prompts(21), clip_text.text_prompts(81)
+    assert len(voc) == 45 and len(coco) == 103 and voc[0] == "aeroplane" and voc[14].startswith("person with clothes")
+    assert voc[20:] == clip_text.BACKGROUND_CATEGORY and coco[80:] == clip_text.BACKGROUND_CATEGORY_COCO
