@@ -90,6 +90,7 @@ SIGNATURES = {
     "excel_prompt_ensemble": (c_i, [c_f, c_i, c_i, c_f, c_f]),
     "excel_decoder_train_workspace_bytes": (c_sz, [C.c_void_p, c_i, c_i]),
     "excel_decoder_forward_train": (c_i, [C.c_void_p, c_f, c_i, c_i, c_f, c_sz, c_f, c_f, C.c_float, C.c_uint, c_f]),
+    "excel_decoder_train_attn_fts": (c_i, [C.c_void_p, c_i, c_i, c_f, c_sz, c_f, c_f]),
     "excel_decoder_backward": (c_i, [C.c_void_p, c_f, c_i, c_i, c_f, c_sz, c_f, c_f, C.POINTER(DecoderWeights), C.c_float, C.c_uint, c_f]),
     "excel_adamw_step": (c_i, [c_f, c_f, c_f, c_f, c_ll, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, c_i, c_f]),
     "excel_train_losses_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i]),

@@ -675,7 +675,7 @@ __global__ __launch_bounds__(512, 2) void attn_accum_bf_kernel(AccumArgs p) {
     const int r = lane & 31, kh = lane >> 5;
     const int wq = wave >> 1, wk = wave & 1;
     int kt = blockIdx.x, qt = blockIdx.y, b = blockIdx.z;
-    if (p.dbg & 8) {      // experiment: XCD-contiguous tile order (workgroups sharing X / Y tiles on one L2)
+    if (EXCEL_DBG(p.dbg) & 8) {      // experiment: XCD-contiguous tile order (workgroups sharing X / Y tiles on one L2)
         const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         const int id = xcd_remap(lin, gridDim.x * gridDim.y * gridDim.z);
         kt = id % gridDim.x; qt = (id / gridDim.x) % gridDim.y; b = id / (gridDim.x * gridDim.y);
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(512, 2) void attn_accum_bf_kernel(AccumArgs p) {
     // query tile and half of the last key tile empty): nothing to score, the wave only keeps the staging and barriers going
     const bool tile_oob = (qt * 128 + wq * 32 >= N) || (kt * 64 + wk * 32 >= N);
     auto score = [&](int offY, int offX, int type, int h, f32x16& acc) {
-        if ((p.dbg & 1) || tile_oob) return;
+        if ((EXCEL_DBG(p.dbg) & 1) || tile_oob) return;
         const float2 ml = lstats[((h & 1) * NTYPE + type) * 128 + wq * 32 + r];
         const u16* y16 = tiles + offY + (wk * 32 + r) * 128;
         const u16* x16 = tiles + offX + (wq * 32 + r) * 128;
@@ -778,12 +778,12 @@ __global__ __launch_bounds__(512, 2) void attn_accum_bf_kernel(AccumArgs p) {
         issue_x(XK, 1, 0);
         issue_y(YK, 1, 0);
         for (int h = 0; h < p.H; ++h) {
-            const bool more = h + 1 < p.H && !(p.dbg & 2);
+            const bool more = h + 1 < p.H && !(EXCEL_DBG(p.dbg) & 2);
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          // YQ,stats,XQ(h) landed (XK,YK(h) may be in flight)
             __builtin_amdgcn_s_barrier();
-            if (!(p.dbg & 2) || h == 0) { issue_x(XV, 2, h); issue_y(YV, 2, h); }
+            if (!(EXCEL_DBG(p.dbg) & 2) || h == 0) { issue_x(XV, 2, h); issue_y(YV, 2, h); }
             score(YQ, XQ, 1, h, accA);                                // q.q
-            if (!(p.dbg & 2) || h == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // XK,YK(h) landed (XV,YV in flight)
+            if (!(EXCEL_DBG(p.dbg) & 2) || h == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // XK,YK(h) landed (XV,YV in flight)
             __builtin_amdgcn_s_barrier();
             if (more) { issue_y(YQ, 0, h + 1); issue_stats(h + 1); }
             score(YK, XQ, 0, h, accW);                                // q.k
@@ -810,7 +810,7 @@ __global__ __launch_bounds__(512, 2) void attn_accum_bf_kernel(AccumArgs p) {
         }
     }
     __syncthreads();
-    if (p.dbg & 4) { if (accA[0] + accW[0] == 12345.f) p.a_sum[0] = 1.f; return; }
+    if (EXCEL_DBG(p.dbg) & 4) { if (accA[0] + accW[0] == 12345.f) p.a_sum[0] = 1.f; return; }
 
     // transpose each wave's [key][q] tile through LDS (pitch 33) and store rows of q with consecutive keys
     float* tb = reinterpret_cast<float*>(tiles) + wave * (32 * 33);
@@ -888,18 +888,15 @@ int excel_launch_attn_accum(const float* qkvh, const float* stats, float* a_sum,
     EXCEL_CHECK_ARG(!surgery || (a_sum && NP >= N && NP <= cdiv(N, 64) * 64), "attn_accum: bad a_sum/NP");
     AccumArgs a{qkvh, reinterpret_cast<const float2*>(stats), a_sum, w_aff, attn_out, B, H, N, NP, scale, w_scale, aff_scale, aff_init, qkvs, 0, a_sum_split, surgery ? ex_attn : nullptr, (float)H};
     dim3 grid(cdiv(N, 64), cdiv(N, 64), B);
-    static const char* old = getenv("EXCEL_ACCUM_OLD");
+#ifdef EXCEL_DEV
     { static const char* d = getenv("EXCEL_ACCUM_DBG"); if (d) a.dbg = atoi(d); }
-    if (qkvs && !old) {
+#endif
+    if (qkvs) {            // bf16x3 mode beyond the strip kernel's reach (attn_strip.hip: N > 1280)
         dim3 g2(cdiv(N, 64), cdiv(N, 128), B);
         if (surgery) hipLaunchKernelGGL((attn_accum_bf_kernel<true>), g2, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((attn_accum_bf_kernel<false>), g2, dim3(512), 0, st, a);
-    } else if (surgery && qkvs)
-        hipLaunchKernelGGL((attn_accum_kernel<true, true>), grid, dim3(256), 0, st, a);
-    else if (surgery)
+    } else if (surgery)
         hipLaunchKernelGGL((attn_accum_kernel<true, false>), grid, dim3(256), 0, st, a);
-    else if (qkvs)
-        hipLaunchKernelGGL((attn_accum_kernel<false, true>), grid, dim3(256), 0, st, a);
     else
         hipLaunchKernelGGL((attn_accum_kernel<false, false>), grid, dim3(256), 0, st, a);
     EXCEL_CHECK_LAUNCH("attn_accum");

@@ -85,3 +85,218 @@ int excel_launch_cam_epilogue(float* S, float* out_full, float* out_slice, int B
     EXCEL_CHECK_LAUNCH("cam_epilogue");
     return EXCEL_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ fused patch-text CAM
+// The north-star's named kernel: everything between the visual projection and the attribute maps in ONE launch,
+//   x_raw [B,N,C] (= ln_post(x) @ proj)  ->  token-axis L2 norm (clip/clip.py:353)  ->  S = f . text^T on the matrix core
+//   ->  class-prior weights, redundancy subtraction, min-max over all N tokens (clip/clip.py:288-310)  ->  attr maps.
+// One workgroup per image (the reductions over the token axis - column norms and per-class min/max - stay inside it); the
+// 8 waves take 32-token tiles.  Per tile a wave computes the TRANSPOSED scores S^T[class][token] = text . x'^T, so a token is a
+// lane column: the redundancy term (a sum over classes) is an in-lane sum plus one cross-half shuffle.
+//   BF:  x' = x * inv_norm is split into bf16 hi/lo in registers, text comes pre-split (blocked hi/lo layout of common.h):
+//        3 x v_mfma_f32_32x32x16_bf16 per 16-k step (bf16x3, fp32-grade)
+//   !BF: exact fp32 on v_mfma_f32_32x32x2_f32
+// The normalised features f are never written unless the caller asks for them (generate_clip_fts' return value).
+#define PTC_MAXCT 4            // class tiles of 32: T <= 128
+struct PtcArgs {
+    const float* x_raw;            // [B,N,C]
+    const float* text;             // [T,C] fp32 (exact mode)
+    const unsigned short* text_s;  // [T][2C] split bf16 (bf16x3 mode)
+    float* sim;                    // [B,N,ldT] scratch: un-normalised similarities
+    float* out_full;               // [B,N,T]   (may be null)
+    float* out_slice;              // [B,N-1,F] (may be null)
+    float* feats;                  // [B,N,C] normalised image_features (may be null)
+    int N, C, T, F, ldT;
+    float temp;
+};
+
+template <bool BF, int CT>
+__global__ __launch_bounds__(512) void patch_text_cam_kernel(PtcArgs p) {
+    __shared__ float inv[1024];                    // 1 / ||x[:, c]||_2 over the tokens
+    __shared__ float w[PTC_MAXCT * 32];            // class-prior weights (0 for padded classes)
+    __shared__ float red_mn[8][PTC_MAXCT * 32], red_mx[8][PTC_MAXCT * 32];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, kh = lane >> 5;
+    const int N = p.N, C = p.C, T = p.T;
+    const float* X = p.x_raw + (long long)b * N * C;
+
+    // ---- column norms over the token axis, fixed summation order (4 interleaved partial sums per column)
+    for (int c = tid; c < C; c += 512) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int n = 0;
+        for (; n + 4 <= N; n += 4) {
+            const float v0 = X[(long long)n * C + c], v1 = X[(long long)(n + 1) * C + c], v2 = X[(long long)(n + 2) * C + c], v3 = X[(long long)(n + 3) * C + c];
+            s0 = fmaf(v0, v0, s0); s1 = fmaf(v1, v1, s1); s2 = fmaf(v2, v2, s2); s3 = fmaf(v3, v3, s3);
+        }
+        for (; n < N; ++n) { const float v = X[(long long)n * C + c]; s0 = fmaf(v, v, s0); }
+        inv[c] = 1.f / sqrtf((s0 + s1) + (s2 + s3));
+    }
+    __syncthreads();
+    if (p.feats) {
+        float* Fo = p.feats + (long long)b * N * C;
+        for (long long i = (long long)tid * 4; i < (long long)N * C; i += 512 * 4) {
+            const int c = (int)(i % C);
+            f32x4 v = *reinterpret_cast<const f32x4*>(X + i);
+            v[0] *= inv[c]; v[1] *= inv[c + 1]; v[2] *= inv[c + 2]; v[3] *= inv[c + 3];
+            *reinterpret_cast<f32x4*>(Fo + i) = v;
+        }
+    }
+
+    float* simb = p.sim + (long long)b * N * p.ldT;
+    const int ntile = (N + 31) / 32;
+    float mn[CT][16], mx[CT][16];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { mn[ct][e] = INFINITY; mx[ct][e] = -INFINITY; }
+
+    bool first = true;
+    for (int tile = wave; tile < ntile || first; tile += 8) {
+        const bool live = tile < ntile;                       // every wave takes part in the barrier of its first round
+        const int n = min(tile * 32 + r, N - 1);              // token of this lane column (clamped; masked at the end)
+        f32x16 acc[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[ct][e] = 0.f;
+        if (live) {
+            const float* xrow = X + (long long)n * C;
+            if (BF) {
+                for (int k0 = 0; k0 < C; k0 += 16) {
+                    const int c0 = k0 + 8 * kh;
+                    const f32x4 xa = *reinterpret_cast<const f32x4*>(xrow + c0), xb = *reinterpret_cast<const f32x4*>(xrow + c0 + 4);
+                    const f32x4 ia = *reinterpret_cast<const f32x4*>(inv + c0), ib = *reinterpret_cast<const f32x4*>(inv + c0 + 4);
+                    bf16x8 xh, xl;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float v = (j < 4) ? xa[j] * ia[j] : xb[j - 4] * ib[j - 4];
+                        xh[j] = (__bf16)v;
+                        xl[j] = (__bf16)(v - (float)xh[j]);
+                    }
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+                        const int cls = ct * 32 + r;
+                        bf16x8 th = {0, 0, 0, 0, 0, 0, 0, 0}, tl = th;
+                        if (cls < T) {
+                            const unsigned short* tp = p.text_s + (long long)cls * 2 * C + split_off(c0, 0);
+                            th = *reinterpret_cast<const bf16x8*>(tp);
+                            tl = *reinterpret_cast<const bf16x8*>(tp + 32);
+                        }
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tl, xh, acc[ct], 0, 0, 0);
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th, xl, acc[ct], 0, 0, 0);
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th, xh, acc[ct], 0, 0, 0);
+                    }
+                }
+            } else {
+                for (int k0 = 0; k0 < C; k0 += 8) {
+                    const int c0 = k0 + 4 * kh;
+                    f32x4 xv = *reinterpret_cast<const f32x4*>(xrow + c0);
+                    const f32x4 iv = *reinterpret_cast<const f32x4*>(inv + c0);
+                    xv *= iv;
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+                        const int cls = ct * 32 + r;
+                        f32x4 tv = {0.f, 0.f, 0.f, 0.f};
+                        if (cls < T) tv = *reinterpret_cast<const f32x4*>(p.text + (long long)cls * C + c0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(tv[e], xv[e], acc[ct], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (first) {
+            // class-prior weights from the cls token (token 0 = lane columns 0 / 32 of wave 0's first tile):  softmax(temp * S[0,:]) / mean
+            if (wave == 0) {
+                if (r == 0) {
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) w[ct * 32 + c32_row(e, lane)] = acc[ct][e];      // S[0, class]
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                float v[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) v[i] = (lane + 64 * i < T) ? w[lane + 64 * i] * p.temp : -INFINITY;
+                const float m = wave_max(fmaxf(v[0], v[1]));
+                float e0 = (lane < T) ? __expf(v[0] - m) : 0.f, e1 = (lane + 64 < T) ? __expf(v[1] - m) : 0.f;
+                const float sum = wave_sum(e0 + e1);
+                e0 = e0 / sum;
+                e1 = e1 / sum;
+                const float mean = wave_sum(e0 + e1) / (float)T;
+                __builtin_amdgcn_wave_barrier();
+                w[lane] = (lane < T) ? e0 / mean : 0.f;
+                if (CT > 2) w[lane + 64] = (lane + 64 < T) ? e1 / mean : 0.f;
+            }
+            __syncthreads();
+            first = false;
+        }
+        if (!live) break;
+        // sim[n,t] = w[t] S[n,t] - (1/T) sum_t' w[t'] S[n,t']      (clip.py:301-306 in GEMM form)
+        float part = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                acc[ct][e] *= w[ct * 32 + c32_row(e, lane)];
+                part += acc[ct][e];
+            }
+        part += __shfl_xor(part, 32, 64);
+        const float red = part / (float)T;
+        const bool tok_ok = tile * 32 + r < N;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int cls = ct * 32 + c32_row(e, lane);
+                const float s = acc[ct][e] - red;
+                if (tok_ok && cls < T) {
+                    simb[(long long)(tile * 32 + r) * p.ldT + cls] = s;
+                    mn[ct][e] = fminf(mn[ct][e], s);
+                    mx[ct][e] = fmaxf(mx[ct][e], s);
+                }
+            }
+    }
+    // ---- per-class min / max over all tokens: across the 32 token columns of the wave, then across waves
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            float a = mn[ct][e], c = mx[ct][e];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) { a = fminf(a, __shfl_xor(a, o, 64)); c = fmaxf(c, __shfl_xor(c, o, 64)); }
+            if (r == 0) { red_mn[wave][ct * 32 + c32_row(e, lane)] = a; red_mx[wave][ct * 32 + c32_row(e, lane)] = c; }
+        }
+    __syncthreads();       // also orders this workgroup's sim writes before the re-read below
+    if (tid < CT * 32) {
+        float a = red_mn[0][tid], c = red_mx[0][tid];
+        for (int i = 1; i < 8; ++i) { a = fminf(a, red_mn[i][tid]); c = fmaxf(c, red_mx[i][tid]); }
+        red_mn[0][tid] = a;
+        red_mx[0][tid] = c - a;
+    }
+    __syncthreads();
+    // ---- attr = (sim - min) / (max - min)   (clip.py:308; NaN when max == min, like the reference)
+    for (long long i = tid; i < (long long)N * T; i += 512) {
+        const int n = (int)(i / T), t = (int)(i - (long long)n * T);
+        const float v = (simb[(long long)n * p.ldT + t] - red_mn[0][t]) / red_mx[0][t];
+        if (p.out_full) p.out_full[((long long)b * N + n) * T + t] = v;
+        if (p.out_slice && n >= 1 && t < p.F) p.out_slice[((long long)b * (N - 1) + (n - 1)) * p.F + t] = v;
+    }
+}
+
+int excel_launch_patch_text_cam(const float* x_raw, const float* text, const unsigned short* text_split, float* sim_ws, float* out_full,
+                                float* out_slice, float* feats, int B, int N, int C, int T, int F, int ldT, float temp, int bf, hipStream_t st) {
+    ProfScope prof__(PROF_CAM_EPILOGUE, st, 2.0 * B * (double)N * C * T);
+    EXCEL_CHECK_ARG(T >= 1 && T <= PTC_MAXCT * 32 && F <= T && ldT >= T, "patch_text_cam: need 1 <= F <= T <= %d (T=%d F=%d)", PTC_MAXCT * 32, T, F);
+    EXCEL_CHECK_ARG(C <= 1024 && (C % 32) == 0, "patch_text_cam: C must be a multiple of 32, <= 1024 (C=%d)", C);
+    EXCEL_CHECK_ARG(!bf || text_split, "patch_text_cam: bf16x3 mode needs the split text");
+    PtcArgs a{x_raw, text, text_split, sim_ws, out_full, out_slice, feats, N, C, T, F, ldT, temp};
+    const int ct = cdiv(T, 32);
+#define PTC_LAUNCH(BFV, CTV) hipLaunchKernelGGL((patch_text_cam_kernel<BFV, CTV>), dim3(B), dim3(512), 0, st, a)
+    if (bf) { if (ct <= 1) PTC_LAUNCH(true, 1); else if (ct == 2) PTC_LAUNCH(true, 2); else PTC_LAUNCH(true, 4); }
+    else { if (ct <= 1) PTC_LAUNCH(false, 1); else if (ct == 2) PTC_LAUNCH(false, 2); else PTC_LAUNCH(false, 4); }
+#undef PTC_LAUNCH
+    EXCEL_CHECK_LAUNCH("patch_text_cam");
+    return EXCEL_OK;
+}

@@ -37,6 +37,14 @@ static inline long long cdivl(long long a, long long b) { return (a + b - 1) / b
 
 #define WAVE 64
 
+// Ablation switches exist only in development builds (EXCEL_DEV=1 python -m excel_amd.build): the shipped library reads no
+// environment variable on a launch path and its kernels carry no debug branches.
+#ifdef EXCEL_DEV
+#define EXCEL_DBG(x) (x)
+#else
+#define EXCEL_DBG(x) 0
+#endif
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -282,8 +282,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16x3_kernel(GemmBfArgs
         issue_tile(0, 0);
         __syncthreads();                  // drains the LDS-DMA (vmcnt(0)) and publishes the tile
         for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk && !(p.dbg & 2)) issue_tile(kt + 1, (kt + 1) & 1);      // in flight during this step's MFMAs
-            if (!(p.dbg & 1)) compute(kt & 1);
+            if (kt + 1 < nk && !(EXCEL_DBG(p.dbg) & 2)) issue_tile(kt + 1, (kt + 1) & 1);      // in flight during this step's MFMAs
+            if (!(EXCEL_DBG(p.dbg) & 1)) compute(kt & 1);
             __syncthreads();
         }
     } else {
@@ -302,8 +302,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16x3_kernel(GemmBfArgs
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __builtin_amdgcn_s_barrier();
-            if (kt + 2 < nk && !(p.dbg & 2)) issue_tile(kt + 2, stage == 0 ? NSTAGE - 1 : stage - 1);
-            if (!(p.dbg & 1)) compute(stage);
+            if (kt + 2 < nk && !(EXCEL_DBG(p.dbg) & 2)) issue_tile(kt + 2, stage == 0 ? NSTAGE - 1 : stage - 1);
+            if (!(EXCEL_DBG(p.dbg) & 1)) compute(stage);
             stage = (stage + 1 == NSTAGE) ? 0 : stage + 1;
         }
         __syncthreads();
@@ -422,13 +422,19 @@ int excel_launch_vt_split(const float* v, unsigned short* vt, int B, int H, int 
 
 int excel_launch_gemm_bf16x3(const GemmBfArgs& p_in, hipStream_t stream) {
     GemmBfArgs p = p_in;
+#ifdef EXCEL_DEV
     { static const char* d = getenv("EXCEL_BF_DBG"); if (d) p.dbg = atoi(d); }
+#endif
     ProfScope prof__(PROF_GEMM_BF16X3, stream, 2.0 * p.M * (double)p.N * p.K * (p.batch > 1 ? p.batch : 1));
     EXCEL_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0 && (p.K % TBK) == 0, "gemm_bf16x3: K must be a multiple of %d (K=%d)", TBK, p.K);
     EXCEL_CHECK_ARG(p.out_mode != GEMM_OUT_SPLIT_BF16 || (p.N % 32) == 0, "gemm_bf16x3: split output needs N %% 32 == 0");
     EXCEL_CHECK_ARG((p.lda % 8) == 0 && (p.ldb % 8) == 0 && p.lda >= 2 * p.K && p.ldb >= 2 * p.K, "gemm_bf16x3: bad lda/ldb");
     EXCEL_CHECK_ARG((((uintptr_t)p.A | (uintptr_t)p.B) & 15) == 0, "gemm_bf16x3: operands must be 16-byte aligned");
+#ifdef EXCEL_DEV
     static const char* force = getenv("EXCEL_BF_TILE");      // dev knob: "128" | "256x128" | "256" | "320"
+#else
+    const char* const force = nullptr;
+#endif
     int kind;   // 0: 128x128, 1: 256x128, 2: 256x256, 3: 320x256
     if (force) kind = !strcmp(force, "320") ? 3 : !strcmp(force, "256") ? 2 : (!strcmp(force, "256x128") ? 1 : 0);
     else if (p.M < 2048 || (p.batch > 1)) kind = 0;

@@ -409,14 +409,24 @@ __global__ __launch_bounds__(256) void argmax_label_kernel(const float* __restri
 
 #define CONF_MAXBINS 8192
 __global__ __launch_bounds__(256) void confusion_kernel(const unsigned char* __restrict__ gt, const unsigned char* __restrict__ pred,
-                                                        long long n, int nc, unsigned long long* __restrict__ hist) {
+                                                        long long n, int nc, unsigned long long* __restrict__ hist, int head) {
     __shared__ unsigned int lh[CONF_MAXBINS];
     const int bins = nc * nc;
     for (int i = threadIdx.x; i < bins; i += 256) lh[i] = 0;
     __syncthreads();
+    // gt / pred slices of a larger tensor need not be 16-byte aligned: when both share the same misalignment a scalar head brings
+    // them to a 16-byte boundary, otherwise (`head` < 0) the whole range goes through the scalar path
+    if (head > 0 && blockIdx.x == 0 && threadIdx.x < head && threadIdx.x < n) {
+        const int g = gt[threadIdx.x], p = pred[threadIdx.x];
+        if (g < nc && p < nc) atomicAdd(&lh[g * nc + p], 1u);
+    }
+    if (head >= 0) {
+        gt += head; pred += head; n -= head;
+        if (n < 0) n = 0;
+    }
     const long long stride = (long long)gridDim.x * 256 * 16;
     for (long long base = ((long long)blockIdx.x * 256 + threadIdx.x) * 16; base < n; base += stride) {
-        if (base + 16 <= n) {
+        if (head >= 0 && base + 16 <= n) {
             const uint4 g4 = *reinterpret_cast<const uint4*>(gt + base);
             const uint4 p4 = *reinterpret_cast<const uint4*>(pred + base);
             const unsigned int gw[4] = {g4.x, g4.y, g4.z, g4.w}, pw[4] = {p4.x, p4.y, p4.z, p4.w};
@@ -426,7 +436,8 @@ __global__ __launch_bounds__(256) void confusion_kernel(const unsigned char* __r
                 if (g < nc && p < nc) atomicAdd(&lh[g * nc + p], 1u);
             }
         } else {
-            for (long long j = base; j < n; ++j) {
+            const long long end = (base + 16 < n) ? base + 16 : n;
+            for (long long j = base; j < end; ++j) {
                 const int g = gt[j], p = pred[j];
                 if (g < nc && p < nc) atomicAdd(&lh[g * nc + p], 1u);
             }
@@ -477,9 +488,14 @@ static void par_it_launch(const float* aff, const float* in, float* out, const i
     int halo = 0;
     for (int i = 0; i < ND; ++i) halo = dl.d[i] > halo ? dl.d[i] : halo;
     halo = (halo + 3) / 4 * 4;
-    if (vec && halo == 24 && !getenv("EXCEL_PAR_NO_LDS"))
+#ifdef EXCEL_DEV
+    static const bool no_lds = getenv("EXCEL_PAR_NO_LDS") != nullptr;
+#else
+    const bool no_lds = false;
+#endif
+    if (vec && halo == 24 && !no_lds)
         hipLaunchKernelGGL((par_iterate_lds_kernel<ND, 24>), dim3(cdiv(W, 64), cdiv(H, 16), B), dim3(256), 0, st, aff, in, out, nchan, dl, Cmax, H, W);
-    else if (vec && halo == 8 && !getenv("EXCEL_PAR_NO_LDS"))
+    else if (vec && halo == 8 && !no_lds)
         hipLaunchKernelGGL((par_iterate_lds_kernel<ND, 8>), dim3(cdiv(W, 64), cdiv(H, 16), B), dim3(256), 0, st, aff, in, out, nchan, dl, Cmax, H, W);
     else if (vec)
         hipLaunchKernelGGL(par_iterate4_kernel<ND>, dim3(cdiv(W, 256), cdiv(H, 4), B), dim3(256), 0, st, aff, in, out, nchan, dl, Cmax, H, W);
@@ -545,9 +561,11 @@ int excel_launch_confusion(const unsigned char* gt, const unsigned char* pred, l
                            hipStream_t st) {
     ProfScope prof__(PROF_CONFUSION, st);
     EXCEL_CHECK_ARG(nc >= 1 && nc * nc <= CONF_MAXBINS, "confusion: num_classes %d too large", nc);
-    EXCEL_CHECK_ARG((((uintptr_t)gt | (uintptr_t)pred) & 15) == 0, "confusion: gt/pred must be 16-byte aligned");
+    // scalar elements in front of the first 16-byte boundary (same for both pointers), or -1: no common alignment -> scalar path
+    const int mg = (int)((16 - ((uintptr_t)gt & 15)) & 15), mp = (int)((16 - ((uintptr_t)pred & 15)) & 15);
+    const int head = (mg == mp) ? mg : -1;
     const int blocks = (int)((cdivl(n, 256 * 16) < 2048) ? cdivl(n, 256 * 16) : 2048);
-    hipLaunchKernelGGL(confusion_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, gt, pred, n, nc, hist);
+    hipLaunchKernelGGL(confusion_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, gt, pred, n, nc, hist, head);
     EXCEL_CHECK_LAUNCH("confusion");
     return EXCEL_OK;
 }

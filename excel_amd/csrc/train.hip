@@ -416,9 +416,11 @@ __global__ __launch_bounds__(256) void tr_adamw_kernel(float* __restrict__ p, co
 extern "C" int excel_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1, float beta2,
                                 float eps, float weight_decay, int step, void* stream) {
     EXCEL_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "adamw_step: bad argument");
-    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    // bias corrections in double on the host like torch.optim.AdamW (1 - beta2^t in fp32 loses ~6e-5 relative at small t)
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     hipLaunchKernelGGL(tr_adamw_kernel, dim3((unsigned)cdivl(n, 256)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1,
-                       beta2, eps, weight_decay, bc1, sqrtf(bc2));
+                       beta2, eps, weight_decay, bc1, bc2s);
     EXCEL_CHECK_LAUNCH("adamw_step");
     return EXCEL_OK;
 }
@@ -598,6 +600,17 @@ static int tr_linear_bwd(const float* dY, int ldy, const float* X, int ldx, cons
 
 // Backward of excel_decoder_forward_train (same all_feats / workspace).  `grads` has the layout of the weights; every
 // pointer in it is WRITTEN (device memory of the parameter's shape).
+// attn_fts of the LAST forward_train on this workspace: the fused, Dropout2d-masked features [B*P, E] -> [B,E,g,g].  The training
+// loop's LVC cue is `attn_fts.clone().detach()` of the train-mode forward (scripts/train_voc.py:186-189), i.e. the post-dropout tensor.
+extern "C" int excel_decoder_train_attn_fts(excel_decoder_t h, int B, int g, const void* workspace, size_t workspace_bytes, float* attn_fts_out,
+                                            void* stream) {
+    EXCEL_CHECK_ARG(h && workspace && attn_fts_out && B > 0 && g > 0, "excel_decoder_train_attn_fts: bad argument");
+    const excel_decoder_config& c = h->cfg;
+    TrainWs ws = train_ws_layout(c, B, g, (char*)workspace);
+    EXCEL_CHECK_ARG(workspace_bytes >= ws.total, "excel_decoder_train_attn_fts: workspace too small");
+    return excel_launch_dec_transpose(ws.fts, attn_fts_out, B, g * g, c.embed, c.embed, g * g, (hipStream_t)stream);
+}
+
 extern "C" int excel_decoder_backward(excel_decoder_t h, const float* all_feats, int B, int g, void* workspace, size_t workspace_bytes,
                                       const float* d_seg, const float* d_attn_pred, const excel_decoder_weights* grads, float dropout_p,
                                       unsigned dropout_seed, void* stream) {

@@ -287,12 +287,21 @@ class DecoderHandle:
             self._gtable = g
         return self._grads, self._gtable
 
+    def _check_feats(self, L, N, D, g):
+        """all_feats [L,B,N,D] must match the head's configuration: the kernels index by it (a wrong shape would read out of bounds)."""
+        c = self.cfg
+        if L != c["vit_layers"] or D != c["vit_width"]:
+            raise ValueError(f"all_feats must be [{c['vit_layers']},B,N,{c['vit_width']}], got L={L}, D={D}")
+        if g * g + 1 != N:
+            raise ValueError("all_feats must hold cls + a square grid of patch tokens")
+
     def forward_train(self, all_feats, dropout_p=0.0, dropout_seed=0):
         """-> (seg [B,nc,g,g], attn_pred [B,P,P], ctx) ; ctx goes to backward().  dropout_p: the head's Dropout2d (0.1 in the reference)."""
         all_feats = f32c(all_feats)
         L, B, N, D = all_feats.shape
         g = int(round((N - 1) ** 0.5))
         c = self.cfg
+        self._check_feats(L, N, D, g)
         dev = all_feats.device
         seg = torch.empty((B, c["num_classes"], g, g), dtype=torch.float32, device=dev)
         ap = torch.empty((B, g * g, g * g), dtype=torch.float32, device=dev)
@@ -301,6 +310,14 @@ class DecoderHandle:
         check(lib().excel_decoder_forward_train(self._h, _p(all_feats), B, g, _p(ws, torch.uint8), need, _p(seg), _p(ap), float(dropout_p),
                                                 int(dropout_seed) & 0xFFFFFFFF, _stream()), "excel_decoder_forward_train")
         return seg, ap, (all_feats, B, g, ws, need, float(dropout_p), int(dropout_seed) & 0xFFFFFFFF)
+
+    def train_attn_fts(self, ctx):
+        """attn_fts [B,E,g,g] of the forward_train that produced `ctx`: the post-Dropout2d fused features (the LVC cue of the
+        training loop, scripts/train_voc.py:186-189)."""
+        all_feats, B, g, ws, need, _, _ = ctx
+        fts = torch.empty((B, self.cfg["embed"], g, g), dtype=torch.float32, device=all_feats.device)
+        check(lib().excel_decoder_train_attn_fts(self._h, B, g, _p(ws, torch.uint8), need, _p(fts), _stream()), "excel_decoder_train_attn_fts")
+        return fts
 
     def backward(self, ctx, d_seg, d_attn_pred=None):
         """-> dict of gradients keyed like self.t (fuse{l}.proj_w ..., blk{l}.fc1_w ..., fuse_w, pred_w ...)."""
@@ -326,11 +343,8 @@ class DecoderHandle:
         all_feats = f32c(all_feats)
         L, B, N, D = all_feats.shape
         c = self.cfg
-        if L != c["vit_layers"] or D != c["vit_width"]:
-            raise ValueError(f"all_feats must be [{c['vit_layers']},B,N,{c['vit_width']}], got {tuple(all_feats.shape)}")
         g = int(round((N - 1) ** 0.5))
-        if g * g + 1 != N:
-            raise ValueError("all_feats must hold cls + a square grid of patch tokens")
+        self._check_feats(L, N, D, g)
         dev = all_feats.device
         fts = torch.empty((B, c["embed"], g, g), dtype=torch.float32, device=dev)
         seg = torch.empty((B, c["num_classes"], g, g), dtype=torch.float32, device=dev) if want_seg else None

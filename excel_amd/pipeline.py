@@ -104,6 +104,9 @@ class TrainingFreePipeline:
         H, W = (gts.shape[-2:] if gts is not None else (label_hw or (S, S)))
         sa.wait_stream(cur)
         with torch.cuda.stream(sa):
+            # the caller may free / reuse these right after the call: the caching allocator must know stream A reads them
+            inputs.record_stream(sa)
+            cls_labels.record_stream(sa)
             _, _, attr, attn_w, _ = self.model(inputs)
             idx, ncls, nchan = ops.cls_compact(cls_labels, self.smax, want_nchan=True)
             refined = ops.refine_cams_with_aff_batched(attr, attn_w.w_aff, idx, ncls, g, self.caa_thre)

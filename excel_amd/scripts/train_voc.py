@@ -75,8 +75,9 @@ class DecoderTrainer:
             attr_maps_raw = ops.clip_feature_surgery(image_features, model._text_rows, num_fg=model.num_classes - 1, want_full=False)[1]
             segs, attn_pred, ctx = dec.forward_train(all_feats, dropout_p=self.dropout_p,
                                                      dropout_seed=self.seed * 1000003 + self.global_step)            # :60-76 (Dropout2d active: model.train())
-            if n_iter >= self.lvc_iter:                                                                              # fts_diver = attn_fts of this forward
-                attr_maps_raw = cure_attr_map(model, inputs, ex_feats=dec.forward(all_feats, want_seg=False)[0])      # :188-189
+            if n_iter >= self.lvc_iter:
+                # fts_diver = attn_fts.clone().detach() of THIS train-mode forward (:186-189): the post-Dropout2d features
+                attr_maps_raw = cure_attr_map(model, inputs, ex_feats=dec.train_attn_fts(ctx))
             aff_pseudos = self.pseudo_labels(inputs, cls_labels, attr_maps_raw, attn_weights, attn_pred, n_iter)
             aff_src = None
             if n_iter >= self.seg_aff_iter:                                                                          # :204, :210

@@ -192,6 +192,10 @@ int excel_train_losses(const float* seg, const float* attn_pred, const unsigned 
 size_t excel_decoder_train_workspace_bytes(excel_decoder_t h, int B, int g);
 int excel_decoder_forward_train(excel_decoder_t h, const float* all_feats, int B, int g, void* workspace, size_t workspace_bytes,
                                 float* seg_out, float* attn_pred_out, float dropout_p, unsigned dropout_seed, void* stream);
+/* attn_fts [B,E,g,g] of the last excel_decoder_forward_train on `workspace`: the fused features AFTER the head's Dropout2d, what the
+ * reference's training loop clones as the LVC cue (scripts/train_voc.py:186-189: fts_diver = attn_fts.clone().detach()). */
+int excel_decoder_train_attn_fts(excel_decoder_t h, int B, int g, const void* workspace, size_t workspace_bytes, float* attn_fts_out,
+                                 void* stream);
 int excel_decoder_backward(excel_decoder_t h, const float* all_feats, int B, int g, void* workspace, size_t workspace_bytes,
                            const float* d_seg, const float* d_attn_pred, const excel_decoder_weights* grads, float dropout_p,
                            unsigned dropout_seed, void* stream);

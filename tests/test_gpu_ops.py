@@ -392,6 +392,21 @@ def test_confusion(ops, nc, n):
     assert np.array_equal(host(hist), 2 * ref)
 
 
+def test_confusion_unaligned_slices(ops):
+    """gt / pred views that do not start on a 16-byte boundary (labels_u8[i], gts[lo:hi] of an odd-sized image): same
+    misalignment -> scalar head + vector body; different misalignment -> scalar path.  Both equal fast_hist."""
+    rs = np.random.RandomState(9)
+    nc, n = 21, 5003
+    gt = rs.randint(0, nc, n + 40).astype(np.uint8)
+    gt[rs.rand(n + 40) < 0.05] = 255
+    pr = rs.randint(0, nc, n + 40).astype(np.uint8)
+    G, P = dev(gt), dev(pr)
+    for og, op_ in ((3, 3), (5, 5), (1, 6), (0, 7), (13, 13)):
+        hist = ops.confusion_accumulate(G[og:og + n], P[op_:op_ + n], nc)
+        assert np.array_equal(host(hist), oracle.evaluate.fast_hist(gt[og:og + n], pr[op_:op_ + n], nc)), (og, op_)
+    assert int(host(ops.confusion_accumulate(G[3:10], P[3:10], nc)).sum()) == int((gt[3:10] < nc).sum())     # shorter than the head
+
+
 def test_confusion_golden(ops, golden):
     g = golden("ops.npz")
     gts = g["sc_gts"].astype(np.int64)

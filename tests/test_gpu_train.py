@@ -137,3 +137,24 @@ def test_train_step_end_to_end(ops, golden):
     hist5, _ = run(lvc_iter=10 ** 9, dropout_p=0.1, seg_aff_iter=3)
     assert [h["seg_loss"] for h in hist4] == [h["seg_loss"] for h in hist5]        # the counter-based mask keeps it reproducible
     assert hist4[0]["seg_loss"] != hist[0]["seg_loss"] and all(np.isfinite(h["diver_loss"]) for h in hist4)
+
+
+def test_train_attn_fts_is_the_post_dropout_cue(ops, golden):
+    """scripts/train_voc.py:186-189: fts_diver = attn_fts.clone().detach() of the TRAIN-mode forward, i.e. after the head's Dropout2d.
+    Without dropout it equals the inference head's attn_fts; with p > 0 whole (image, channel) planes are zero and the others are the
+    inference values scaled by 1 / (1 - p)."""
+    g, gd = golden("train_tiny.npz"), golden("decoder_tiny.npz")
+    h, _ = _handle_and_names(ops, g)
+    feats = dev(gd["all_feats"])
+    ref = host(h.forward(feats, want_seg=False)[0])                     # [B,E,g,g]
+    _, _, ctx0 = h.forward_train(feats)
+    np.testing.assert_allclose(host(h.train_attn_fts(ctx0)), ref, rtol=0, atol=1e-6 * float(np.abs(ref).max()))
+    p = 0.25
+    _, _, ctx = h.forward_train(feats, dropout_p=p, dropout_seed=7)
+    got = host(h.train_attn_fts(ctx))
+    dead = np.all(got == 0, axis=(2, 3))                                # [B,E] dropped planes
+    assert 0 < dead.sum() < dead.size and abs(dead.mean() - p) < 0.2
+    keep = ~dead
+    np.testing.assert_allclose(got[keep], ref[keep] / (1 - p), rtol=0, atol=2e-6 * float(np.abs(ref).max()) / (1 - p))
+    with pytest.raises(ValueError):
+        h.forward_train(feats[:, :, :, :-4].contiguous())              # wrong width: refused instead of reading out of bounds
