@@ -100,6 +100,8 @@ SIGNATURES = {
     "excel_denormalize_img": (c_i, [c_f, c_i, c_i, c_i, C.POINTER(C.c_float), C.POINTER(C.c_float), c_f, c_f, c_f]),
     "excel_seg_scale_accumulate": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, C.c_float, c_f]),
     "excel_cam_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
+    "excel_patch_text_cam_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
+    "excel_patch_text_cam": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, C.c_float, c_i, c_f, c_f, c_f, c_f, c_f]),
     "excel_clip_feature_surgery": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, C.c_float, c_f, c_f, c_f, c_f]),
     "excel_attn_layer_mean": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
     "excel_trans_mat_workspace_bytes": (c_sz, [c_i, c_i]),

@@ -55,7 +55,12 @@ def generate_clip_fts(inputs, model, return_weights=True, ex_feats=None, n_attn_
 def clip_feature_surgery(image_features, text_features, redundant_feats=None, t=2):
     """[B,N,C] x [T,C] -> attr maps [B,N,T] (:288-310)."""
     if redundant_feats is not None:
-        raise NotImplementedError("redundant_feats branch (clip.py:290-291) is not on the training-free path")
+        # :289-290 similarity = image_features @ (text_features - redundant_feats).t().  The reference then returns the unassigned
+        # name `attr_maps` (:310, UnboundLocalError), so this branch cannot run there; the evident intent (the CLIP-Surgery function
+        # it derives from) is to return the similarity itself, which is what this does: one NT GEMM over all B*N token rows.
+        B, N, Cc = image_features.shape
+        txt = (torch.as_tensor(text_features).float() - torch.as_tensor(redundant_feats).float()).to(image_features.device)
+        return ops.gemm(ops.f32c(image_features).reshape(B * N, Cc), ops.f32c(txt.reshape(-1, Cc))).reshape(B, N, -1)
     full, _ = ops.clip_feature_surgery(image_features, text_features, t=float(t))
     return full
 

@@ -21,6 +21,7 @@ extern "C" int excel_abi_version(void) { return 1; }
 
 // ------------------------------------------------------------------------------------ profiling hooks
 bool g_excel_prof_on = false;
+int g_excel_prof_gemm_cat = -1;
 unsigned long long g_excel_prof_mask = ~0ull;
 int g_excel_prof_every = 1;
 unsigned g_excel_prof_seen[PROF_NCAT];
@@ -31,7 +32,7 @@ std::vector<hipEvent_t> g_prof_pool;
 double g_prof_work[PROF_NCAT];
 const char* PROF_NAMES[PROF_NCAT] = {"gemm_nt", "gemm_nn", "gemm_bf16x3", "attn_rowpass", "attn_accum", "layernorm", "embed", "token_norm",
                                      "cam_epilogue", "sinkhorn", "bbox_mask", "matvec", "cam_upsample", "par_affinity",
-                                     "par_iterate", "argmax", "confusion", "other"};
+                                     "par_iterate", "argmax", "confusion", "other", "cam_proj", "cam_fused"};
 hipEvent_t prof_event() {
     if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
     hipEvent_t e; (void)hipEventCreate(&e); return e;
@@ -390,7 +391,7 @@ static int vit_forward_impl(excel_vit_t h, const float* img, int B, int S, void*
                             float* image_features, float* x_raw, float* w_aff, int aff_layers, float* attn_out,
                             int n_attn_out, float* feats_out, const float* ex_attn, int flags, void* stream) {
     const bool aliased_feats = feats_out && (flags & EXCEL_VIT_FEATS_AS_REFERENCE);
-    EXCEL_CHECK_ARG(h && img && workspace && image_features, "excel_vit_forward: null argument");
+    EXCEL_CHECK_ARG(h && img && workspace && (image_features || x_raw), "excel_vit_forward: null argument (image_features or x_raw is required)");
     const excel_vit_config& c = h->cfg;
     EXCEL_CHECK_ARG(B > 0 && S > 0 && S % c.patch == 0, "excel_vit_forward: S must be a positive multiple of the patch size");
     const int ps = c.patch, g = S / ps, P = g * g, N = P + 1, D = c.width, H = c.heads, L = c.layers, C = c.out_dim;
@@ -550,8 +551,11 @@ static int vit_forward_impl(excel_vit_t h, const float* img, int B, int S, void*
     // x[0] = x_ori[0] (:442) fused into ln_post (:445), then @ proj (:446)
     TRY(excel_launch_layernorm(ws.x, c.n_surgery > 0 ? ws.xo : nullptr, N, h->w.ln_post_w, h->w.ln_post_b, ws.y, M, D, eps, st, bf));
     float* fraw = x_raw ? x_raw : ws.fraw;
-    TRY(linear(ws.y, h->projT, h->s_projT, nullptr, nullptr, fraw, C, D, GEMM_ACT_NONE, GEMM_OUT_PLAIN));
-    TRY(excel_launch_token_axis_normalize(fraw, ws.ss, image_features, B, N, C, st));             // clip.py:353
+    g_excel_prof_gemm_cat = PROF_CAM_PROJ;                     // the CAM's projection GEMM is reported on its own (bench.py roofline_sim_gemm)
+    const int rc_proj = linear(ws.y, h->projT, h->s_projT, nullptr, nullptr, fraw, C, D, GEMM_ACT_NONE, GEMM_OUT_PLAIN);
+    g_excel_prof_gemm_cat = -1;
+    TRY(rc_proj);
+    if (image_features) TRY(excel_launch_token_axis_normalize(fraw, ws.ss, image_features, B, N, C, st));   // clip.py:353 (the fused CAM kernel does it itself)
     return EXCEL_OK;
 }
 
@@ -570,6 +574,24 @@ extern "C" int excel_clip_feature_surgery(const float* image_features, const flo
     GemmArgs ga = gemm_args(image_features, text, S, nullptr, nullptr, B * N, T, C, C, C, ldT, 0, GEMM_ACT_NONE);
     TRY(excel_launch_gemm(ga, true, 1, ST(stream)));
     return excel_launch_cam_epilogue(S, out_full, out_slice, B, N, T, ldT, F, temperature, ST(stream));
+}
+
+// Fused path (cam.hip: patch_text_cam_kernel): token-axis norm + similarity on the matrix core + surgery epilogue in one launch,
+// straight from the un-normalised token features excel_vit_forward returns as x_raw.
+extern "C" size_t excel_patch_text_cam_workspace_bytes(int B, int N, int C, int T) {
+    return align_up((size_t)B * N * ((T + 3) / 4 * 4) * sizeof(float), 256) + align_up((size_t)T * C * sizeof(float), 256);
+}
+
+extern "C" int excel_patch_text_cam(const float* x_raw, const float* text, int B, int N, int C, int T, int F, float temperature, int mode,
+                                    float* out_full, float* out_slice, float* image_features, void* workspace, void* stream) {
+    EXCEL_CHECK_ARG(x_raw && text && workspace && (out_full || out_slice), "patch_text_cam: null argument");
+    EXCEL_CHECK_ARG(mode == 0 || mode == 1, "patch_text_cam: mode must be 0 (exact fp32) or 1 (bf16x3)");
+    const int ldT = (T + 3) / 4 * 4;
+    float* sim = (float*)workspace;
+    unsigned short* ts = (unsigned short*)((char*)workspace + align_up((size_t)B * N * ldT * sizeof(float), 256));
+    if (mode == 1) TRY(excel_launch_split_bf16(text, ts, T, C, ST(stream)));       // [T][2C] blocked hi|lo (a few KB, once per call)
+    return excel_launch_patch_text_cam(x_raw, text, mode == 1 ? ts : nullptr, sim, out_full, out_slice, image_features, B, N, C, T, F, ldT,
+                                       temperature, mode, ST(stream));
 }
 
 // ------------------------------------------------------------------------------------ affinity

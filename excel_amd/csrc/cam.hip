@@ -145,12 +145,6 @@ __global__ __launch_bounds__(512) void patch_text_cam_kernel(PtcArgs p) {
 
     float* simb = p.sim + (long long)b * N * p.ldT;
     const int ntile = (N + 31) / 32;
-    float mn[CT][16], mx[CT][16];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { mn[ct][e] = INFINITY; mx[ct][e] = -INFINITY; }
-
     bool first = true;
     for (int tile = wave; tile < ntile || first; tile += 8) {
         const bool live = tile < ntile;                       // every wave takes part in the barrier of its first round
@@ -251,25 +245,23 @@ __global__ __launch_bounds__(512) void patch_text_cam_kernel(PtcArgs p) {
             for (int e = 0; e < 16; ++e) {
                 const int cls = ct * 32 + c32_row(e, lane);
                 const float s = acc[ct][e] - red;
-                if (tok_ok && cls < T) {
-                    simb[(long long)(tile * 32 + r) * p.ldT + cls] = s;
-                    mn[ct][e] = fminf(mn[ct][e], s);
-                    mx[ct][e] = fmaxf(mx[ct][e], s);
-                }
+                if (tok_ok && cls < T) simb[(long long)(tile * 32 + r) * p.ldT + cls] = s;
             }
     }
-    // ---- per-class min / max over all tokens: across the 32 token columns of the wave, then across waves
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            float a = mn[ct][e], c = mx[ct][e];
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) { a = fminf(a, __shfl_xor(a, o, 64)); c = fmaxf(c, __shfl_xor(c, o, 64)); }
-            if (r == 0) { red_mn[wave][ct * 32 + c32_row(e, lane)] = a; red_mx[wave][ct * 32 + c32_row(e, lane)] = c; }
+    __syncthreads();       // orders this workgroup's sim writes before the re-reads below
+    // ---- per-class min / max over all tokens (one wave per token row, lanes over the classes; the [N,T] slab is L2/L1 resident)
+    {
+        float mn0 = INFINITY, mn1 = INFINITY, mx0 = -INFINITY, mx1 = -INFINITY;
+        for (int n = wave; n < N; n += 8) {
+            const float* row = simb + (long long)n * p.ldT;
+            if (lane < T) { const float v = row[lane]; mn0 = fminf(mn0, v); mx0 = fmaxf(mx0, v); }
+            if (lane + 64 < T) { const float v = row[lane + 64]; mn1 = fminf(mn1, v); mx1 = fmaxf(mx1, v); }
         }
-    __syncthreads();       // also orders this workgroup's sim writes before the re-read below
-    if (tid < CT * 32) {
+        red_mn[wave][lane] = mn0; red_mx[wave][lane] = mx0;
+        red_mn[wave][lane + 64] = mn1; red_mx[wave][lane + 64] = mx1;
+    }
+    __syncthreads();
+    if (tid < PTC_MAXCT * 32) {
         float a = red_mn[0][tid], c = red_mx[0][tid];
         for (int i = 1; i < 8; ++i) { a = fminf(a, red_mn[i][tid]); c = fmaxf(c, red_mx[i][tid]); }
         red_mn[0][tid] = a;
@@ -287,7 +279,7 @@ __global__ __launch_bounds__(512) void patch_text_cam_kernel(PtcArgs p) {
 
 int excel_launch_patch_text_cam(const float* x_raw, const float* text, const unsigned short* text_split, float* sim_ws, float* out_full,
                                 float* out_slice, float* feats, int B, int N, int C, int T, int F, int ldT, float temp, int bf, hipStream_t st) {
-    ProfScope prof__(PROF_CAM_EPILOGUE, st, 2.0 * B * (double)N * C * T);
+    ProfScope prof__(PROF_CAM_FUSED, st, 2.0 * B * (double)N * C * T);
     EXCEL_CHECK_ARG(T >= 1 && T <= PTC_MAXCT * 32 && F <= T && ldT >= T, "patch_text_cam: need 1 <= F <= T <= %d (T=%d F=%d)", PTC_MAXCT * 32, T, F);
     EXCEL_CHECK_ARG(C <= 1024 && (C % 32) == 0, "patch_text_cam: C must be a multiple of 32, <= 1024 (C=%d)", C);
     EXCEL_CHECK_ARG(!bf || text_split, "patch_text_cam: bf16x3 mode needs the split text");

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
 }
 
 int excel_launch_gemm(const GemmArgs& p, bool b_kmajor, int batch, hipStream_t stream) {
-    ProfScope prof__(b_kmajor ? PROF_GEMM_NT : PROF_GEMM_NN, stream, 2.0 * p.M * (double)p.N * p.K * batch);
+    ProfScope prof__(g_excel_prof_gemm_cat >= 0 ? g_excel_prof_gemm_cat : (b_kmajor ? PROF_GEMM_NT : PROF_GEMM_NN), stream, 2.0 * p.M * (double)p.N * p.K * batch);
     EXCEL_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0 && batch > 0, "gemm: bad shape M=%d N=%d K=%d batch=%d", p.M, p.N, p.K, batch);
     EXCEL_CHECK_ARG((p.lda % 4) == 0 && (p.Kld % 4) == 0 && p.Kld <= p.lda, "gemm: lda/Kld must be multiples of 4 (lda=%d Kld=%d)", p.lda, p.Kld);
     EXCEL_CHECK_ARG((((uintptr_t)p.A | (uintptr_t)p.B) & 15) == 0, "gemm: A/B must be 16-byte aligned");

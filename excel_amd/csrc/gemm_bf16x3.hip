@@ -425,7 +425,7 @@ int excel_launch_gemm_bf16x3(const GemmBfArgs& p_in, hipStream_t stream) {
 #ifdef EXCEL_DEV
     { static const char* d = getenv("EXCEL_BF_DBG"); if (d) p.dbg = atoi(d); }
 #endif
-    ProfScope prof__(PROF_GEMM_BF16X3, stream, 2.0 * p.M * (double)p.N * p.K * (p.batch > 1 ? p.batch : 1));
+    ProfScope prof__(g_excel_prof_gemm_cat >= 0 ? g_excel_prof_gemm_cat : PROF_GEMM_BF16X3, stream, 2.0 * p.M * (double)p.N * p.K * (p.batch > 1 ? p.batch : 1));
     EXCEL_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0 && (p.K % TBK) == 0, "gemm_bf16x3: K must be a multiple of %d (K=%d)", TBK, p.K);
     EXCEL_CHECK_ARG(p.out_mode != GEMM_OUT_SPLIT_BF16 || (p.N % 32) == 0, "gemm_bf16x3: split output needs N %% 32 == 0");
     EXCEL_CHECK_ARG((p.lda % 8) == 0 && (p.ldb % 8) == 0 && p.lda >= 2 * p.K && p.ldb >= 2 * p.K, "gemm_bf16x3: bad lda/ldb");

@@ -93,16 +93,18 @@ class ExCEL_model:
         """model(img) -> (seg, attn_fts, attr_maps_raw [B,P,F], attn_weights, attn_pred)      (:48-78)
         model(img, ex_feats=[B,C,g,g]) -> attr_maps_raw of the LVC branch                       (:50-53)"""
         if ex_feats is not None:
-            image_features, _, _ = clip.generate_clip_fts(img, self.encoder, return_weights=True, ex_feats=ex_feats)       # :51
-            return ops.clip_feature_surgery(image_features, self._text_rows, num_fg=self.num_classes - 1, want_full=False)[1]   # :52
+            r = self.encoder.encode_image(img, True, ex_feats, want_w_aff=False, want_raw=True, want_features=False)          # :51
+            return ops.patch_text_cam(r["x_raw"], self._text_rows, num_fg=self.num_classes - 1,
+                                      mode=self.encoder.visual.handle().gemm_mode())[1]                                  # :52
         want_feats = want_feats or self.feature_head is not None or self._dec is not None
         # the decoder consumes the list exactly as the reference stacks it (in-place aliasing quirk, include/excel_hip.h)
-        image_features, attn_weights, all_feats = clip.generate_clip_fts(img, self.encoder, return_weights=True,
-                                                                         n_attn_out=n_attn_out, want_feats=want_feats,
-                                                                         feats_as_reference=self._dec is not None)   # :57
-        _, attr_maps_raw = ops.clip_feature_surgery(image_features, self._text_rows, num_fg=self.num_classes - 1,
-                                                    want_full=False)                                                    # :58
-        self.last_image_features = image_features
+        # :57-58 back to back -> the fused kernel: the tower hands over the un-normalised token features, the token-axis norm,
+        # the similarity GEMM and the surgery epilogue are one launch (excel_patch_text_cam)
+        r = self.encoder.encode_image(img, True, None, want_w_aff=True, aff_layers=6, n_attn_out=n_attn_out, want_feats=want_feats,
+                                      feats_as_reference=self._dec is not None, want_raw=True, want_features=False)
+        attn_weights, all_feats = clip.clip.LazyAttnWeights(r["w_aff"], r["attn"], 6), r["feats"]
+        _, attr_maps_raw, _ = ops.patch_text_cam(r["x_raw"], self._text_rows, num_fg=self.num_classes - 1,
+                                                 mode=self.encoder.visual.handle().gemm_mode())
         self.last_all_feats = all_feats
         seg = attn_fts = attn_pred = None
         if self._dec is not None:

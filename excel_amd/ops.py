@@ -165,7 +165,7 @@ class VitHandle:
         return ws, need
 
     def forward(self, imgs, want_w_aff=True, aff_layers=6, n_attn_out=0, want_feats=False, want_raw=False, ex_attn=None,
-                feats_as_reference=False):
+                feats_as_reference=False, want_features=True):
         """-> dict(image_features [B,N,C], w_aff [B,P,P]|None, attn [n,B,N,N]|None, feats [L,B,N,D]|None, x_raw|None)
         ex_attn [B,P,P]: LVC cue added to every head of every surgery block (clip_surgery_model.py:127-141).
         feats_as_reference: `feats` as the reference's decoder receives them (in-place aliasing quirk, include/excel_hip.h)."""
@@ -176,8 +176,11 @@ class VitHandle:
         g = S // c["patch"]
         N = g * g + 1
         dev = imgs.device
-        f = torch.empty((B, N, c["out_dim"]), dtype=torch.float32, device=dev)
-        raw = torch.empty_like(f) if want_raw else None
+        if not (want_features or want_raw):
+            raise ValueError("VitHandle.forward: want_features or want_raw")
+        # want_features=False: only x_raw (the fused CAM kernel normalises over the token axis itself)
+        f = torch.empty((B, N, c["out_dim"]), dtype=torch.float32, device=dev) if want_features else None
+        raw = torch.empty((B, N, c["out_dim"]), dtype=torch.float32, device=dev) if want_raw else None
         w_aff = torch.empty((B, N - 1, N - 1), dtype=torch.float32, device=dev) if want_w_aff else None
         attn = torch.empty((n_attn_out, B, N, N), dtype=torch.float32, device=dev) if n_attn_out else None
         feats = torch.empty((c["layers"], B, N, c["width"]), dtype=torch.float32, device=dev) if want_feats else None
@@ -502,6 +505,26 @@ def clip_feature_surgery(image_features, text_features, num_fg=None, t=2.0, want
     check(lib().excel_clip_feature_surgery(_p(image_features), _p(text_features), B, N, Cc, T, F_, float(t), _p(full), _p(sl),
                                            _p(ws, torch.uint8), _stream()), "excel_clip_feature_surgery")
     return full, sl
+
+
+def patch_text_cam(x_raw, text_features, num_fg=None, t=2.0, want_full=False, want_features=False, mode="bf16x3"):
+    """Fused path (excel_patch_text_cam): un-normalised token features x_raw [B,N,C] (VitHandle.forward(want_raw=True)) + text [T,C]
+    -> (full [B,N,T] | None, slice [B,N-1,F] | None, image_features [B,N,C] | None): clip.py:353 + :288-310 in one launch."""
+    x_raw = f32c(x_raw)
+    text_features = f32c(text_features)
+    B, N, Cc = x_raw.shape
+    T = text_features.shape[0]
+    dev = x_raw.device
+    full = torch.empty((B, N, T), dtype=torch.float32, device=dev) if want_full else None
+    F_ = T if num_fg is None else num_fg
+    sl = torch.empty((B, N - 1, F_), dtype=torch.float32, device=dev) if num_fg is not None else None
+    feats = torch.empty_like(x_raw) if want_features else None
+    if full is None and sl is None:
+        raise ValueError("patch_text_cam: nothing to compute (want_full=False and num_fg=None)")
+    ws = _ws(lib().excel_patch_text_cam_workspace_bytes(B, N, Cc, T), dev)
+    check(lib().excel_patch_text_cam(_p(x_raw), _p(text_features), B, N, Cc, T, F_, float(t), 1 if mode == "bf16x3" else 0, _p(full), _p(sl),
+                                     _p(feats), _p(ws, torch.uint8), _stream()), "excel_patch_text_cam")
+    return full, sl, feats
 
 
 # ------------------------------------------------------------------ affinity random walk

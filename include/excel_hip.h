@@ -92,7 +92,7 @@ size_t excel_vit_workspace_bytes(excel_vit_t h, int B, int S);
 
 /* VisionTransformer.forward + generate_clip_fts (clip/clip_surgery_model.py:419-448, clip/clip.py:348-358).
  *   img            [B,3,S,S]
- *   image_features [B,N,C]  token-axis L2-normalised (clip.py:353)                         (required)
+ *   image_features [B,N,C]  token-axis L2-normalised (clip.py:353)                         (optional when x_raw is given)
  *   x_raw          [B,N,C]  ln_post(x) @ proj before the normalisation                      (optional, may be NULL)
  *   w_aff          [B,P,P]  mean over the last `aff_layers` layers of attn[:,1:,1:] -- exactly what
  *                           refine_cams_with_aff consumes (utils/affutils.py:180,197); block weights are head-MEAN
@@ -233,6 +233,14 @@ int excel_seg_scale_accumulate(const float* segs, float* acc, int B, int nc, int
 size_t excel_cam_workspace_bytes(int B, int N, int T);
 int excel_clip_feature_surgery(const float* image_features, const float* text, int B, int N, int C, int T, int F,
                                float temperature, float* out_full, float* out_slice, void* workspace, void* stream);
+
+/* The same attribute maps in ONE launch from the UN-normalised token features (x_raw of excel_vit_forward): token-axis L2 norm
+ * (clip/clip.py:353) + similarity GEMM on the matrix core + the surgery epilogue (clip/clip.py:288-310) -- model/model_excel.py:57-58
+ * back to back.  mode 1: bf16x3 (fp32 operands as bf16 hi+lo, 3 MFMAs per product), mode 0: exact fp32 MFMA.
+ * image_features [B,N,C] (optional): the normalised features generate_clip_fts returns.  T <= 128, C % 32 == 0, C <= 1024. */
+size_t excel_patch_text_cam_workspace_bytes(int B, int N, int C, int T);
+int excel_patch_text_cam(const float* x_raw, const float* text, int B, int N, int C, int T, int F, float temperature, int mode,
+                         float* out_full, float* out_slice, float* image_features, void* workspace, void* stream);
 
 /* ------------------------------------------------------------------ affinity random walk */
 

@@ -183,6 +183,39 @@ def test_clip_feature_surgery(ops, B, N, C, T, F):
     assert maxabs(host(sl), ref[:, 1:, :F]) < 2e-5
 
 
+@pytest.mark.parametrize("mode,tol", [("f32", 2e-5), ("bf16x3", 6e-5)])
+@pytest.mark.parametrize("B,N,C,T,F", [(3, 785, 512, 45, 20), (1, 1025, 512, 103, 80), (2, 37, 64, 9, 4), (1, 17, 32, 33, 33)])
+def test_patch_text_cam_fused(ops, B, N, C, T, F, mode, tol):
+    """excel_patch_text_cam: token-axis L2 norm (clip.py:353) + similarity on the matrix core + surgery epilogue (clip.py:288-310)
+    in one launch from the UN-normalised token features, against the oracle's generate_clip_fts tail + clip_feature_surgery."""
+    rs = np.random.RandomState(N + T + C)
+    x = (rs.standard_normal((B, N, C)) * (1 + rs.rand(1, 1, C) * 3)).astype(np.float32)      # uneven column norms
+    t = rs.standard_normal((T, C)).astype(np.float32)
+    t /= np.linalg.norm(t, axis=1, keepdims=True)
+    f = (x / np.sqrt((x * x).sum(axis=1, keepdims=True, dtype=np.float32))).astype(np.float32)   # clip.py:353
+    ref = oracle.cam.clip_feature_surgery(f, t)
+    full, sl, feats = ops.patch_text_cam(dev(x), dev(t), num_fg=F, want_full=True, want_features=True, mode=mode)
+    assert maxabs(host(feats), f) < 1e-6
+    assert maxabs(host(full), ref) < tol and maxabs(host(sl), ref[:, 1:, :F]) < tol
+    # the two-launch path on the normalised features gives the same maps
+    full2, _ = ops.clip_feature_surgery(dev(f), dev(t), num_fg=F)
+    assert maxabs(host(full), host(full2)) < tol
+    _, sl_only, none = ops.patch_text_cam(dev(x), dev(t), num_fg=F, mode=mode)                # slice only, no feature write
+    assert none is None and torch.equal(sl_only, sl)
+
+
+def test_clip_feature_surgery_redundant_feats_branch(ops):
+    """clip.py:289-290: similarity = image_features @ (text_features - redundant_feats).t() (the reference then returns an
+    unassigned name, :310; the evident intent - the similarity - is returned here)."""
+    from excel_amd import clip as xclip
+    rs = np.random.RandomState(5)
+    f = rs.standard_normal((2, 37, 64)).astype(np.float32)
+    t = rs.standard_normal((9, 64)).astype(np.float32)
+    red = rs.standard_normal((1, 64)).astype(np.float32)
+    out = host(xclip.clip_feature_surgery(dev(f), dev(t), redundant_feats=dev(red)))
+    assert out.shape == (2, 37, 9) and maxabs(out, f @ (t - red).T) < 1e-4
+
+
 def test_clip_feature_surgery_golden(ops, golden):
     g = golden("ops.npz")
     full, _ = ops.clip_feature_surgery(dev(g["cfs_f"]), dev(g["cfs_t"]))

@@ -180,3 +180,30 @@ def test_text_tower_and_prompt_ensemble(golden):
     out = oracle.text.encode_text(g["tokens"], w, heads=2)
     assert relmax(out, g["out"]) < 1e-5
     assert maxabs(oracle.text.prompt_ensemble(g["out"]), g["ensemble"]) < 1e-6
+
+
+def test_torch_cpu_port_matches_numpy_oracle():
+    """oracle/torch_cpu.py (the multi-threaded CPU baseline of bench.py) against the numpy oracle it mirrors: ViT features / last-6
+    attention weights to fp32 round-off, PAR, and the batch-1 evaluation loop label for label."""
+    from oracle import torch_cpu
+    from oracle.vit import VitConfig, make_vit_weights
+    cfg = VitConfig(width=128, layers=8, heads=2, patch=16, out_dim=64, input_resolution=64, n_surgery=5)
+    w = oracle.vit.reload_self_attn(make_vit_weights(cfg, seed=11), cfg, 6, "train")
+    rs = np.random.RandomState(3)
+    text = rs.standard_normal((9, 64)).astype(np.float32)
+    text /= np.linalg.norm(text, axis=1, keepdims=True)
+    samples = []
+    for i in range(3):
+        cls = np.zeros(4, np.float32)
+        cls[rs.choice(4, size=1 + i % 2, replace=False)] = 1
+        samples.append((rs.standard_normal((3, 96, 96)).astype(np.float32), rs.randint(0, 5, (70, 90)).astype(np.uint8), cls))
+    x1, a1, _ = oracle.vit.vit_forward_single(samples[0][0], w, cfg)
+    x2, a2 = torch_cpu.TorchVit(w, cfg, 6).forward(samples[0][0])
+    assert np.abs(x1 - x2).max() < 1e-4 and np.abs(np.stack(a1[-6:]) - a2).max() < 1e-4
+    m = rs.rand(1, 3, 31, 45).astype(np.float32)
+    im = rs.standard_normal((1, 3, 24, 24)).astype(np.float32)
+    assert np.abs(oracle.par.PAR([1, 2, 4, 8, 12, 24], 5)(im, m) - torch_cpu.TorchPAR([1, 2, 4, 8, 12, 24], 5)(im, m)).max() < 1e-5
+    h1, p1 = oracle.pipeline.build_validation(samples, w, cfg, text.T.copy(), num_classes=5, resize_size=96)
+    h2, p2, stage = torch_cpu.build_validation(iter(samples), w, cfg, text.T.copy(), num_classes=5, resize_size=96)
+    assert np.array_equal(h1, h2) and all(np.array_equal(a, b) for a, b in zip(p1, p2))
+    assert set(stage) == {"vit", "cam", "aff_random_walk", "upsample_par_argmax", "score"}
