@@ -112,6 +112,7 @@ SIGNATURES = {
     "excel_refine_cams_with_aff": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, C.c_double, c_f, c_f, c_f]),
     "excel_cam_upsample_bkg": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f]),
     "excel_par_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
+    "excel_par_set_mode": (c_i, [c_i]),
     "excel_par_forward": (c_i, [c_f, c_i, c_i, c_f, c_f, c_i, c_i, c_i, c_i, C.POINTER(C.c_int32), c_i, c_i,
                                 C.c_float, C.c_float, c_f, c_f, c_f]),
     "excel_argmax_label": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_ll, c_f, c_f, c_f]),

@@ -20,6 +20,7 @@ extern "C" const char* excel_last_error(void) { return g_err; }
 extern "C" int excel_abi_version(void) { return 1; }
 
 // ------------------------------------------------------------------------------------ profiling hooks
+int g_excel_par_mode = 0;
 bool g_excel_prof_on = false;
 int g_excel_prof_gemm_cat = -1;
 unsigned long long g_excel_prof_mask = ~0ull;
@@ -688,7 +689,11 @@ extern "C" int excel_par_forward(const float* imgs, int h, int w, const float* m
         TRY(excel_launch_bilinear_ac(imgs, guide, B * 3, h, w, H, W, st));
         gimg = guide;
     }
-    TRY(excel_launch_par_affinity(gimg, aff, B, H, W, dilations, ndil, w1, w2, st));
+    // Affinities: either streamed as 8*ndil planes per image, or (default where the tiled kernel applies) recomputed in every step
+    // from the guide image and 5 per-pixel statistics: bit-identical weights from a tenth of the bytes (par.hip).
+    const bool recompute = g_excel_par_mode != 1 && n_iter > 0 &&
+                           excel_par_guide_supported(gimg, aff, masks, out, H, W, dilations, ndil) && (((uintptr_t)pp & 15) == 0);
+    TRY(excel_launch_par_affinity(gimg, aff, B, H, W, dilations, ndil, w1, w2, st, recompute ? 1 : 0));
     if (n_iter == 0) {
         hipMemcpyAsync(out, masks, sizeof(float) * (size_t)B * Cmax * hw, hipMemcpyDeviceToDevice, st);
         return EXCEL_OK;
@@ -697,9 +702,18 @@ extern "C" int excel_par_forward(const float* imgs, int h, int w, const float* m
     const float* cur = masks;
     for (int it = 0; it < n_iter; ++it) {
         float* dst = (((n_iter - 1 - it) & 1) == 0) ? out : pp;
-        TRY(excel_launch_par_iterate(aff, cur, dst, nchan, B, Cmax, H, W, dilations, ndil, st));
+        if (recompute) TRY(excel_launch_par_iterate_guide(gimg, aff, cur, dst, nchan, B, Cmax, H, W, dilations, ndil, w1, w2, st));
+        else TRY(excel_launch_par_iterate(aff, cur, dst, nchan, B, Cmax, H, W, dilations, ndil, st));
         cur = dst;
     }
+    return EXCEL_OK;
+}
+
+// 0 (default): recompute the PAR affinities per step where supported; 1: always stream the affinity planes (the two are bit-identical;
+// kept selectable so that tests can compare them and profiles can show both)
+extern "C" int excel_par_set_mode(int mode) {
+    EXCEL_CHECK_ARG(mode == 0 || mode == 1, "excel_par_set_mode: mode must be 0 or 1");
+    g_excel_par_mode = mode;
     return EXCEL_OK;
 }
 

@@ -121,16 +121,26 @@ __global__ __launch_bounds__(512) void patch_text_cam_kernel(PtcArgs p) {
     const int N = p.N, C = p.C, T = p.T;
     const float* X = p.x_raw + (long long)b * N * C;
 
-    // ---- column norms over the token axis, fixed summation order (4 interleaved partial sums per column)
+    // ---- column norms over the token axis, fixed summation order: 16 interleaved partial sums per column (16 independent row
+    // loads in flight: the loop is latency-bound), combined pairwise
     for (int c = tid; c < C; c += 512) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        float s16[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s16[j] = 0.f;
         int n = 0;
-        for (; n + 4 <= N; n += 4) {
-            const float v0 = X[(long long)n * C + c], v1 = X[(long long)(n + 1) * C + c], v2 = X[(long long)(n + 2) * C + c], v3 = X[(long long)(n + 3) * C + c];
-            s0 = fmaf(v0, v0, s0); s1 = fmaf(v1, v1, s1); s2 = fmaf(v2, v2, s2); s3 = fmaf(v3, v3, s3);
+        for (; n + 16 <= N; n += 16) {
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = X[(long long)(n + j) * C + c];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) s16[j] = fmaf(v[j], v[j], s16[j]);
         }
-        for (; n < N; ++n) { const float v = X[(long long)n * C + c]; s0 = fmaf(v, v, s0); }
-        inv[c] = 1.f / sqrtf((s0 + s1) + (s2 + s3));
+        for (int j = 0; n < N; ++n, ++j) { const float v = X[(long long)n * C + c]; s16[j] = fmaf(v, v, s16[j]); }
+#pragma unroll
+        for (int st = 8; st > 0; st >>= 1)
+#pragma unroll
+            for (int j = 0; j < st; ++j) s16[j] += s16[j + st];
+        inv[c] = 1.f / sqrtf(s16[0]);
     }
     __syncthreads();
     if (p.feats) {
@@ -157,9 +167,29 @@ __global__ __launch_bounds__(512) void patch_text_cam_kernel(PtcArgs p) {
         if (live) {
             const float* xrow = X + (long long)n * C;
             if (BF) {
-                for (int k0 = 0; k0 < C; k0 += 16) {
+                // register double buffer: the loads of k-step k0+16 are in flight while k0 is split and multiplied
+                f32x4 xa, xb;
+                bf16x8 th[CT], tl[CT];
+                auto fetch = [&](int k0, f32x4& a, f32x4& bq, bf16x8 (&h)[CT], bf16x8 (&l)[CT]) {
                     const int c0 = k0 + 8 * kh;
-                    const f32x4 xa = *reinterpret_cast<const f32x4*>(xrow + c0), xb = *reinterpret_cast<const f32x4*>(xrow + c0 + 4);
+                    a = *reinterpret_cast<const f32x4*>(xrow + c0);
+                    bq = *reinterpret_cast<const f32x4*>(xrow + c0 + 4);
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+                        const int cls = min(ct * 32 + r, T - 1);                      // padded class rows: clamped load, zeroed below
+                        const unsigned short* tp = p.text_s + (long long)cls * 2 * C + split_off(c0, 0);
+                        h[ct] = *reinterpret_cast<const bf16x8*>(tp);
+                        l[ct] = *reinterpret_cast<const bf16x8*>(tp + 32);
+                    }
+                };
+                fetch(0, xa, xb, th, tl);
+                for (int k0 = 0; k0 < C; k0 += 16) {
+                    f32x4 nxa = xa, nxb = xb;
+                    bf16x8 nth[CT], ntl[CT];
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) { nth[ct] = th[ct]; ntl[ct] = tl[ct]; }
+                    if (k0 + 16 < C) fetch(k0 + 16, nxa, nxb, nth, ntl);
+                    const int c0 = k0 + 8 * kh;
                     const f32x4 ia = *reinterpret_cast<const f32x4*>(inv + c0), ib = *reinterpret_cast<const f32x4*>(inv + c0 + 4);
                     bf16x8 xh, xl;
 #pragma unroll
@@ -170,17 +200,15 @@ __global__ __launch_bounds__(512) void patch_text_cam_kernel(PtcArgs p) {
                     }
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct) {
-                        const int cls = ct * 32 + r;
-                        bf16x8 th = {0, 0, 0, 0, 0, 0, 0, 0}, tl = th;
-                        if (cls < T) {
-                            const unsigned short* tp = p.text_s + (long long)cls * 2 * C + split_off(c0, 0);
-                            th = *reinterpret_cast<const bf16x8*>(tp);
-                            tl = *reinterpret_cast<const bf16x8*>(tp + 32);
-                        }
-                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tl, xh, acc[ct], 0, 0, 0);
-                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th, xl, acc[ct], 0, 0, 0);
-                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th, xh, acc[ct], 0, 0, 0);
+                        bf16x8 h = th[ct], l = tl[ct];
+                        if (ct * 32 + r >= T) { h = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; l = h; }
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l, xh, acc[ct], 0, 0, 0);
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h, xl, acc[ct], 0, 0, 0);
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h, xh, acc[ct], 0, 0, 0);
                     }
+                    xa = nxa; xb = nxb;
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) { th[ct] = nth[ct]; tl[ct] = ntl[ct]; }
                 }
             } else {
                 for (int k0 = 0; k0 < C; k0 += 8) {

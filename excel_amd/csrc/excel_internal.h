@@ -76,7 +76,10 @@ int excel_launch_matvec(const float* T, const float* v, const int* ncls, float* 
 int excel_launch_cam_upsample_bkg(const float* r, const int* ncls, float* rn, float* cams, int B, int g, int Smax, int H, int W,
                                   hipStream_t st);
 int excel_launch_par_affinity(const float* img, float* aff, int B, int H, int W, const int* dil, int ndil, float w1, float w2,
-                              hipStream_t st);
+                              hipStream_t st, int compact = 0);
+int excel_par_guide_supported(const float* guide, const float* stats, const float* in, const float* out, int H, int W, const int* dil, int ndil);
+int excel_launch_par_iterate_guide(const float* guide, const float* stats, const float* in, float* out, const int* nchan, int B, int Cmax,
+                                   int H, int W, const int* dil, int ndil, float w1, float w2, hipStream_t st);
 int excel_launch_par_iterate(const float* aff, const float* in, float* out, const int* nchan, int B, int Cmax, int H, int W,
                              const int* dil, int ndil, hipStream_t st);
 int excel_launch_bilinear_ac(const float* in, float* out, int planes, int h, int w, int H, int W, hipStream_t st);

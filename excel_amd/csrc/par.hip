@@ -22,9 +22,14 @@ struct ParDil {
 __device__ __constant__ int TAP_DY[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
 __device__ __constant__ int TAP_DX[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
 
+// COMPACT: instead of the 48 affinity planes write the 5 per-pixel statistics they are a function of,
+//   stats[b][0..2] = k2_c = 1 / ((std_c + 1e-8) w1)^2,   stats[b][3] = m (max of the 48 exponents),   stats[b][4] = 1 / sum exp
+// par_iterate_guide_kernel recomputes  aff_t = exp(sum_c -(I_nb - I)^2 k2_c / 3 - m) / sum + pos_t  from them with the SAME operations
+// in the same order, i.e. bit-identical weights, from 20 B/pixel instead of 192 B/pixel.
+// (a RUN-TIME flag on one instantiation: both output forms come from the same compiled arithmetic.)
 template <int ND>
 __global__ __launch_bounds__(256) void par_affinity_kernel(const float* __restrict__ img, float* __restrict__ aff, ParDil dl,
-                                                           int H, int W, float w1) {
+                                                           int H, int W, float w1, int COMPACT) {
     constexpr int NT = 8 * ND;
     const int b = blockIdx.z;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -69,6 +74,7 @@ __global__ __launch_bounds__(256) void par_affinity_kernel(const float* __restri
         // were ~80 % of this kernel's instructions); differs from the literal form by one rounding (~1e-7 relative)
         const float k = 1.f / (den * w1);
         const float k2 = k * k;
+        if (COMPACT && in_x) aff[((long long)b * 5 + c) * HW + (long long)y * W + x] = k2;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const float dv = nb[t] - ctr;
@@ -77,12 +83,17 @@ __global__ __launch_bounds__(256) void par_affinity_kernel(const float* __restri
     }
     float m = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) { acc[t] = acc[t] * (1.f / 3.f); m = fmaxf(m, acc[t]); }
-    float s = 0.f;
+    for (int t = 0; t < NT; ++t) { acc[t] = __fmul_rn(acc[t], 1.f / 3.f); m = fmaxf(m, acc[t]); }     // mean over RGB (no contraction:
+    float s = 0.f;                                                                                   //  par_iterate_guide_kernel redoes it)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) { acc[t] = __expf(acc[t] - m); s += acc[t]; }
+    for (int t = 0; t < NT; ++t) { acc[t] = __expf(__fsub_rn(acc[t], m)); s += acc[t]; }
     const float inv_s = 1.f / s;
     if (!in_x) return;
+    if (COMPACT) {
+        aff[((long long)b * 5 + 3) * HW + (long long)y * W + x] = m;
+        aff[((long long)b * 5 + 4) * HW + (long long)y * W + x] = inv_s;
+        return;
+    }
     float* out = aff + (long long)b * NT * HW + (long long)y * W + x;
 #pragma unroll
     for (int t = 0; t < NT; ++t) out[(long long)t * HW] = fmaf(acc[t], inv_s, dl.pos_sm[t]);
@@ -294,8 +305,9 @@ __device__ __forceinline__ void par_lds_pair(const float* __restrict__ ac, const
                     if (r == 1 && dx == 0) continue;
                     const int k = (r == 0) ? dx + 1 : (r == 1 ? (dx < 0 ? 3 : 4) : dx + 6);
                     const int off = rr[r] * TP + cb + dx * d;
-                    acc0 += *reinterpret_cast<const f32x4*>(&tile[off]) * w8[k];
-                    if (nc > 1) acc1 += *reinterpret_cast<const f32x4*>(&tile[TR * TP + off]) * w8[k];
+                    // explicit fused multiply-adds in tap order: the result does not depend on how an instantiation is contracted
+                    acc0 = __builtin_elementwise_fma(*reinterpret_cast<const f32x4*>(&tile[off]), w8[k], acc0);
+                    if (nc > 1) acc1 = __builtin_elementwise_fma(*reinterpret_cast<const f32x4*>(&tile[TR * TP + off]), w8[k], acc1);
                     if (KEEP && dx == 1) __builtin_amdgcn_sched_barrier(0);
                 }
         } else {
@@ -315,7 +327,7 @@ __device__ __forceinline__ void par_lds_pair(const float* __restrict__ ac, const
                             if (r == 1 && dx == 0) continue;
                             const int k = (r == 0) ? dx + 1 : (r == 1 ? (dx < 0 ? 3 : 4) : dx + 6);
                             const f32x4 v = {win[4 + SH * dx], win[5 + SH * dx], win[6 + SH * dx], win[7 + SH * dx]};
-                            if (ch == 0) acc0 += v * w8[k]; else acc1 += v * w8[k];
+                            if (ch == 0) acc0 = __builtin_elementwise_fma(v, w8[k], acc0); else acc1 = __builtin_elementwise_fma(v, w8[k], acc1);
                         }
                         if (KEEP) __builtin_amdgcn_sched_barrier(0);      // one row's window live at a time (192 aff VGPRs are pinned)
                     }
@@ -364,6 +376,174 @@ __global__ __launch_bounds__(256, 2) void par_iterate_lds_kernel(const float* __
     } else {
         f32x4 none[1][8];
         par_lds_pair<ND, HALO, 0>(a, none, tile, in_b, out_px, nch, dl, x0, y0, tid, tx, ty, valid, H, W, HW);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Jacobi step that RECOMPUTES the affinities from the guide image (par_affinity_kernel COMPACT statistics).
+// The 48 weights of a pixel are a function of 3 image values per tap and 5 per-pixel statistics; streaming them as 48 fp32
+// planes made the step HBM-bound at (48 + 2C) x 4 B/pixel - here a step reads (5 + 3 + 2C) x 4 B/pixel and pays
+// ~10 VALU operations per tap.  One workgroup = a 64 x 16 pixel tile (thread = 4 pixels); the planes it needs - the three guide
+// channels, then the image's mask channels - go through a DOUBLE-BUFFERED LDS tile (64 rows x 128 floats incl. the 24-pixel halo),
+// filled by 4-byte LDS-DMA with edge-clamped per-lane source addresses (= replicate padding): plane p+1 streams in while the taps
+// of plane p are evaluated, one barrier per plane, no staging registers.  Phase 1 (guide planes) accumulates the tap exponents in
+// wall[ND][8] (float4 = this thread's 4 pixels), a finalisation turns them into the weights, phase 2 (mask planes) applies them.
+// Same operations in the same order as par_affinity_kernel + the streamed-plane kernel -> bit-identical results.
+#define PG_TP 128            // LDS row pitch (floats): 512 B keeps every ds_read_b128 group on distinct banks
+template <int ND, int HALO>
+__global__ __launch_bounds__(256, 2) void par_iterate_guide_kernel(const float* __restrict__ guide, const float* __restrict__ stats,
+                                                                   const float* __restrict__ in, float* __restrict__ out,
+                                                                   const int* __restrict__ nchan, ParDil dl, int Cmax, int H, int W, int dbg) {
+    constexpr int TR = 16 + 2 * HALO, TP = PG_TP;
+    static_assert(64 + 2 * HALO <= TP, "tile row does not fit the LDS pitch");
+    __shared__ __attribute__((aligned(1024))) float tile[2 * TR * TP];   // [2][TR][TP]
+    const int b = blockIdx.z, x0 = blockIdx.x * 64, y0 = blockIdx.y * 16;
+    const int tid = threadIdx.x, lane = tid & 63, tx = tid & 15, ty = tid >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = x0 + 4 * tx, py = y0 + ty;
+    const bool valid = px < W && py < H;
+    const int nch = nchan ? min(nchan[b], Cmax) : Cmax;
+    const long long HW = (long long)H * W;
+    const long long pix = (long long)min(py, H - 1) * W + min(px, W - 4);
+    const float* st_b = stats + (long long)b * 5 * HW + pix;
+
+    // ---- plane staging by LDS-DMA: wave w fills rows [w*TR/4, (w+1)*TR/4) of the tile, two 64-float pieces per row
+    typedef __attribute__((address_space(3))) unsigned char* lds_bptr;
+    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)(guide + (long long)b * 3 * HW), 0, (int)(3 * HW * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc((void*)(in + (long long)b * Cmax * HW), 0, (int)((long long)Cmax * HW * 4), 0x00020000);
+    const int xoffA = min(max(x0 - HALO + lane, 0), W - 1) * 4, xoffB = min(max(x0 - HALO + 64 + lane, 0), W - 1) * 4;   // replicate padding in x
+    const unsigned tile_b = lds_addr(tile);
+    constexpr int RPW = TR / 4;                                  // rows per wave
+    auto stage = [&](int p, int buf) {                           // plane p of the sequence [guide 0..2, mask 0..nch-1] -> buffer buf
+        const bool is_g = p < 3;
+        const int plane_off = (is_g ? p : p - 3) * (int)(HW * 4);
+        unsigned dst = tile_b + (buf * TR + wave * RPW) * (TP * 4);
+        asm volatile("" : "+s"(dst));
+#pragma unroll 4
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int gy = min(max(y0 - HALO + wave * RPW + rr, 0), H - 1);                    // replicate padding in y (scalar)
+            const int soff = plane_off + gy * W * 4;
+            if (is_g) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_bptr)(unsigned long long)(dst + rr * (TP * 4)), 4, xoffA, soff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_bptr)(unsigned long long)(dst + rr * (TP * 4) + 256), 4, xoffB, soff, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_m, (lds_bptr)(unsigned long long)(dst + rr * (TP * 4)), 4, xoffA, soff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_m, (lds_bptr)(unsigned long long)(dst + rr * (TP * 4) + 256), 4, xoffB, soff, 0, 0);
+            }
+        }
+    };
+
+    f32x4 wall[ND][8];
+#pragma unroll
+    for (int di = 0; di < ND; ++di)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wall[di][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // taps of one staged plane: FN(di, k, float4 of the 4 neighbours); LDS reads as inline asm (a compiler-visible ds_read behind the
+    // pending LDS-DMA of the NEXT plane would be preceded by s_waitcnt vmcnt(0))
+    const int cb = HALO + 4 * tx;
+    auto taps = [&](int buf, auto&& fn) {
+        // opaque per plane: otherwise the ~50 per-lane LDS tap addresses (x 2 buffers) are hoisted out of the plane loop and compete
+        // with the pinned weight registers (spills)
+        int cbo = cb, tyo = ty;
+        asm volatile("" : "+v"(cbo), "+v"(tyo));
+        const unsigned base = tile_b + buf * (TR * TP * 4);
+#pragma unroll
+        for (int di = 0; di < ND; ++di) {
+            const int d = dl.d[di];
+            const int rrow[3] = {tyo + HALO - d, tyo + HALO, tyo + HALO + d};
+            if ((d & 3) == 0) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {                    // one tap row at a time: at most 3 float4 in flight next to the 192 weight registers
+                    const unsigned rowa = base + (rrow[r] * TP + cbo) * 4;
+                    f32x4 L, M, R;
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(L) : "v"(rowa - d * 4) : "memory");
+                    if (r != 1) asm volatile("ds_read_b128 %0, %1" : "=v"(M) : "v"(rowa) : "memory");
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(R) : "v"(rowa + d * 4) : "memory");
+                    if (r != 1) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(L), "+v"(M), "+v"(R)::"memory");
+                        fn(di, r == 0 ? 0 : 5, L);
+                        fn(di, r == 0 ? 1 : 6, M);
+                        fn(di, r == 0 ? 2 : 7, R);
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(L), "+v"(R)::"memory");
+                        fn(di, 3, L);
+                        fn(di, 4, R);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);           // consume this row before the next row's reads are issued
+                }
+            } else {
+                auto window = [&](auto shift_tag) {
+                    constexpr int SH = decltype(shift_tag)::value;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const unsigned rowa = base + (rrow[r] * TP + cbo) * 4;
+                        f32x4 L, M, R;
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(L) : "v"(rowa - 16) : "memory");
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(M) : "v"(rowa) : "memory");
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(R) : "v"(rowa + 16) : "memory");
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(L), "+v"(M), "+v"(R)::"memory");
+                        const float win[12] = {L[0], L[1], L[2], L[3], M[0], M[1], M[2], M[3], R[0], R[1], R[2], R[3]};
+#pragma unroll
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            if (r == 1 && dx == 0) continue;
+                            const int k = (r == 0) ? dx + 1 : (r == 1 ? (dx < 0 ? 3 : 4) : dx + 6);
+                            fn(di, k, f32x4{win[4 + SH * dx], win[5 + SH * dx], win[6 + SH * dx], win[7 + SH * dx]});
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                };
+                if (d == 1) window(std::integral_constant<int, 1>{});
+                else if (d == 2) window(std::integral_constant<int, 2>{});
+                else window(std::integral_constant<int, 3>{});
+            }
+        }
+    };
+
+    const int np = 3 + nch;
+    stage(0, 0);
+    float* out_px = out + (long long)b * Cmax * HW + (long long)py * W + px;
+    // phase 1 in its own loop (one body: with two different bodies in one rolled loop the 192 in-place accumulators were copied / spilled)
+#pragma unroll 1
+    for (int p = 0; p < 3; ++p) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's pieces of plane p have landed
+        __builtin_amdgcn_s_barrier();                                // ... everyone's have, and everyone is done with plane p-1's buffer
+        stage(p + 1, (p + 1) & 1);                                   // (np >= 4) streams in behind the taps below
+        if (EXCEL_DBG(dbg) & 1) continue;
+        // guide channel p:  z_t += -(I_nb - I)^2 k2_p   as fma(dv dv, -k2, z), dv = nb + (-ctr): bit-identical to the affinity kernel,
+        // in forms that map onto packed VALU instructions without separate negations
+        const f32x4 nk2 = -*reinterpret_cast<const f32x4*>(st_b + (long long)p * HW);
+        f32x4 ctr;
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(ctr) : "v"(tile_b + (((p & 1) * TR + ty + HALO) * TP + cb) * 4) : "memory");
+        const f32x4 nctr = -ctr;
+        taps(p & 1, [&](int di, int k, const f32x4 nb) {
+            const f32x4 dv = nb + nctr;
+            wall[di][k] = __builtin_elementwise_fma(dv * dv, nk2, wall[di][k]);
+        });
+    }
+    if (!(EXCEL_DBG(dbg) & 2)) {
+        // aff_t = exp(z_t / 3 - m) / sum + pos_t : the affinity kernel's operations, one rounding each
+        const f32x4 m4 = *reinterpret_cast<const f32x4*>(st_b + 3 * HW), is4 = *reinterpret_cast<const f32x4*>(st_b + 4 * HW);
+#pragma unroll
+        for (int di = 0; di < ND; ++di)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                f32x4 e;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e[j] = __expf(__fsub_rn(__fmul_rn(wall[di][k][j], 1.f / 3.f), m4[j]));
+                const float ps = dl.pos_sm[di * 8 + k];
+                wall[di][k] = __builtin_elementwise_fma(e, is4, f32x4{ps, ps, ps, ps});
+            }
+    }
+    // phase 2: the weights are loop invariant
+    for (int p = 3; p < np; ++p) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (p + 1 < np) stage(p + 1, (p + 1) & 1);
+        if (EXCEL_DBG(dbg) & 4) continue;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        taps(p & 1, [&](int di, int k, const f32x4 nb) { acc = __builtin_elementwise_fma(nb, wall[di][k], acc); });   // tap order, fused
+        if (valid) *reinterpret_cast<f32x4*>(out_px + (long long)(p - 3) * HW) = acc;
     }
 }
 
@@ -477,8 +657,8 @@ static int make_dil(const int* dil, int ndil, float w1, float w2, ParDil* out) {
 }
 
 template <int ND>
-static void par_aff_launch(const float* img, float* aff, const ParDil& dl, int B, int H, int W, float w1, hipStream_t st) {
-    hipLaunchKernelGGL(par_affinity_kernel<ND>, dim3(cdiv(W, 64), cdiv(H, 4), B), dim3(256), 0, st, img, aff, dl, H, W, w1);
+static void par_aff_launch(const float* img, float* aff, const ParDil& dl, int B, int H, int W, float w1, hipStream_t st, bool compact) {
+    hipLaunchKernelGGL(par_affinity_kernel<ND>, dim3(cdiv(W, 64), cdiv(H, 4), B), dim3(256), 0, st, img, aff, dl, H, W, w1, compact ? 1 : 0);
 }
 template <int ND>
 static void par_it_launch(const float* aff, const float* in, float* out, const int* nchan, const ParDil& dl, int B, int Cmax,
@@ -503,6 +683,29 @@ static void par_it_launch(const float* aff, const float* in, float* out, const i
         hipLaunchKernelGGL(par_iterate_kernel<ND>, dim3(cdiv(W, 64), cdiv(H, 4), B), dim3(256), 0, st, aff, in, out, nchan, dl, Cmax, H, W);
 }
 
+// guide-recompute path: same preconditions as the LDS kernel
+static bool par_guide_ok(const void* guide, const void* stats, const void* in, const void* out, int H, int W, const int* dil, int ndil, int* halo_out) {
+    bool vec = (W % 4) == 0 && W >= 8 && ((((uintptr_t)guide | (uintptr_t)stats | (uintptr_t)in | (uintptr_t)out) & 15) == 0);
+    int halo = 0;
+    for (int i = 0; i < ndil; ++i) { vec = vec && ((dil[i] & 3) == 0 || dil[i] <= 3); halo = dil[i] > halo ? dil[i] : halo; }
+    halo = (halo + 3) / 4 * 4;
+    *halo_out = halo;
+    // 8*ndil float4 weights stay in registers (6 dilations = 192 of 256 VGPRs); the scalar offsets of the LDS-DMA are 32-bit
+    return vec && (halo == 24 || halo == 8) && ndil <= 6 && (long long)H * W * 4 * 64 < (1LL << 31);
+}
+template <int ND>
+static void par_guide_launch(const float* guide, const float* stats, const float* in, float* out, const int* nchan, const ParDil& dl, int B,
+                             int Cmax, int H, int W, int halo, hipStream_t st) {
+    const dim3 grid(cdiv(W, 64), cdiv(H, 16), B);
+    int dbg = 0;
+#ifdef EXCEL_DEV
+    static const int env_dbg = getenv("EXCEL_PAR_DBG") ? atoi(getenv("EXCEL_PAR_DBG")) : 0;
+    dbg = env_dbg;
+#endif
+    if (halo == 24) hipLaunchKernelGGL((par_iterate_guide_kernel<ND, 24>), grid, dim3(256), 0, st, guide, stats, in, out, nchan, dl, Cmax, H, W, dbg);
+    else hipLaunchKernelGGL((par_iterate_guide_kernel<ND, 8>), grid, dim3(256), 0, st, guide, stats, in, out, nchan, dl, Cmax, H, W, dbg);
+}
+
 #define ND_SWITCH(nd, CALL)                 \
     switch (nd) {                           \
         case 1: CALL(1); break;             \
@@ -516,12 +719,12 @@ static void par_it_launch(const float* aff, const float* in, float* out, const i
     }
 
 int excel_launch_par_affinity(const float* img, float* aff, int B, int H, int W, const int* dil, int ndil, float w1, float w2,
-                              hipStream_t st) {
+                              hipStream_t st, int compact) {
     ProfScope prof__(PROF_PAR_AFFINITY, st);
     ParDil dl;
     int rc = make_dil(dil, ndil, w1, w2, &dl);
     if (rc) return rc;
-#define CALL(N) par_aff_launch<N>(img, aff, dl, B, H, W, w1, st)
+#define CALL(N) par_aff_launch<N>(img, aff, dl, B, H, W, w1, st, compact != 0)
     ND_SWITCH(ndil, CALL)
 #undef CALL
     EXCEL_CHECK_LAUNCH("par_affinity");
@@ -538,6 +741,27 @@ int excel_launch_par_iterate(const float* aff, const float* in, float* out, cons
     ND_SWITCH(ndil, CALL)
 #undef CALL
     EXCEL_CHECK_LAUNCH("par_iterate");
+    return EXCEL_OK;
+}
+
+// One Jacobi step with the affinities recomputed from (guide, stats); returns 1 when the shape is not supported (caller streams
+// the 48 affinity planes instead).  w1 / w2 enter through the position term only (the colour term's w1 is inside stats).
+int excel_par_guide_supported(const float* guide, const float* stats, const float* in, const float* out, int H, int W, const int* dil, int ndil) {
+    int halo;
+    return par_guide_ok(guide, stats, in, out, H, W, dil, ndil, &halo) ? 1 : 0;
+}
+int excel_launch_par_iterate_guide(const float* guide, const float* stats, const float* in, float* out, const int* nchan, int B, int Cmax,
+                                   int H, int W, const int* dil, int ndil, float w1, float w2, hipStream_t st) {
+    int halo;
+    if (!par_guide_ok(guide, stats, in, out, H, W, dil, ndil, &halo)) return 1;
+    ProfScope prof__(PROF_PAR_ITERATE, st);
+    ParDil dl;
+    int rc = make_dil(dil, ndil, w1, w2, &dl);
+    if (rc) return rc;
+#define CALL(N) par_guide_launch<N>(guide, stats, in, out, nchan, dl, B, Cmax, H, W, halo, st)
+    ND_SWITCH(ndil, CALL)
+#undef CALL
+    EXCEL_CHECK_LAUNCH("par_iterate_guide");
     return EXCEL_OK;
 }
 

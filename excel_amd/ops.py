@@ -739,6 +739,12 @@ def prof_enable(on=True, categories=None, every=1):
     check(lib().excel_prof_enable(1 if on else 0), "excel_prof_enable")
 
 
+def par_set_mode(mode):
+    """"recompute" (default): PAR affinities recomputed inside every Jacobi step from the guide image + 5 per-pixel statistics;
+    "stream": the 8*ndil affinity planes are streamed from HBM.  Bit-identical outputs (same arithmetic, same order)."""
+    check(lib().excel_par_set_mode({"recompute": 0, "stream": 1}[mode]), "excel_par_set_mode")
+
+
 def prof_collect():
     """-> {category: dict(ms=summed elapsed, launches=count, work=algorithmic FLOPs or 0)} and clears the log."""
     n = lib().excel_prof_num_categories()

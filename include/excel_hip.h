@@ -290,6 +290,10 @@ size_t excel_par_workspace_bytes(int B, int Cmax, int H, int W, int ndil);
 int excel_par_forward(const float* imgs, int h, int w, const float* masks, const int32_t* nchan, int B, int Cmax, int H, int W,
                       const int32_t* dilations /*host*/, int ndil, int n_iter, float w1, float w2, float* out,
                       void* workspace, void* stream);
+/* PAR affinities: mode 0 (default) recomputes the 8*ndil weights of a pixel inside every Jacobi step from the guide image and 5
+ * per-pixel statistics (20 B/pixel instead of 192 B/pixel of HBM traffic per step); mode 1 streams them as planes.  Same arithmetic
+ * in the same order: the outputs are bit-identical.  Process-wide. */
+int excel_par_set_mode(int mode);
 
 /* refined.argmax(1) -> valid_key lookup (utils/affutils.py:86-87, :168).  cls_idx may be NULL (identity keys). */
 int excel_argmax_label(const float* cams, const int32_t* nchan, const int32_t* cls_idx, int B, int Smax, int Cmax,

@@ -425,6 +425,29 @@ def test_confusion(ops, nc, n):
     assert np.array_equal(host(hist), 2 * ref)
 
 
+@pytest.mark.parametrize("B,C,H,W,dil,it", [(2, 3, 64, 80, (1, 2, 4, 8, 12, 24), 5), (1, 7, 96, 96, (1, 2, 4, 8, 12, 24), 20),
+                                            (3, 2, 50, 36, (1, 2, 4, 8), 3), (2, 4, 448, 448, (1, 2, 4, 8, 12, 24), 2)])
+def test_par_recompute_equals_streamed_affinities(ops, B, C, H, W, dil, it):
+    """The default PAR step recomputes its 48 weights per pixel from the guide image and 5 per-pixel statistics (same operations in
+    the same order as the affinity kernel); streaming the 48 planes must give the SAME BITS, ragged channel counts included."""
+    rs = np.random.RandomState(H + C)
+    img = dev(rs.standard_normal((B, 3, H, W)).astype(np.float32))
+    masks = dev(rs.rand(B, C, H, W).astype(np.float32))
+    nchan = dev(np.array([max(1, C - b) for b in range(B)], np.int32))
+    try:
+        ops.par_set_mode("stream")
+        ref = ops.par_forward(img, masks, dil, it, nchan=nchan)
+        ops.par_set_mode("recompute")
+        got = ops.par_forward(img, masks, dil, it, nchan=nchan)
+    finally:
+        ops.par_set_mode("recompute")
+    for b in range(B):
+        k = int(host(nchan)[b])
+        assert torch.equal(got[b, :k], ref[b, :k])
+    lo = oracle.par.PAR(list(dil), it)(host(img)[:1], host(masks)[:1, :int(host(nchan)[0])])
+    assert maxabs(host(got)[0, :int(host(nchan)[0])], lo[0]) < 2e-4
+
+
 def test_confusion_unaligned_slices(ops):
     """gt / pred views that do not start on a 16-byte boundary (labels_u8[i], gts[lo:hi] of an odd-sized image): same
     misalignment -> scalar head + vector body; different misalignment -> scalar path.  Both equal fast_hist."""
