@@ -39,7 +39,7 @@ def main(fetch_csv, write_csv):
                       bytes_per_launch=int((2 * f_kb + w_kb) * 1024))
     top = {}
     for cat, prefix in (("gemm_bf16x3", "gemm_bf16x3_kernel"), ("par_iterate", "par_iterate"), ("attn_rowpass", "attn_rowpass"),
-                        ("attn_accum", "attn_accum")):
+                        ("attn_accum", "attn_accum"), ("attn_strip", "attn_strip"), ("par_iterate_guide", "par_iterate_guide")):
         ks = [v for k, v in out.items() if k.startswith(prefix)]
         n = sum(v["launches"] for v in ks)
         if n:        # launch-weighted mean over the template instances of one bench category
