@@ -36,6 +36,7 @@ struct RowpassArgs {
     int flash_nq;        // q-blocks >= flash_nq of type 0 only produce row stats (last block: only the cls row's output is consumed)
     const unsigned short* vt;     // V^T in split format [B][H*64][2*vt_kp] (gemm_bf16x3.hip: vt_split_kernel): P.V as bf16x3 (null = fp32 P.V)
     int vt_kp;
+    int xcd_local;       // 1: workgroups of one (image, head) on one XCD
 };
 
 typedef unsigned short u16;
@@ -455,16 +456,23 @@ __device__ __forceinline__ void rowpass_body_bf(const RowpassArgs& p, float* sme
 
 __global__ __launch_bounds__(256, 2) void attn_rowpass_kernel(RowpassArgs p) {
     __shared__ __attribute__((aligned(1024))) float smem[3 * 4096];   // 48 KB: 3-stage ring of (K tile 8 KB + V^T tile 8 KB); >= the 33.8 KB of the fp32 path
-    const int bh = blockIdx.y;
+    int bh = blockIdx.y, qb = blockIdx.x;
+    if (p.xcd_local) {
+        // the q-blocks of one (image, head) share its K / V^T tiles: keep them on one XCD (consecutive logical ids) so the tiles are
+        // fetched from the fabric once, not once per XCD (measured fabric traffic of this kernel: 2.6x its algorithmic bytes)
+        const int id = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+        qb = id % gridDim.x;
+        bh = id / gridDim.x;
+    }
     const int b = bh / p.H, h = bh % p.H;
     const int type = blockIdx.z;
-    const bool flash = type == 0 && (int)blockIdx.x < p.flash_nq;
+    const bool flash = type == 0 && qb < p.flash_nq;
     if (p.qkvs && p.vt) {
-        if (flash) rowpass_body_bf<true>(p, smem, b, h, 0, blockIdx.x);
-        else rowpass_body_bf<false>(p, smem, b, h, type, blockIdx.x);
+        if (flash) rowpass_body_bf<true>(p, smem, b, h, 0, qb);
+        else rowpass_body_bf<false>(p, smem, b, h, type, qb);
     } else {
-        if (flash) rowpass_body<true, false>(p, smem, b, h, 0, blockIdx.x);
-        else rowpass_body<false, false>(p, smem, b, h, type, blockIdx.x);
+        if (flash) rowpass_body<true, false>(p, smem, b, h, 0, qb);
+        else rowpass_body<false, false>(p, smem, b, h, type, qb);
     }
 }
 
@@ -874,7 +882,10 @@ int excel_launch_attn_rowpass(const float* qkvh, float* out, float* stats, int B
     EXCEL_CHECK_ARG(hd == HD, "attention: head_dim must be 64 (got %d)", hd);
     EXCEL_CHECK_ARG(ntypes == 1 || ntypes == 4, "attention: ntypes must be 1 or 4");
     EXCEL_CHECK_ARG(!qkvs || vt, "attention: the bf16x3 row pass needs V^T (vt) next to the split q|k|v");
-    RowpassArgs a{qkvh, out, reinterpret_cast<float2*>(stats), B, H, N, scale, split_out, qkvs, flash_nq, vt, vt_kp};
+    RowpassArgs a{qkvh, out, reinterpret_cast<float2*>(stats), B, H, N, scale, split_out, qkvs, flash_nq, vt, vt_kp, 1};
+#ifdef EXCEL_DEV
+    { static const int x = getenv("EXCEL_ROWPASS_XCD") ? atoi(getenv("EXCEL_ROWPASS_XCD")) : 1; a.xcd_local = x; }
+#endif
     hipLaunchKernelGGL(attn_rowpass_kernel, dim3(cdiv(N, 128), B * H, ntypes), dim3(256), 0, st, a);
     EXCEL_CHECK_LAUNCH("attn_rowpass");
     return EXCEL_OK;
