@@ -103,6 +103,8 @@ SIGNATURES = {
     "excel_patch_text_cam_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
     "excel_patch_text_cam": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, C.c_float, c_i, c_f, c_f, c_f, c_f, c_f]),
     "excel_clip_feature_surgery": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, C.c_float, c_f, c_f, c_f, c_f]),
+    "excel_dcrf_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
+    "excel_dcrf_inference": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, c_f, c_f, c_f]),
     "excel_attn_layer_mean": (c_i, [c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f]),
     "excel_trans_mat_workspace_bytes": (c_sz, [c_i, c_i]),
     "excel_compute_trans_mat": (c_i, [c_f, c_i, c_i, c_f, c_f, c_f]),

@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libexcel_hip.so")
-SOURCES = ["gemm.hip", "gemm_bf16x3.hip", "norm.hip", "attn.hip", "attn_strip.hip", "cam.hip", "aff.hip", "par.hip", "attr.hip", "lvc.hip", "decoder.hip", "train.hip", "abi.hip"]
+SOURCES = ["gemm.hip", "gemm_bf16x3.hip", "norm.hip", "attn.hip", "attn_strip.hip", "cam.hip", "aff.hip", "par.hip", "attr.hip", "lvc.hip", "decoder.hip", "train.hip", "crf.hip", "abi.hip"]
 HEADERS = ["common.h", "excel_internal.h", "decoder_internal.h", os.path.join("..", "..", "include", "excel_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
          # fully unroll the big register-tile epilogues (a partially unrolled loop indexes the accumulator array

@@ -739,6 +739,20 @@ def prof_enable(on=True, categories=None, every=1):
     check(lib().excel_prof_enable(1 if on else 0), "excel_prof_enable")
 
 
+def dcrf_inference(image_u8, prob, iters, pos_w, pos_xy_std, bi_w, bi_xy_std, bi_rgb_std, is_energy=False):
+    """image [H,W,3] uint8, prob [C,H,W] f32 (probabilities, or unary energies when is_energy) -> Q [C,H,W] (excel_dcrf_inference)."""
+    prob = f32c(prob)
+    if image_u8.dtype != torch.uint8 or not image_u8.is_contiguous():
+        image_u8 = image_u8.to(torch.uint8).contiguous()
+    Cn, H, W = prob.shape
+    assert tuple(image_u8.shape) == (H, W, 3), (tuple(image_u8.shape), (H, W, 3))
+    out = torch.empty_like(prob)
+    ws = _ws(lib().excel_dcrf_workspace_bytes(H, W, Cn), prob.device)
+    check(lib().excel_dcrf_inference(_p(image_u8, torch.uint8), _p(prob), 1 if is_energy else 0, H, W, Cn, int(iters), float(pos_w), float(pos_xy_std),
+                                     float(bi_w), float(bi_xy_std), float(bi_rgb_std), _p(out), _p(ws, torch.uint8), _stream()), "excel_dcrf_inference")
+    return out
+
+
 def par_set_mode(mode):
     """"recompute" (default): PAR affinities recomputed inside every Jacobi step from the guide image + 5 per-pixel statistics;
     "stream": the 8*ndil affinity planes are streamed from HBM.  Bit-identical outputs (same arithmetic, same order)."""

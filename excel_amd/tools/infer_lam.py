@@ -46,8 +46,9 @@ def get_parser():
     p.add_argument("--data_folder", default=None, type=str, help="VOC2012 root (JPEGImages/, SegmentationClassAug/): real data instead of --synthetic")
     p.add_argument("--list_folder", default=None, type=str, help="directory with <infer_set>.txt and cls_labels_onehot.npy")
     p.add_argument("--u8_input", default=False, type=_bool, help="feed decoded uint8 HWC images and normalise on the device")
-    p.add_argument("--crf_post", default=False, type=_bool, help="write the per-image logits record of tools/infer_lam.py:116-119 (api path)")
+    p.add_argument("--crf_post", default=False, type=_bool, help="write the per-image logits records (:116-119, api path) and run the DenseCRF stage over them (:179-237)")
     p.add_argument("--logits_dir", default="./logits", type=str)
+    p.add_argument("--segs_crf_rgb_dir", default=None, type=str, help="colour-coded CRF label images (tools/infer_lam.py:228); default: not written")
     p.add_argument("--num_classes", default=21, type=int)
     p.add_argument("--ignore_index", default=255, type=int)
     p.add_argument("--local_rank", default=int(os.environ.get("LOCAL_RANK", 0)), type=int)
@@ -199,6 +200,42 @@ def resolve_model_inputs(args):
     return kw
 
 
+def crf_proc(args, rank=0, world=1, device="cuda"):
+    """tools/infer_lam.py:179-237: DenseCRF (iter 10, pos_xy_std 1, pos_w 3, bi_xy_std 67, bi_rgb_std 3, bi_w 4, :191-198) over the logits
+    records of the main loop, label = pad(keys_gt + 1)[argmax] (:225-226), colour-coded PNG (:228), scores against the ground truth
+    (:233).  The reference fans the images out over CPU processes (joblib); here every rank takes names r, r+R, ... through the
+    device-side mean field (excel_dcrf_inference) and the confusion matrices are all-gathered like the main loop's.
+    -> (score dict, summed hist)"""
+    from PIL import Image
+    from ..utils import evaluate, imutils
+    from ..utils.dcrf import DenseCRF
+    from .. import ops
+    with open(os.path.join(args.list_folder, args.infer_set) + ".txt") as f:
+        name_list = [x for x in f.read().split("\n") if x]                                  # :182-184
+    images_path = os.path.join(args.data_folder, "JPEGImages")
+    labels_path = os.path.join(args.data_folder, "SegmentationClassAug")
+    post = DenseCRF(iter_max=10, pos_xy_std=1, pos_w=3, bi_xy_std=67, bi_rgb_std=3, bi_w=4)  # :191-198
+    hist = torch.zeros((args.num_classes, args.num_classes), dtype=torch.int64, device=device)
+    for i in shard_indices(len(name_list), rank, world):
+        name = name_list[i]
+        lams, keys = imutils.load_logits(os.path.join(args.logits_dir, name + ".npy"))      # :203-206
+        image = np.asarray(Image.open(os.path.join(images_path, name + ".jpg")).convert("RGB")).astype(np.uint8)   # :209-210, :220
+        if "test" in args.infer_set:
+            label = image[:, :, 0]                                                          # :213-214
+        else:
+            label = np.array(Image.open(os.path.join(labels_path, name + ".png")))          # :216
+        prob = post(torch.from_numpy(image).to(device), torch.from_numpy(np.asarray(lams, np.float32)).to(device))   # :221
+        pred = prob.argmax(0)                                                               # :222
+        keys_t = torch.from_numpy(np.pad(np.asarray(keys) + 1, (1, 0), mode="constant")).to(device)   # :225
+        pred_crf = keys_t[pred].to(torch.uint8)                                             # :226
+        if getattr(args, "segs_crf_rgb_dir", None):
+            os.makedirs(args.segs_crf_rgb_dir, exist_ok=True)
+            Image.fromarray(imutils.encode_cmap(pred_crf.cpu().numpy())).save(os.path.join(args.segs_crf_rgb_dir, name + ".png"))   # :228
+        hist = ops.confusion_accumulate(torch.from_numpy(np.array(label, dtype=np.uint8)).to(device), pred_crf, args.num_classes, hist)
+    _, total = gather_hists(hist)
+    return evaluate.scores_from_hist(total), total                                          # :233
+
+
 def validate(args=None):
     from ..model.model_excel import ExCEL_model
     from ..utils import evaluate
@@ -231,6 +268,12 @@ def validate(args=None):
         logging.info(f"Training_free:{args.training_free}, LAM_score:")
         logging.info("\n" + format_scores_table(score, VOC_CLASSES))
         logging.info(f"mIoU {score['miou'] * 100:.3f}  images {int(nimg) * world}  ({nimg / secs:.1f} img/s/rank)")
+    if getattr(args, "crf_post", False) and getattr(args, "data_folder", None):             # :173-174
+        crf_score, crf_total = crf_proc(args, rank, world, device)
+        validate.last_crf = (crf_score, crf_total)
+        if rank == 0:
+            logging.info("crf_seg_score:")
+            logging.info("\n" + format_scores_table(crf_score, VOC_CLASSES))
     return score, total
 
 

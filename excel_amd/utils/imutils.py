@@ -7,8 +7,8 @@ records tools/infer_lam.py exchanges with its CRF stage.
   crf_keys_to_labels       tools/infer_lam.py:225-227: keys = pad(keys_gt + 1, (1, 0)); label = keys[argmax]
   save_label_png           the colour-coded label image the reference writes with imageio (:228); PIL here
 
-Plain numpy / PIL on the host: these are file formats, not compute.  DenseCRF itself (utils/dcrf.py, pydensecrf) is not
-rebuilt (third-party CPU library, absent from this image).
+Plain numpy / PIL on the host: these are file formats, not compute.  DenseCRF itself (utils/dcrf.py) is excel_amd/utils/dcrf.py over
+excel_dcrf_inference (crf.hip).
 """
 import os
 

@@ -242,6 +242,18 @@ size_t excel_patch_text_cam_workspace_bytes(int B, int N, int C, int T);
 int excel_patch_text_cam(const float* x_raw, const float* text, int B, int N, int C, int T, int F, float temperature, int mode,
                          float* out_full, float* out_slice, float* image_features, void* workspace, void* stream);
 
+/* ------------------------------------------------------------------ DenseCRF post-processing */
+
+/* utils/dcrf.py:42-68 (class DenseCRF; :7-40 crf_inference / crf_inference_label use the same call with other parameters), driven by
+ * tools/infer_lam.py:179-237: DenseCRF2D(W, H, C) + setUnaryEnergy + addPairwiseGaussian(sxy = pos_xy_std, compat = pos_w) +
+ * addPairwiseBilateral(sxy = bi_xy_std, srgb = bi_rgb_std, rgbim, compat = bi_w) + inference(iters) of pydensecrf (DIAG kernels,
+ * symmetric normalisation, Potts compatibilities): mean-field inference with permutohedral-lattice message passing, all on the device.
+ *   rgb_hwc [H,W,3] uint8, prob [C,H,W]: probabilities (prob_is_energy = 0: unary = -log(clip(p, 1e-5, 1)), pydensecrf's
+ *   unary_from_softmax) or the unary energies themselves (prob_is_energy = 1, e.g. unary_from_labels)  ->  q_out [C,H,W]. */
+size_t excel_dcrf_workspace_bytes(int H, int W, int C);
+int excel_dcrf_inference(const unsigned char* rgb_hwc, const float* prob, int prob_is_energy, int H, int W, int C, int iters, float pos_w,
+                         float pos_xy_std, float bi_w, float bi_xy_std, float bi_rgb_std, float* q_out, void* workspace, void* stream);
+
 /* ------------------------------------------------------------------ affinity random walk */
 
 /* mean over layers of attn[l, 1:, 1:] for one stacked tensor [Lw,B,N,N] -> [B,P,P] (utils/affutils.py:180,197). */

@@ -21,6 +21,11 @@ Pinning status (see DESIGN.md "Oracle"):
     from /root/reference and from this image (version unpinned upstream,
     requirements.txt does not list it).  Their published semantics are
     restated in oracle/aff.py and covered by hand-made known-answer cases.
+  * PARITY UNPINNED for the DenseCRF stage (oracle/dcrf.py): pydensecrf (conda pin
+    1.0rc3, requirements.txt:4) is third-party, absent from /root/reference and
+    from this image, and the reference holds no vector for it; the published
+    mean-field / permutohedral-lattice algorithm is restated and covered by
+    property tests (constant preservation, symmetry, partition of unity).
 """
 
-from . import interp, vit, cam, attr, aff, par, evaluate, pipeline, decoder, text  # noqa: F401
+from . import interp, vit, cam, attr, aff, par, evaluate, pipeline, decoder, text, dcrf  # noqa: F401

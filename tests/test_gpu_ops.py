@@ -448,6 +448,41 @@ def test_par_recompute_equals_streamed_affinities(ops, B, C, H, W, dil, it):
     assert maxabs(host(got)[0, :int(host(nchan)[0])], lo[0]) < 2e-4
 
 
+@pytest.mark.parametrize("H,W,C,params", [(24, 30, 3, (10, 3, 1, 4, 67, 3)), (37, 29, 5, (5, 3, 3, 10, 80, 13)), (50, 64, 2, (10, 3, 1, 4, 67, 3))])
+def test_dcrf_vs_oracle(ops, H, W, C, params):
+    """excel_dcrf_inference (utils/dcrf.py:42-68 with the parameter sets of tools/infer_lam.py:191-198 and utils/dcrf.py:20-21) against
+    the numpy restatement of the published mean-field / permutohedral-lattice algorithm; marginals within 2e-4, labels equal except
+    where the two top marginals tie."""
+    rs = np.random.RandomState(H + C)
+    img = (rs.rand(H, W, 3) * 255).astype(np.uint8)
+    img[:, : W // 2] = (img[:, : W // 2] * 0.15 + 140).astype(np.uint8)           # a smooth half and a noisy half
+    p = rs.rand(C, H, W).astype(np.float32) ** 2 + 1e-3
+    p /= p.sum(0, keepdims=True)
+    ref = oracle.dcrf.dense_crf_2d(img, oracle.dcrf.unary_from_softmax(p), *params)
+    got = host(ops.dcrf_inference(dev(img, torch.uint8), dev(p), *params))
+    assert maxabs(got, ref) < 1e-3 and float(np.abs(got - ref).mean()) < 2e-5      # ten softmax iterations amplify fp32 round-off at a few pixels
+    np.testing.assert_allclose(got.sum(0), 1.0, atol=1e-5)
+    top2 = np.sort(ref, 0)[-2:]
+    clear = (top2[1] - top2[0]) > 1e-3
+    assert np.array_equal(got.argmax(0)[clear], ref.argmax(0)[clear])
+    again = host(ops.dcrf_inference(dev(img, torch.uint8), dev(p), *params))
+    assert np.array_equal(got, again)                                             # fixed-point splat: bit-reproducible
+
+
+def test_dcrf_mirror_api(ops):
+    """excel_amd.utils.dcrf keeps the reference module's surface (DenseCRF class, crf_inference, crf_inference_label) on numpy inputs."""
+    from excel_amd.utils import dcrf
+    rs = np.random.RandomState(2)
+    H, W = 30, 41
+    img = (rs.rand(H, W, 3) * 255).astype(np.uint8)
+    p = rs.rand(4, H, W).astype(np.float32)
+    q = dcrf.DenseCRF(iter_max=10, pos_w=3, pos_xy_std=1, bi_w=4, bi_xy_std=67, bi_rgb_std=3)(img, p)      # un-normalised "probabilities" like valid_lam
+    assert isinstance(q, np.ndarray) and maxabs(q, oracle.dcrf.DenseCRF(10, 3, 1, 4, 67, 3)(img, p)) < 1e-3
+    assert maxabs(dcrf.crf_inference(img, p / p.sum(0), t=3), oracle.dcrf.crf_inference(img, p / p.sum(0), t=3)) < 1e-3
+    lab = rs.randint(0, 4, (H, W))
+    assert np.mean(dcrf.crf_inference_label(img, lab, t=3, n_labels=4) == oracle.dcrf.crf_inference_label(img, lab, t=3, n_labels=4)) > 0.995
+
+
 def test_confusion_unaligned_slices(ops):
     """gt / pred views that do not start on a 16-byte boundary (labels_u8[i], gts[lo:hi] of an odd-sized image): same
     misalignment -> scalar head + vector body; different misalignment -> scalar path.  Both equal fast_hist."""

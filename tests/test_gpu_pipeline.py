@@ -806,10 +806,20 @@ def test_infer_lam_on_disk_voc(gpu, tmp_path):
         assert maxabs(host(model.integral_text_features)[i], oracle.text.prompt_ensemble(e)) < 1e-4
     assert int(host(total).sum()) == npix and 0.0 <= score["miou"] <= 1.0
     score2, total2 = infer_lam.validate(infer_lam.get_parser().parse_args(common + ["--api_path", "true", "--crf_post", "true",
-                                                                               "--logits_dir", str(tmp_path / "logits")]))
+                                                                               "--logits_dir", str(tmp_path / "logits"),
+                                                                               "--segs_crf_rgb_dir", str(tmp_path / "crf_rgb")]))
     assert np.abs(host(total) - host(total2)).sum() <= 1e-3 * npix
     lam, keys = imutils.load_logits(str(tmp_path / "logits" / (ids[2] + ".npy")))
     assert lam.shape == (3, 110, 104) and list(keys) == [2, 11]
+    # the DenseCRF stage (tools/infer_lam.py:179-237) ran over the records: its histogram covers the same pixels, the colour-coded
+    # label images exist, and image 2's CRF labels are the oracle's (numpy restatement of the published algorithm)
+    crf_score, crf_total = infer_lam.validate.last_crf
+    assert int(host(crf_total).sum()) == npix and 0.0 <= crf_score["miou"] <= 1.0
+    rgb_png = np.asarray(Image.open(tmp_path / "crf_rgb" / (ids[2] + ".png")).convert("RGB"))
+    img2 = np.asarray(Image.open(root / "JPEGImages" / (ids[2] + ".jpg")).convert("RGB")).astype(np.uint8)
+    q = oracle.dcrf.DenseCRF(10, 3, 1, 4, 67, 3)(img2, lam)
+    ref_lab = np.pad(np.asarray(keys) + 1, (1, 0), mode="constant")[q.argmax(0)]
+    assert np.mean(np.all(rgb_png == imutils.encode_cmap(ref_lab), axis=-1)) > 0.995
 
 
 @pytest.mark.parametrize("gemm_mode,min_agree", [("f32", 0.9995), ("bf16x3", 0.998)])   # bf16x3: a few boundary pixels of a ~2.5k-pixel map, through a net that amplifies round-off ~300x
@@ -848,3 +858,38 @@ def test_random_shapes_soak_vs_oracle(gpu, case, gemm_mode, min_agree):
         assert float(np.mean(lab[b] == r)) >= min_agree
         ref_hist += oracle.evaluate.fast_hist(gts[b].flatten(), lab[b].flatten(), F_ + 1)
     assert np.array_equal(host(pipe.hist), ref_hist)
+
+
+def test_soak_aggregate_label_agreement_bf16x3(gpu):
+    """The default (bf16x3) mode against the fp32 oracle over a whole soak set, pixel-weighted: >= 99.95 % (tools_dev/parity_stages.py over
+    60 cases / 0.92 M pixels measures 99.993 % against the exact-fp32 mode with NO differing box mask; the per-image minimum is 99.86 %
+    on a 1.6 k-pixel map, i.e. 2 arg-max ties - which is why the per-image gate of the soak test is 99.8 % and this one is tighter)."""
+    from excel_amd.model import ExCEL_model
+    from excel_amd.pipeline import TrainingFreePipeline
+    par = oracle.par.PAR([1, 2, 4, 8, 12, 24], 20)
+    bad = px = 0
+    for case in range(100, 110):
+        rs = np.random.RandomState(2000 + case)
+        S = int(rs.choice([64, 96, 128]))
+        B = int(rs.randint(1, 4))
+        F_ = int(rs.randint(2, 6))
+        T = F_ + int(rs.randint(1, 5))
+        H, W = int(rs.randint(40, 120)), int(rs.randint(40, 120))
+        w = make_vit_weights(TINY, seed=int(rs.randint(0, 100)))
+        text = rs.standard_normal((T, 64)).astype(np.float32)
+        text /= np.linalg.norm(text, axis=1, keepdims=True)
+        model = ExCEL_model(clip_model="tiny", num_classes=F_ + 1, img_size=S, mode="train", state_dict=w, vit_cfg=TINY_KW, text_attr=text.T.copy(),
+                            gemm_mode="bf16x3")
+        wo = oracle.vit.reload_self_attn(w, TINY, S // 16, "train")
+        imgs = rs.standard_normal((B, 3, S, S)).astype(np.float32)
+        gts = rs.randint(0, F_ + 1, (B, H, W)).astype(np.uint8)
+        cls = np.zeros((B, F_), np.float32)
+        for b in range(B):
+            cls[b, rs.choice(F_, size=int(rs.randint(1, min(F_, 3) + 1)), replace=False)] = 1
+        pipe = TrainingFreePipeline(model, num_classes=F_ + 1, smax=int(cls.sum(1).max()))
+        lab = host(pipe.run_batch(dev(imgs), dev(cls), dev(gts)))
+        for b in range(B):
+            r = oracle.pipeline.run_sample(imgs[b], cls[b], (H, W), wo, TINY, text.T.copy(), F_, par, S)
+            bad += int((lab[b] != r).sum())
+            px += r.size
+    assert 1.0 - bad / px >= 0.9995, (bad, px)

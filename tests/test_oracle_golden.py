@@ -207,3 +207,36 @@ def test_torch_cpu_port_matches_numpy_oracle():
     h2, p2, stage = torch_cpu.build_validation(iter(samples), w, cfg, text.T.copy(), num_classes=5, resize_size=96)
     assert np.array_equal(h1, h2) and all(np.array_equal(a, b) for a, b in zip(p1, p2))
     assert set(stage) == {"vit", "cam", "aff_random_walk", "upsample_par_argmax", "score"}
+
+
+def test_dcrf_oracle_properties():
+    """oracle/dcrf.py restates the published permutohedral-lattice mean field (no pydensecrf here: parity unpinned): barycentric weights
+    are a partition of unity, the lattice filter is linear and nearly self-adjoint, marginals stay normalised, a strong Potts
+    term smooths an isolated outlier, and zero iterations is softmax(-U)."""
+    from oracle import dcrf
+    rs = np.random.RandomState(0)
+    H, W, C = 20, 26, 3
+    img = (rs.rand(H, W, 3) * 40 + 100).astype(np.uint8)
+    lat = dcrf.Permutohedral(dcrf.features_2d(H, W, 67, img, 3))
+    np.testing.assert_allclose(lat.bary.sum(1), 1.0, atol=2e-5)
+    assert lat.bary.min() > -1e-5 and lat.offset.max() == lat.M - 1
+    a, b = rs.rand(H * W, 2).astype(np.float32), rs.rand(H * W, 2).astype(np.float32)
+    # (near-)symmetry: the transpose of the filter applies the blur passes in reverse order, which differs only where a neighbour is absent
+    assert abs(float((a * lat.compute(b)).sum()) - float((lat.compute(a) * b).sum())) < 1e-2 * float((a * lat.compute(b)).sum())
+    np.testing.assert_allclose(lat.compute(2 * a + b), 2 * lat.compute(a) + lat.compute(b), rtol=1e-4, atol=1e-5)
+    p = rs.rand(C, H, W).astype(np.float32)
+    p /= p.sum(0, keepdims=True)
+    crf = dcrf.DenseCRF(iter_max=10, pos_w=3, pos_xy_std=1, bi_w=4, bi_xy_std=67, bi_rgb_std=3)     # tools/infer_lam.py:191-198
+    Q = crf(img, p)
+    np.testing.assert_allclose(Q.sum(0), 1.0, atol=1e-5)
+    Q0 = dcrf.dense_crf_2d(img, dcrf.unary_from_softmax(p), 0, 3, 1, 4, 67, 3)
+    np.testing.assert_allclose(Q0, p / p.sum(0, keepdims=True), atol=1e-5)        # softmax(log p) = p
+    # one confident outlier inside a uniform, uniformly coloured region is absorbed by its neighbours
+    flat = np.full((H, W, 3), 128, np.uint8)
+    pp = np.zeros((2, H, W), np.float32)
+    pp[0] = 0.7
+    pp[1] = 0.3
+    pp[:, 10, 13] = (0.3, 0.7)
+    assert dcrf.DenseCRF(10, 3, 1, 4, 67, 3)(flat, pp).argmax(0)[10, 13] == 0
+    lab = dcrf.crf_inference_label(flat, rs.randint(0, 3, (H, W)), t=2, n_labels=3)
+    assert lab.shape == (H, W)
