@@ -37,6 +37,7 @@ struct StripArgs {
     float ex_scale;       // = H
     int aff_init;         // 1: w_aff = ..., 0: w_aff += ...
     int surgery;          // 1: sweep A + sweep W, 0: sweep W only
+    int split_c;          // > 0: the two sweeps of a strip are separate workgroups, split_c strips per XCD (see the launcher)
 };
 
 template <int NTW, int DBG>
@@ -52,7 +53,19 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
     const int r = lane & 31, kh = lane >> 5;
     const int N = p.N, H = p.H;
 
-    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    // `part`: 0 = this workgroup runs every sweep the launch asks for, 1 = sweep A only, 2 = sweep W only.  Split launch: XCD x owns
+    // strips [x c, (x+1) c); its first c workgroups (dispatched first) are the long A sweeps (3H phases), the next c the short W
+    // sweeps (H phases) of the same strips - longest-first, so the tail of the last round is H phases long instead of 4H.
+    int id, part = 0;
+    if (p.split_c > 0) {
+        const int x = blockIdx.x & 7, loc = blockIdx.x >> 3;
+        const int second = loc >= p.split_c ? 1 : 0;
+        id = x * p.split_c + loc - second * p.split_c;
+        part = 1 + second;
+        if (id >= p.B * p.nstrips) return;                            // padding of the last XCD's chunk (whole workgroup, before any barrier)
+    } else {
+        id = xcd_remap(blockIdx.x, gridDim.x);
+    }
     const int b = id / p.nstrips, strip = id - b * p.nstrips;
     const int q0 = strip * 32;
 
@@ -284,7 +297,7 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
 
-    if (p.surgery) {
+    if (p.surgery && part != 2) {
         run_sweep(0, 3 * H);
         // A_sum: split-bf16 rows; one 32-key tile = one 128-B block [hi 32 | lo 32]
 #pragma unroll
@@ -324,7 +337,7 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
         }
     }
 
-    if (p.w_aff || p.attn_out) {
+    if ((p.w_aff || p.attn_out) && part != 1) {
         run_sweep(3 * H, 4 * H);
         const long long P = N - 1;
 #pragma unroll
@@ -365,8 +378,13 @@ int excel_launch_attn_strip(const unsigned short* qkvs, unsigned short* a_sum, f
     const int nw = cdiv(ntiles, ntw);                          // 25 tiles: 7 waves x (4,4,4,4,3,3,3)
     EXCEL_CHECK_ARG(ntiles / nw >= ntw - 1 && (long long)3 * H * N * 256 < (1LL << 31), "attn_strip: unsupported shape");
     StripArgs a{qkvs, a_sum, w_aff, attn_out, surgery ? ex_attn : nullptr, B, H, N, KP, ntiles, cdiv(N, 32), scale, w_scale, aff_scale, (float)H,
-                aff_init, surgery};
-    const dim3 grid(B * a.nstrips), block(nw * 64);
+                aff_init, surgery, 0};
+    // Both sweeps wanted: one workgroup per (strip, sweep).  A strip workgroup fills a CU (148 KB LDS), so B x nstrips = 800 uniform
+    // workgroups on 256 CUs are 3.125 rounds = 4 rounds of 4H phases; split, the 3H-phase workgroups go first and the H-phase ones
+    // level the tail: 150-156 phase-times per CU instead of 192.
+    const bool split = surgery && (w_aff || attn_out);
+    if (split) a.split_c = cdiv(B * a.nstrips, 8);
+    const dim3 grid(split ? 8 * 2 * a.split_c : B * a.nstrips), block(nw * 64);
 #ifdef EXCEL_DEV
     // dev build only: ablation variants (bit0 no MFMA, bit1 no DMA in the loop, bit2 no softmax, bit3 no schedule groups)
     static const int dbg = getenv("EXCEL_STRIP_DBG") ? atoi(getenv("EXCEL_STRIP_DBG")) : 0;
