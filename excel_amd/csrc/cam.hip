@@ -110,42 +110,66 @@ struct PtcArgs {
     float temp;
 };
 
-template <bool BF, int CT>
-__global__ __launch_bounds__(512) void patch_text_cam_kernel(PtcArgs p) {
+// NT threads per workgroup: 1024 where the register budget of 16 waves allows it (<= 2 class tiles), 512 otherwise.  The workgroup is
+// latency-bound (one CU streams its image's [N, C] slab twice), so the wave count is its throughput.
+template <bool BF, int CT, int NT>
+__global__ __launch_bounds__(NT) void patch_text_cam_kernel(PtcArgs p) {
+    constexpr int NW = NT / 64;
     __shared__ float inv[1024];                    // 1 / ||x[:, c]||_2 over the tokens
     __shared__ float w[PTC_MAXCT * 32];            // class-prior weights (0 for padded classes)
-    __shared__ float red_mn[8][PTC_MAXCT * 32], red_mx[8][PTC_MAXCT * 32];
+    __shared__ float red_mn[NW][PTC_MAXCT * 32], red_mx[NW][PTC_MAXCT * 32];
+    __shared__ float part[16 * 512];               // [residue n % 16][column] partial sums of squares (columns in chunks of <= 512)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, kh = lane >> 5;
     const int N = p.N, C = p.C, T = p.T;
     const float* X = p.x_raw + (long long)b * N * C;
 
-    // ---- column norms over the token axis, fixed summation order: 16 interleaved partial sums per column (16 independent row
-    // loads in flight: the loop is latency-bound), combined pairwise
-    for (int c = tid; c < C; c += 512) {
-        float s16[16];
+    // ---- column norms over the token axis, fixed summation order: 16 partial sums per column (rows n = j mod 16, increasing n),
+    // combined pairwise.  The 16 residues of a column are spread over G = NT / columns threads (more row loads in flight: the loop
+    // is latency-bound); the partials meet in LDS and the pairwise tree is the same whatever G is.
+    for (int c0 = 0; c0 < C; c0 += 512) {
+        const int cw = min(512, C - c0);
+        int G = 1;
+        while (G < 16 && 2 * G * cw <= NT) G *= 2;
+        const int per = 16 / G;                                   // residues per thread
+        if (tid < G * cw) {
+            const int g = tid / cw, c = c0 + tid - g * cw;
+            float s16[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) s16[j] = 0.f;
-        int n = 0;
-        for (; n + 16 <= N; n += 16) {
-            float v[16];
+            for (int j = 0; j < 16; ++j) s16[j] = 0.f;
+            for (int n0 = 0; n0 < N; n0 += 16) {
+                float v[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = X[(long long)(n + j) * C + c];
+                for (int jj = 0; jj < 16; ++jj) {
+                    const int n = n0 + g * per + jj;
+                    v[jj] = (jj < per && n < N) ? X[(long long)n * C + c] : 0.f;
+                }
 #pragma unroll
-            for (int j = 0; j < 16; ++j) s16[j] = fmaf(v[j], v[j], s16[j]);
+                for (int jj = 0; jj < 16; ++jj)
+                    if (jj < per && n0 + g * per + jj < N) s16[jj] = fmaf(v[jj], v[jj], s16[jj]);
+            }
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj)
+                if (jj < per) part[(g * per + jj) * 512 + (c - c0)] = s16[jj];
         }
-        for (int j = 0; n < N; ++n, ++j) { const float v = X[(long long)n * C + c]; s16[j] = fmaf(v, v, s16[j]); }
+        __syncthreads();
+        if (tid < cw) {
+            float s16[16];
 #pragma unroll
-        for (int st = 8; st > 0; st >>= 1)
+            for (int j = 0; j < 16; ++j) s16[j] = part[j * 512 + tid];
 #pragma unroll
-            for (int j = 0; j < st; ++j) s16[j] += s16[j + st];
-        inv[c] = 1.f / sqrtf(s16[0]);
+            for (int st = 8; st > 0; st >>= 1)
+#pragma unroll
+                for (int j = 0; j < st; ++j) s16[j] += s16[j + st];
+            inv[c0 + tid] = 1.f / sqrtf(s16[0]);
+        }
+        __syncthreads();
     }
     __syncthreads();
     if (p.feats) {
         float* Fo = p.feats + (long long)b * N * C;
-        for (long long i = (long long)tid * 4; i < (long long)N * C; i += 512 * 4) {
+        for (long long i = (long long)tid * 4; i < (long long)N * C; i += NT * 4) {
             const int c = (int)(i % C);
             f32x4 v = *reinterpret_cast<const f32x4*>(X + i);
             v[0] *= inv[c]; v[1] *= inv[c + 1]; v[2] *= inv[c + 2]; v[3] *= inv[c + 3];
@@ -156,7 +180,7 @@ __global__ __launch_bounds__(512) void patch_text_cam_kernel(PtcArgs p) {
     float* simb = p.sim + (long long)b * N * p.ldT;
     const int ntile = (N + 31) / 32;
     bool first = true;
-    for (int tile = wave; tile < ntile || first; tile += 8) {
+    for (int tile = wave; tile < ntile || first; tile += NW) {
         const bool live = tile < ntile;                       // every wave takes part in the barrier of its first round
         const int n = min(tile * 32 + r, N - 1);              // token of this lane column (clamped; masked at the end)
         f32x16 acc[CT];
@@ -280,7 +304,7 @@ __global__ __launch_bounds__(512) void patch_text_cam_kernel(PtcArgs p) {
     // ---- per-class min / max over all tokens (one wave per token row, lanes over the classes; the [N,T] slab is L2/L1 resident)
     {
         float mn0 = INFINITY, mn1 = INFINITY, mx0 = -INFINITY, mx1 = -INFINITY;
-        for (int n = wave; n < N; n += 8) {
+        for (int n = wave; n < N; n += NW) {
             const float* row = simb + (long long)n * p.ldT;
             if (lane < T) { const float v = row[lane]; mn0 = fminf(mn0, v); mx0 = fmaxf(mx0, v); }
             if (lane + 64 < T) { const float v = row[lane + 64]; mn1 = fminf(mn1, v); mx1 = fmaxf(mx1, v); }
@@ -291,13 +315,13 @@ __global__ __launch_bounds__(512) void patch_text_cam_kernel(PtcArgs p) {
     __syncthreads();
     if (tid < PTC_MAXCT * 32) {
         float a = red_mn[0][tid], c = red_mx[0][tid];
-        for (int i = 1; i < 8; ++i) { a = fminf(a, red_mn[i][tid]); c = fmaxf(c, red_mx[i][tid]); }
+        for (int i = 1; i < NW; ++i) { a = fminf(a, red_mn[i][tid]); c = fmaxf(c, red_mx[i][tid]); }
         red_mn[0][tid] = a;
         red_mx[0][tid] = c - a;
     }
     __syncthreads();
     // ---- attr = (sim - min) / (max - min)   (clip.py:308; NaN when max == min, like the reference)
-    for (long long i = tid; i < (long long)N * T; i += 512) {
+    for (long long i = tid; i < (long long)N * T; i += NT) {
         const int n = (int)(i / T), t = (int)(i - (long long)n * T);
         const float v = (simb[(long long)n * p.ldT + t] - red_mn[0][t]) / red_mx[0][t];
         if (p.out_full) p.out_full[((long long)b * N + n) * T + t] = v;
@@ -313,9 +337,9 @@ int excel_launch_patch_text_cam(const float* x_raw, const float* text, const uns
     EXCEL_CHECK_ARG(!bf || text_split, "patch_text_cam: bf16x3 mode needs the split text");
     PtcArgs a{x_raw, text, text_split, sim_ws, out_full, out_slice, feats, N, C, T, F, ldT, temp};
     const int ct = cdiv(T, 32);
-#define PTC_LAUNCH(BFV, CTV) hipLaunchKernelGGL((patch_text_cam_kernel<BFV, CTV>), dim3(B), dim3(512), 0, st, a)
-    if (bf) { if (ct <= 1) PTC_LAUNCH(true, 1); else if (ct == 2) PTC_LAUNCH(true, 2); else PTC_LAUNCH(true, 4); }
-    else { if (ct <= 1) PTC_LAUNCH(false, 1); else if (ct == 2) PTC_LAUNCH(false, 2); else PTC_LAUNCH(false, 4); }
+#define PTC_LAUNCH(BFV, CTV, NTV) hipLaunchKernelGGL((patch_text_cam_kernel<BFV, CTV, NTV>), dim3(B), dim3(NTV), 0, st, a)
+    if (bf) { if (ct <= 1) PTC_LAUNCH(true, 1, 1024); else if (ct == 2) PTC_LAUNCH(true, 2, 1024); else PTC_LAUNCH(true, 4, 512); }
+    else { if (ct <= 1) PTC_LAUNCH(false, 1, 1024); else if (ct == 2) PTC_LAUNCH(false, 2, 1024); else PTC_LAUNCH(false, 4, 512); }
 #undef PTC_LAUNCH
     EXCEL_CHECK_LAUNCH("patch_text_cam");
     return EXCEL_OK;

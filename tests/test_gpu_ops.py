@@ -257,29 +257,30 @@ def _smooth_maps(rs, B, g, F):
     return out
 
 
-KNOWN = {
-    # name: (map rows as strings, expected mask rows)  -- threshold 0.5 on maps holding 0 / 1 values
-    "single_pixel_centre": (["00000", "00000", "00100", "00000", "00000"], ["00000", "00000", "00100", "00000", "00000"]),
-    "border_box_loses_last_col_row": (["00000", "00000", "00011", "00011", "00011"], ["00000", "00000", "00010", "00010", "00000"]),
-    "corner_pixel_vanishes": (["00000", "00000", "00000", "00000", "00001"], ["00000", "00000", "00000", "00000", "00000"]),
-    "hole_filled_by_box": (["11100", "10100", "11100", "00000", "00000"], ["11100", "11100", "11100", "00000", "00000"]),
-    "diagonal_touch_is_one_component": (["10000", "01000", "00000", "00000", "00000"], ["11000", "11000", "00000", "00000", "00000"]),
-    "two_separate_blobs": (["10000", "00000", "00100", "00000", "00000"], ["10000", "00000", "00100", "00000", "00000"]),
-    "all_zero": (["00000", "00000", "00000", "00000", "00000"], ["00000", "00000", "00000", "00000", "00000"]),
-}
+from _known_boxes import GRADED, KNOWN  # noqa: E402
+
+
+def _check_box_case(ops, m, thr, e):
+    g = m.shape[0]
+    assert m.shape == (g, g)
+    assert np.array_equal(oracle.aff.box_mask(m, thr).astype(np.uint8), e), "oracle known-answer"
+    attr = dev(m.reshape(1, g * g, 1))
+    idx, n = ops.cls_compact(dev(np.ones((1, 1), np.float32)), 2)
+    v, mask = ops.scoremap_box_mask(attr, idx, n, g, thr, want_mask=True)
+    assert np.array_equal(host(mask)[0, 0].reshape(g, g), e)
+    assert np.array_equal(host(v)[0, 0].reshape(g, g), m * e)
 
 
 @pytest.mark.parametrize("name", sorted(KNOWN))
 def test_box_mask_known_answers(ops, name):
     rows, exp = KNOWN[name]
-    m = np.array([[float(c) for c in r] for r in rows], np.float32)
-    e = np.array([[int(c) for c in r] for r in exp], np.uint8)
-    assert np.array_equal(oracle.aff.box_mask(m, 0.5).astype(np.uint8), e), "oracle known-answer"
-    attr = dev(m.reshape(1, 25, 1))
-    idx, n = ops.cls_compact(dev(np.ones((1, 1), np.float32)), 2)
-    v, mask = ops.scoremap_box_mask(attr, idx, n, 5, 0.5, want_mask=True)
-    assert np.array_equal(host(mask)[0, 0].reshape(5, 5), e)
-    assert np.array_equal(host(v)[0, 0].reshape(5, 5), m * e)
+    _check_box_case(ops, np.array([[float(c) for c in r] for r in rows], np.float32), 0.5, np.array([[int(c) for c in r] for r in exp], np.uint8))
+
+
+@pytest.mark.parametrize("name", sorted(GRADED))
+def test_box_mask_graded_known_answers(ops, name):
+    vals, thr, exp = GRADED[name]
+    _check_box_case(ops, np.array(vals, np.float32), thr, np.array([[int(c) for c in r] for r in exp], np.uint8))
 
 
 @pytest.mark.parametrize("g", [6, 28, 32])

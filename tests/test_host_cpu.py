@@ -94,14 +94,7 @@ def test_scores_from_hist_matches_oracle_and_table():
     assert "aeroplane" in tab and "average_metrics" in tab and "iou" in tab.splitlines()[1]
 
 
-KNOWN = {
-    "single_pixel_centre": (["00000", "00000", "00100", "00000", "00000"], ["00000", "00000", "00100", "00000", "00000"]),
-    "border_box_loses_last_col_row": (["00000", "00000", "00011", "00011", "00011"], ["00000", "00000", "00010", "00010", "00000"]),
-    "corner_pixel_vanishes": (["00000", "00000", "00000", "00000", "00001"], ["00000", "00000", "00000", "00000", "00000"]),
-    "hole_filled_by_box": (["11100", "10100", "11100", "00000", "00000"], ["11100", "11100", "11100", "00000", "00000"]),
-    "diagonal_touch_is_one_component": (["10000", "01000", "00000", "00000", "00000"], ["11000", "11000", "00000", "00000", "00000"]),
-    "all_zero": (["00000", "00000", "00000", "00000", "00000"], ["00000", "00000", "00000", "00000", "00000"]),
-}
+from _known_boxes import GRADED, KNOWN  # noqa: E402
 
 
 @pytest.mark.parametrize("name", sorted(KNOWN))
@@ -112,6 +105,13 @@ def test_oracle_box_mask_known_answers(name):
     m = np.array([[float(c) for c in r] for r in rows], np.float32)
     e = np.array([[int(c) for c in r] for r in exp], np.float32)
     assert np.array_equal(oracle.aff.box_mask(m, 0.5), e)
+
+
+@pytest.mark.parametrize("name", sorted(GRADED))
+def test_oracle_box_mask_graded_known_answers(name):
+    vals, thr, exp = GRADED[name]
+    e = np.array([[int(c) for c in r] for r in exp], np.float32)
+    assert np.array_equal(oracle.aff.box_mask(np.array(vals, np.float32), thr), e)
 
 
 def test_oracle_scoremap2bbox_threshold_rule():
