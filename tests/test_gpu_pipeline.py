@@ -33,6 +33,15 @@ def gpu():
     return True
 
 
+def _label_budget(pixels, gemm_mode):
+    """Label pixels allowed to differ from the fp32 reference: the north-star's 99.9 % for the default bf16x3 mode with a 5-pixel floor
+    (one arg-max tie is 0.17 % of a 600-pixel map; the worst soak case is 4 boundary pixels of a 2 508-pixel map upsampled from a 6x6
+    grid, through a random net that amplifies round-off ~300x), 99.95 % / 1 pixel for the exact-fp32 mode (measured: 0 everywhere)."""
+    if gemm_mode == "f32":
+        return max(1, int(0.0005 * pixels))
+    return max(5, int(np.ceil(0.001 * pixels)))
+
+
 def tiny_model(text_attr, seed=11, img_size=96, mode="train", num_classes=5, gemm_mode=None):
     from excel_amd.model import ExCEL_model
     w = make_vit_weights(TINY, seed=seed)
@@ -71,13 +80,13 @@ def test_api_path_matches_golden_trace(gpu, golden, gemm_mode, tol):
         labels, cams = refine_cams_with_bkg_weclip(refined, inputs[0], cls_lst, par, (H, W))
         assert tuple(labels.shape) == (1, H, W) and labels.dtype == torch.int64
         assert maxabs(host(cams), g[f"s{i}_cams"]) < 1e-3
-        agree = float(np.mean(host(labels)[0] == g[f"s{i}_label"]))
-        assert agree >= (0.999 if gemm_mode == "f32" else 0.998), agree
+        mism = int((host(labels)[0] != g[f"s{i}_label"]).sum())
+        assert mism <= _label_budget(H * W, gemm_mode), (mism, H * W)
         preds.append(host(labels)[0].astype(np.int16))
         gts.append(g[f"s{i}_gt"].astype(np.int16))
     sc = evaluate.scores(gts, preds, num_classes=5)
     hist = evaluate.hist_from_labels(gts, preds, 5)
-    assert np.abs(host(hist) - g["hist"]).sum() <= (8 if gemm_mode == "f32" else 60)
+    assert np.abs(host(hist) - g["hist"]).sum() <= (2 if gemm_mode == "f32" else 8)      # measured: 0 / 2 (one pixel of 18 k)
     assert abs(sc["miou"] - float(g["miou"])) < (2e-3 if gemm_mode == "f32" else 5e-3)
 
 
@@ -822,11 +831,11 @@ def test_infer_lam_on_disk_voc(gpu, tmp_path):
     assert np.mean(np.all(rgb_png == imutils.encode_cmap(ref_lab), axis=-1)) > 0.995
 
 
-@pytest.mark.parametrize("gemm_mode,min_agree", [("f32", 0.9995), ("bf16x3", 0.998)])   # bf16x3: a few boundary pixels of a ~2.5k-pixel map, through a net that amplifies round-off ~300x
+@pytest.mark.parametrize("gemm_mode", ["f32", "bf16x3"])
 @pytest.mark.parametrize("case", range(6))
-def test_random_shapes_soak_vs_oracle(gpu, case, gemm_mode, min_agree):
+def test_random_shapes_soak_vs_oracle(gpu, case, gemm_mode):
     """Random network size / batch / class set / label size / caa threshold through the batched pipeline, both matrix-core modes:
-    labels agree with the oracle (>= 99.9 %, the north-star bar; exact mode is at 100 %) and the device histogram equals fast_hist
+    labels agree with the oracle (_label_budget: 99.9 % in the default mode, the north-star bar; exact mode 99.95 %) and the device histogram equals fast_hist
     of those labels (tools_dev/soak.py runs more cases)."""
     from excel_amd.model import ExCEL_model
     from excel_amd.pipeline import TrainingFreePipeline
@@ -855,7 +864,7 @@ def test_random_shapes_soak_vs_oracle(gpu, case, gemm_mode, min_agree):
     ref_hist = np.zeros((F_ + 1, F_ + 1), np.int64)
     for b in range(B):
         r = oracle.pipeline.run_sample(imgs[b], cls[b], (H, W), wo, TINY, text.T.copy(), F_, par, S, caa_thre=thr)
-        assert float(np.mean(lab[b] == r)) >= min_agree
+        assert int((lab[b] != r).sum()) <= _label_budget(r.size, gemm_mode), (int((lab[b] != r).sum()), r.size)
         ref_hist += oracle.evaluate.fast_hist(gts[b].flatten(), lab[b].flatten(), F_ + 1)
     assert np.array_equal(host(pipe.hist), ref_hist)
 
@@ -863,7 +872,7 @@ def test_random_shapes_soak_vs_oracle(gpu, case, gemm_mode, min_agree):
 def test_soak_aggregate_label_agreement_bf16x3(gpu):
     """The default (bf16x3) mode against the fp32 oracle over a whole soak set, pixel-weighted: >= 99.95 % (tools_dev/parity_stages.py over
     60 cases / 0.92 M pixels measures 99.993 % against the exact-fp32 mode with NO differing box mask; the per-image minimum is 99.86 %
-    on a 1.6 k-pixel map, i.e. 2 arg-max ties - which is why the per-image gate of the soak test is 99.8 % and this one is tighter)."""
+    on a 1.6 k-pixel map, i.e. 2 arg-max ties - which is why the per-image budget of the soak test has a 5-pixel floor and this one is tighter)."""
     from excel_amd.model import ExCEL_model
     from excel_amd.pipeline import TrainingFreePipeline
     par = oracle.par.PAR([1, 2, 4, 8, 12, 24], 20)
