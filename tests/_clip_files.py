@@ -48,3 +48,26 @@ def write_tiny_clip(tmp_dir, seed=11):
     ckpt = os.path.join(tmp_dir, "ViT-B-16.pt")                  # the published archive's file name (state_dict form, clip/clip.py:147)
     torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in full.items()}, ckpt)
     return ckpt, bpe_path, full
+
+
+class _Node(torch.nn.Module):
+    """One level of the parameter tree of a TorchScript archive (the published CLIP files are scripted modules, clip/clip.py:138-141)."""
+
+    def forward(self, x):
+        return x
+
+
+def write_tiny_clip_jit(tmp_dir, seed=11):
+    """The same tiny checkpoint as a TorchScript ARCHIVE whose state_dict carries the CLIP keys -> (archive path, full state_dict)."""
+    _, _, full = write_tiny_clip(tmp_dir, seed)
+    root = _Node()
+    for k, v in full.items():
+        parts, m = k.split("."), root
+        for p in parts[:-1]:
+            if p not in m._modules:
+                m.add_module(p, _Node())
+            m = m._modules[p]
+        m.register_parameter(parts[-1], torch.nn.Parameter(torch.from_numpy(np.asarray(v)).clone(), requires_grad=False))
+    path = os.path.join(str(tmp_dir), "ViT-B-16.jit.pt")
+    torch.jit.script(root).save(path)
+    return path, full

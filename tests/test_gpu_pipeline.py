@@ -764,6 +764,22 @@ def test_validation_engine_with_decoder(gpu, golden):
     assert abs(seg_score["pAcc"] - ref_seg["pAcc"]) < 2e-3
 
 
+def test_clip_load_torchscript_archive(gpu, tmp_path):
+    """clip/clip.py:104-154 on a TorchScript archive (the form the published CLIP files have): the tower is built from the archive's
+    tensors with the architecture read off them, the text tower is kept, and the forward equals the one built from the plain dict."""
+    from _clip_files import write_tiny_clip_jit
+    from excel_amd import clip as xclip
+    path, full = write_tiny_clip_jit(tmp_path)
+    model, _ = xclip.load(path, device="cuda")
+    vis = model.visual
+    assert (vis.embed_dim, vis.layers, vis.output_dim) == (128, 8, 512)
+    assert np.array_equal(host(torch.as_tensor(vis.state_dict()["conv1.weight"])), full["visual.conv1.weight"])
+    ref, _ = xclip.load("unused", device="cuda", state_dict={k: torch.from_numpy(np.asarray(v)) for k, v in full.items()})
+    x = dev(np.random.RandomState(0).standard_normal((2, 3, 64, 64)).astype(np.float32))
+    a, b = model.encode_image(x), ref.encode_image(x)
+    assert torch.equal(a["image_features"], b["image_features"]) and model.context_length == 77
+
+
 def test_infer_lam_on_disk_voc(gpu, tmp_path):
     """tools/infer_lam.py over an on-disk VOC-format tree (JPEG + palette PNG + id list + one-hot dict) AND an on-disk CLIP checkpoint
     (visual + text tower) + BPE merges file: the tower is built from the file's weights, the 45 class/background prompts go through

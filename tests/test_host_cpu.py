@@ -399,6 +399,25 @@ def test_infer_lam_resolves_real_inputs_or_refuses(tmp_path, monkeypatch):
     assert sorted(kw4["decoder_state_dict"]) == ["decoder.linear_pred.bias", "decoder_fts_fuse.linear_fuse.bias"]
 
 
+def test_checkpoint_torchscript_archive_branch(tmp_path, monkeypatch):
+    """clip/clip.py:138-141: the published CLIP files are TorchScript archives; read_checkpoint takes their state_dict (every tensor
+    of a scripted module with the CLIP key layout comes back bit-identical) and the harness resolves such a file like a plain one."""
+    from _clip_files import write_tiny_clip_jit
+    from excel_amd.clip import clip as xclip
+    from excel_amd.tools import infer_lam
+    monkeypatch.delenv("EXCEL_CLIP_ROOT", raising=False)
+    path, full = write_tiny_clip_jit(tmp_path)
+    import torch
+    with pytest.raises(RuntimeError):
+        torch.load(path, map_location="cpu", weights_only=True)           # it really is an archive, not a pickled dict
+    sd = xclip.read_checkpoint(path)
+    assert sorted(sd) == sorted(full)
+    assert all(np.array_equal(sd[k].numpy(), np.asarray(full[k])) for k in full)
+    kw = infer_lam.resolve_model_inputs(infer_lam.get_parser().parse_args(
+        ["--data_folder", str(tmp_path), "--model", path, "--bpe_path", str(tmp_path / "bpe_tiny_vocab.txt.gz")]))
+    assert np.array_equal(kw["state_dict"]["visual.conv1.weight"].numpy(), full["visual.conv1.weight"])
+
+
 def test_clip_text_prompt_lists():
     """model/model_excel.py:31: 20 + 25 prompts for VOC, 80 + 23 for COCO (datasets/clip_text.py lists, shipped as data)."""
     from excel_amd.datasets import clip_text
