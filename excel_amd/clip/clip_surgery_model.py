@@ -58,7 +58,8 @@ class VisionTransformer:
 
     @torch.no_grad()
     def forward(self, x, return_weights=False, ex_feats=None, **kw):
-        """:419-448 -> (x [B,N,C] token features, attn_weights, all_feats).  See clip.generate_clip_fts."""
+        """:419-448.  Returns the handle's dict (image_features [B,N,C], w_aff, attn, feats, x_raw - ops.VitHandle.forward);
+        clip.generate_clip_fts turns it into the reference's (image_features, attn_weights, all_feats) triple."""
         if ex_feats is not None:
             # Attention.forward :127-137: the cue is the same for every head and every surgery block -> built once
             kw["ex_attn"] = ops.feature_affinity(ex_feats, "mask_softmax", beta=1.0, gamma=3.0)
