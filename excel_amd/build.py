@@ -35,6 +35,11 @@ def build(force=False, verbose=True):
     hipcc = _hipcc()
     flags = FLAGS + (["-DEXCEL_DEV"] if os.environ.get("EXCEL_DEV") == "1" else [])
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    # objects built with other flags (a dev build, another compiler) are stale whatever their time stamps say
+    stamp = os.path.join(CSRC, ".build_flags")
+    sig = " ".join([hipcc] + flags)
+    if not force and (not os.path.exists(stamp) or open(stamp).read() != sig):
+        force = os.path.exists(LIB) or any(os.path.exists(os.path.join(CSRC, s.replace(".hip", ".o"))) for s in SOURCES)
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
@@ -56,6 +61,8 @@ def build(force=False, verbose=True):
             raise RuntimeError("link failed: %s\n%s" % (" ".join(cmd), res.stderr))
         if verbose:
             print("[excel_amd.build] linked", LIB)
+    with open(stamp, "w") as f:
+        f.write(sig)
     return LIB
 
 
