@@ -303,20 +303,23 @@ __device__ __forceinline__ void rowpass_body_bf(const RowpassArgs& p, float* sme
         const int d = wave * 16 + j * 8 + (lane >> 3);
         voff[j] = (long long)d * 2 * p.vt_kp + (((lane & 7) ^ ((d >> 1) & 7)) * 8);
     }
-    auto issue = [&](int kt, int stage) {
+    // piece idx of this wave's PER_WAVE 1-KB loads of key tile kt: 0, 1 = K rows, 2, 3 = V^T rows (flash only)
+    auto issue_piece = [&](int kt, int stage, int idx) {
         u16* dstk = ring + stage * STAGE_EL;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        if (idx < 2) {
+            const int j = idx;
             const int key = min(kt * 32 + krow[j], N - 1);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ysp + (long long)key * 128 + koff[j]),
                                              (__attribute__((address_space(3))) void*)(dstk + (wave * 8 + j * 4) * 128), 16, 0, 0);
+        } else if (FLASH) {
+            const int j = idx - 2;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(VT + voff[j] + kt * 64),
+                                             (__attribute__((address_space(3))) void*)(dstk + KT_EL + (wave * 16 + j * 8) * 64), 16, 0, 0);
         }
-        if (FLASH) {
+    };
+    auto issue = [&](int kt, int stage) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(VT + voff[j] + kt * 64),
-                                                 (__attribute__((address_space(3))) void*)(dstk + KT_EL + (wave * 16 + j * 8) * 64), 16, 0, 0);
-        }
+        for (int idx = 0; idx < PER_WAVE; ++idx) issue_piece(kt, stage, idx);
     };
 
     const float c2 = p.scale * 1.4426950408889634f;     // scores enter the softmax in log2 units
@@ -337,8 +340,13 @@ __device__ __forceinline__ void rowpass_body_bf(const RowpassArgs& p, float* sme
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nkt) issue(kt + 2, stage == 0 ? 2 : stage - 1);
-        if (q0 >= N) { stage = (stage == 2) ? 0 : stage + 1; continue; }      // wave-uniform: all 32 query rows are padding -> only keep the ring moving
+        const int rstage = stage == 0 ? 2 : stage - 1;                       // slot of tile kt-1, free since the barrier: tile kt+2 goes there
+        const bool refill = kt + 2 < nkt;
+        if (q0 >= N) {                                                        // wave-uniform: all 32 query rows are padding -> only keep the ring moving
+            if (refill) issue(kt + 2, rstage);
+            stage = (stage == 2) ? 0 : stage + 1;
+            continue;
+        }
         // LDS reads as inline asm (common.h): a compiler-visible ds_read behind pending LDS-DMA gets an s_waitcnt vmcnt(0) in front of
         // it, which drained the two key tiles in flight on every step
         const unsigned kr = ring_b + (stage * STAGE_EL + r * 128) * 2;
@@ -353,11 +361,15 @@ __device__ __forceinline__ void rowpass_body_bf(const RowpassArgs& p, float* sme
                 yl[s4] = lds_read16(kr + (((8 + s4 * 2 + kh) ^ (r & 15)) * 16));
             }
             lds_wait8(yh, yl);
+            // the refill is issued one piece per k-step between the score MFMAs (back to back, the pieces of all waves queue up in the CU's
+            // one address path and each wave sits behind its own before it reaches its MFMAs)
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
+                if (refill && s4 < PER_WAVE) issue_piece(kt + 2, rstage, s4);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl[s4], xh[s4], s, 0, 0, 0);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[s4], xl[s4], s, 0, 0, 0);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[s4], xh[s4], s, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         // softmax bookkeeping in log2 units: p = exp2(s*c2 - m2), c2 = scale*log2(e)  (one fma + one v_exp per element);

@@ -97,24 +97,36 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
         return (typ * H + h) * N * 256;
     };
     typedef __attribute__((address_space(3))) unsigned char* lds_bptr;
-    auto dma_tile = [&](int soff, unsigned dst_byte) {
+    // pieces [i0, i1) of an 8-piece (8 KB) tile
+    auto dma_pieces = [&](int soff, unsigned dst_byte, int i0, int i1) {
         // opaque to the optimiser: otherwise the 16 per-instruction LDS destinations (m0 values) are hoisted out of the loop
         // into SGPRs that spill (v_readlane + hazard nops inside the loop); recomputed here they are one s_add each
         asm volatile("" : "+s"(dst_byte));
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_bptr)(unsigned long long)(dst_byte + i * 1024), 16, voff[i & 3], soff + (i >> 2) * 4096, 0, 0);
+            if (i >= i0 && i < i1)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_bptr)(unsigned long long)(dst_byte + i * 1024), 16, voff[i & 3], soff + (i >> 2) * 4096, 0, 0);
     };
+    auto dma_tile = [&](int soff, unsigned dst_byte) { dma_pieces(soff, dst_byte, 0, 8); };
 
     // ---- issue cursor over (phase, tile) in consumption order.  Past the end of a sweep it keeps re-loading the last tile into
     // the slot just freed (never read again), so every wait in the loop is the same counted vmcnt(8): no end-of-stream branches.
     int it_t, it_j, it_g, it_t1, it_poff;
-    auto issue_next = [&]() {
-        dma_tile(it_poff + (first + it_j) * 8192, ring_addr + (it_g & 1) * (TILE_EL * 2));
+    auto issue_advance = [&]() {
         ++it_g;
         if (it_t < it_t1 - 1 || it_j < cnt - 1) {
             if (++it_j == cnt) { it_j = 0; ++it_t; it_poff = plane_off(it_t, false); }
         }
+    };
+    auto issue_next = [&]() {
+        dma_tile(it_poff + (first + it_j) * 8192, ring_addr + (it_g & 1) * (TILE_EL * 2));
+        issue_advance();
+    };
+    // the same tile in four instalments of two pieces, placed between the MFMA groups of the tile being multiplied: eight pieces
+    // issued back to back by every wave at once queue up in the CU's one address path and hold the wave off its MFMAs
+    auto issue_next_part = [&](int part) {
+        dma_pieces(it_poff + (first + it_j) * 8192, ring_addr + (it_g & 1) * (TILE_EL * 2), 2 * part, 2 * part + 2);
+        if (part == 3) issue_advance();
     };
     auto issue_x = [&](int t, int par) {
         const int soff = plane_off(t, true) + q0 * 256;
@@ -202,7 +214,7 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
                         yl[s4] = lds_read16(kr + (((8 + s4 * 2 + kh) ^ (r & 15)) * 16));
                     }
                     lds_wait8(yh, yl);                                                      // fragments in registers: the slot is free
-                    if (!(DBG & 2)) issue_next();                                           // tile gc+2 -> this slot
+                    if ((DBG & 1) && !(DBG & 2)) issue_next();                              // tile gc+2 -> this slot
                     ++gc;
                     f32x16 sj;
 #pragma unroll
@@ -210,9 +222,11 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
                     if (!(DBG & 1)) {
 #pragma unroll
                         for (int s4 = 0; s4 < 4; ++s4) {
+                            if (!(DBG & 2)) issue_next_part(s4);                            // tile gc+2 -> this slot, two pieces per k-step
                             sj = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl[s4], xh[s4], sj, 0, 0, 0);
                             sj = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[s4], xl[s4], sj, 0, 0, 0);
                             sj = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[s4], xh[s4], sj, 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);                              // keep the instalments where they are
                         }
                     } else {
                         sj[0] = (float)yl[0][0] + (float)yh[3][1] + (float)xh[0][0] + (float)xl[3][1];

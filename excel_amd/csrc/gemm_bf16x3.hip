@@ -198,15 +198,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16x3_kernel(GemmBfArgs
         const int grow = isB ? min(n0 + row_l, p.N - 1) : min(m0 + row_l, p.M - 1);
         gsrc[j] = (isB ? p.B + (long long)grow * p.ldb : p.A + (long long)grow * p.lda) + c * 8;   // chunk c of the row's 128-B k-block
     }
+    auto issue_piece = [&](int kt, int stage, int j) {
+        const bool isB = j >= A_PER_WAVE;
+        const int seg = isB ? wave * B_PER_WAVE + (j - A_PER_WAVE) : wave * A_PER_WAVE + j;
+        u16* dst = smem + stage * STAGE + (isB ? BM * TROW : 0) + seg * 8 * TROW;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc[j] + kt * 64),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
     auto issue_tile = [&](int kt, int stage) {
 #pragma unroll
-        for (int j = 0; j < PER_WAVE; ++j) {
-            const bool isB = j >= A_PER_WAVE;
-            const int seg = isB ? wave * B_PER_WAVE + (j - A_PER_WAVE) : wave * A_PER_WAVE + j;
-            u16* dst = smem + stage * STAGE + (isB ? BM * TROW : 0) + seg * 8 * TROW;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc[j] + kt * 64),
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        }
+        for (int j = 0; j < PER_WAVE; ++j) issue_piece(kt, stage, j);
     };
 
     f32x16 acc[TI][2];
@@ -220,7 +221,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16x3_kernel(GemmBfArgs
     const int sw = (r >> 1) & 7;      // (row>>1)&7 of every fragment row this lane reads (tile rows are r + multiples of 32)
     const int nk = p.K / TBK;
 
-    auto compute = [&](int stage) {
+    // kt_next >= 0 (TI == 5 path): the next tile's LDS-DMA pieces are issued one per (k16 sub-step, row tile) pair INSIDE the MFMA
+    // stream instead of all PER_WAVE up front.  A piece occupies the CU's one address / L1 path for ~16 cycles (64 lanes x 16 B at
+    // 64 B/clk): with all 8 waves issuing 9 pieces at the step start that queue was ~1 100 cycles deep, and a wave does not reach its
+    // MFMAs before its own pieces are accepted - measured (PMC, fc2 shape): +75 k of 572 k kernel cycles wherever the data came from.
+    // Same-box A/B of placements (tools_dev/gemm_bench.py, four layer shapes): one piece at the head of each pair -4.5 %; two per
+    // second pair -1 %; behind the pair's MFMAs -3 %; the two waves of a SIMD offset by one pair -3 %; a branch-free peeled loop -2.4 %.
+    auto compute = [&](int stage, int kt_next) {
         const u16* as = smem + stage * STAGE;
         const u16* bs = as + BM * TROW;
 #pragma unroll
@@ -261,6 +268,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16x3_kernel(GemmBfArgs
                 }
 #pragma unroll
                 for (int i = 0; i < TI; ++i) {
+                    if (kt_next >= 0 && s2 * TI + i < PER_WAVE) issue_piece(kt_next, stage ^ 1, s2 * TI + i);
                     if (i + 1 < TI) {
                         const u16* rowp = as + (wm * (TI * 32) + (i + 1) * 32 + r) * TROW;
                         ah[(i + 1) & 1] = *reinterpret_cast<const bf16x8*>(rowp + ch);
@@ -282,8 +290,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16x3_kernel(GemmBfArgs
         issue_tile(0, 0);
         __syncthreads();                  // drains the LDS-DMA (vmcnt(0)) and publishes the tile
         for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk && !(EXCEL_DBG(p.dbg) & 2)) issue_tile(kt + 1, (kt + 1) & 1);      // in flight during this step's MFMAs
-            if (!(EXCEL_DBG(p.dbg) & 1)) compute(kt & 1);
+            const bool more = kt + 1 < nk && !(EXCEL_DBG(p.dbg) & 2);
+            if (TI > 4 && PER_WAVE <= 2 * TI && !(EXCEL_DBG(p.dbg) & 1)) {
+                compute(kt & 1, more ? kt + 1 : -1);               // tile kt+1 streams in behind this step's MFMAs
+            } else {
+                if (more) issue_tile(kt + 1, (kt + 1) & 1);        // in flight during this step's MFMAs
+                if (!(EXCEL_DBG(p.dbg) & 1)) compute(kt & 1, -1);
+            }
             __syncthreads();
         }
     } else {
@@ -303,7 +316,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16x3_kernel(GemmBfArgs
             }
             __builtin_amdgcn_s_barrier();
             if (kt + 2 < nk && !(EXCEL_DBG(p.dbg) & 2)) issue_tile(kt + 2, stage == 0 ? NSTAGE - 1 : stage - 1);
-            if (!(EXCEL_DBG(p.dbg) & 1)) compute(stage);
+            if (!(EXCEL_DBG(p.dbg) & 1)) compute(stage, -1);
             stage = (stage + 1 == NSTAGE) ? 0 : stage + 1;
         }
         __syncthreads();

@@ -2,6 +2,9 @@
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+if os.environ.get("EXCEL_AB_LIB"):      # A/B a differently built library on the same box
+    import excel_amd._lib as _L
+    _L.LIB_PATH = os.path.abspath(os.environ["EXCEL_AB_LIB"])
 from excel_amd import ops
 M, N, K = (int(x) for x in sys.argv[1:4]) if len(sys.argv) > 3 else (25120, 3072, 768)
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 20
