@@ -59,6 +59,11 @@ class TextWeights(C.Structure):
         [("blocks", C.POINTER(DecoderBlockWeights))]
 
 
+class RaggedInfo(C.Structure):
+    _fields_ = [("B", C.c_int32), ("total_tiles", C.c_int32), ("total_pix", C.c_int64), ("total_label_pix", C.c_int64),
+                ("max_plane_pix", C.c_int64), ("table_ints", C.c_int64)]
+
+
 # name -> (restype, argtypes); mirrors include/excel_hip.h one to one
 SIGNATURES = {
     "excel_last_error": (C.c_char_p, []),
@@ -112,11 +117,17 @@ SIGNATURES = {
     "excel_scoremap_box_mask": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, C.c_double, c_f, c_f, c_f]),
     "excel_refine_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "excel_refine_cams_with_aff": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, C.c_double, c_f, c_f, c_f]),
-    "excel_cam_upsample_bkg": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f]),
+    "excel_cam_upsample_bkg": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_f]),
     "excel_par_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i]),
-    "excel_par_set_mode": (c_i, [c_i]),
     "excel_par_forward": (c_i, [c_f, c_i, c_i, c_f, c_f, c_i, c_i, c_i, c_i, C.POINTER(C.c_int32), c_i, c_i,
-                                C.c_float, C.c_float, c_f, c_f, c_f]),
+                                C.c_float, C.c_float, c_f, c_f, c_i, c_f]),
+    "excel_ragged_plan": (c_i, [C.POINTER(C.c_int32), c_i, C.POINTER(RaggedInfo), C.POINTER(C.c_int32)]),
+    "excel_normalize_resize_u8_ragged": (c_i, [c_f, c_f, c_i, c_i, C.POINTER(C.c_double), C.POINTER(C.c_double), c_f, c_f]),
+    "excel_cam_upsample_bkg_ragged": (c_i, [c_f, c_f, c_f, C.POINTER(RaggedInfo), c_i, c_i, c_f, c_f, c_i, c_f]),
+    "excel_par_ragged_workspace_bytes": (c_sz, [c_ll, c_i]),
+    "excel_par_forward_ragged": (c_i, [c_f, c_i, c_i, c_f, c_f, c_f, C.POINTER(RaggedInfo), c_i, C.POINTER(C.c_int32), c_i, c_i,
+                                       C.c_float, C.c_float, c_f, c_f, c_f]),
+    "excel_argmax_label_ragged": (c_i, [c_f, c_f, c_f, c_f, C.POINTER(RaggedInfo), c_i, c_i, c_f, c_f]),
     "excel_argmax_label": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_ll, c_f, c_f, c_f]),
     "excel_confusion_accumulate": (c_i, [c_f, c_f, c_ll, c_i, c_f, c_f]),
     "excel_attr_aggregate": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, C.c_double, c_f, c_f]),

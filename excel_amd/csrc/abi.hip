@@ -17,10 +17,9 @@ void excel_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* excel_last_error(void) { return g_err; }
-extern "C" int excel_abi_version(void) { return 1; }
+extern "C" int excel_abi_version(void) { return 2; }
 
 // ------------------------------------------------------------------------------------ profiling hooks
-int g_excel_par_mode = 0;
 bool g_excel_prof_on = false;
 int g_excel_prof_gemm_cat = -1;
 unsigned long long g_excel_prof_mask = ~0ull;
@@ -661,9 +660,60 @@ extern "C" int excel_refine_cams_with_aff(const float* attr, const float* w_aff,
 }
 
 extern "C" int excel_cam_upsample_bkg(const float* refined, const int32_t* ncls, int B, int g, int Smax, int H, int W, float* cams,
-                                      void* workspace, void* stream) {
+                                      void* workspace, int flags, void* stream) {
     EXCEL_CHECK_ARG(refined && ncls && cams && workspace, "cam_upsample_bkg: null argument");
-    return excel_launch_cam_upsample_bkg(refined, ncls, (float*)workspace, cams, B, g, Smax, H, W, ST(stream));
+    return excel_launch_cam_upsample_bkg(refined, ncls, (float*)workspace, cams, B, g, Smax, H, W, (flags & EXCEL_CAMS_ZERO_UNUSED) ? 1 : 0, ST(stream));
+}
+
+// ------------------------------------------------------------------------------------ ragged batches (images of different sizes)
+extern "C" int excel_ragged_plan(const int32_t* hw, int B, excel_ragged_info* info, int32_t* table) {
+    EXCEL_CHECK_ARG(hw && info && B >= 1, "ragged_plan: bad argument");
+    long long pix = 0, lab = 0, tiles = 0, max_plane = 0;
+    for (int b = 0; b < B; ++b) {
+        const long long H = hw[2 * b], W = hw[2 * b + 1];
+        EXCEL_CHECK_ARG(H >= 1 && W >= 1, "ragged_plan: image %d has size %lld x %lld", b, H, W);
+        const long long Wp = (W + 3) / 4 * 4, plane = H * Wp, nt = ((W + 63) / 64) * ((H + 15) / 16);
+        if (table) {
+            int32_t* rec = table + EXCEL_RAG_REC * b;
+            rec[0] = (int32_t)H; rec[1] = (int32_t)W; rec[2] = (int32_t)pix; rec[3] = (int32_t)tiles; rec[4] = (int32_t)lab; rec[5] = rec[6] = rec[7] = 0;
+            for (long long t = 0; t < nt; ++t) table[EXCEL_RAG_REC * (B + 1) + tiles + t] = b;
+        }
+        pix += plane; lab += H * W; tiles += nt;
+        if (plane > max_plane) max_plane = plane;
+        EXCEL_CHECK_ARG(pix < (1LL << 31) && 3 * lab < (1LL << 31) && tiles < (1LL << 31), "ragged_plan: batch too large for 32-bit offsets");
+    }
+    if (table) {
+        int32_t* rec = table + EXCEL_RAG_REC * B;
+        rec[0] = rec[1] = 0; rec[2] = (int32_t)pix; rec[3] = (int32_t)tiles; rec[4] = (int32_t)lab; rec[5] = rec[6] = rec[7] = 0;
+    }
+    info->B = B; info->total_tiles = (int32_t)tiles; info->total_pix = pix; info->total_label_pix = lab; info->max_plane_pix = max_plane;
+    info->table_ints = EXCEL_RAG_REC * (long long)(B + 1) + tiles;
+    return EXCEL_OK;
+}
+
+static TileGeo ragged_geo(const int32_t* table, int B) {
+    TileGeo g;
+    g.tab = table; g.B = B; g.H = g.W = 0;
+    return g;
+}
+static TileGeo uniform_geo(int B, int H, int W) {
+    TileGeo g;
+    g.tab = nullptr; g.B = B; g.H = H; g.W = W;
+    return g;
+}
+
+extern "C" int excel_normalize_resize_u8_ragged(const uint8_t* hwc, const int32_t* table, int B, int S, const double* mean3, const double* std3,
+                                                float* out, void* stream) {
+    EXCEL_CHECK_ARG(hwc && table && out && mean3 && std3 && B > 0 && S > 0, "normalize_resize_u8_ragged: bad argument");
+    return excel_launch_normalize_resize_u8_ragged(hwc, out, ragged_geo(table, B), S, mean3, std3, ST(stream));
+}
+
+extern "C" int excel_cam_upsample_bkg_ragged(const float* refined, const int32_t* ncls, const int32_t* table, const excel_ragged_info* info, int g,
+                                             int Smax, float* cams, void* workspace, int flags, void* stream) {
+    EXCEL_CHECK_ARG(refined && ncls && table && info && cams && workspace, "cam_upsample_bkg_ragged: null argument");
+    EXCEL_CHECK_ARG((((uintptr_t)cams) & 15) == 0, "cam_upsample_bkg_ragged: cams must be 16-byte aligned");
+    return excel_launch_cam_upsample_bkg_ragged(refined, ncls, (float*)workspace, cams, g, Smax, ragged_geo(table, info->B), info->total_tiles,
+                                                (flags & EXCEL_CAMS_ZERO_UNUSED) ? 1 : 0, ST(stream));
 }
 
 // ------------------------------------------------------------------------------------ PAR / labels / metric
@@ -673,11 +723,24 @@ extern "C" size_t excel_par_workspace_bytes(int B, int Cmax, int H, int W, int n
            align_up((size_t)B * 3 * hw * sizeof(float), 256);
 }
 
+// ping-pong so that the LAST step writes `out`: out, pp alternate backwards from the end
+template <class Step>
+static int par_jacobi(const float* masks, float* out, float* pp, int n_iter, Step step) {
+    const float* cur = masks;
+    for (int it = 0; it < n_iter; ++it) {
+        float* dst = (((n_iter - 1 - it) & 1) == 0) ? out : pp;
+        TRY(step(cur, dst));
+        cur = dst;
+    }
+    return EXCEL_OK;
+}
+
 extern "C" int excel_par_forward(const float* imgs, int h, int w, const float* masks, const int32_t* nchan, int B, int Cmax, int H,
                                  int W, const int32_t* dilations, int ndil, int n_iter, float w1, float w2, float* out,
-                                 void* workspace, void* stream) {
+                                 void* workspace, int flags, void* stream) {
     EXCEL_CHECK_ARG(imgs && masks && out && workspace && dilations, "par_forward: null argument");
     EXCEL_CHECK_ARG(n_iter >= 0 && ndil >= 1 && ndil <= 8, "par_forward: bad n_iter/ndil");
+    EXCEL_CHECK_ARG(B > 0 && Cmax > 0 && H > 0 && W > 0 && h > 0 && w > 0, "par_forward: bad shape");
     const size_t hw = (size_t)H * W;
     char* base = (char*)workspace;
     float* aff = (float*)base;
@@ -689,32 +752,59 @@ extern "C" int excel_par_forward(const float* imgs, int h, int w, const float* m
         TRY(excel_launch_bilinear_ac(imgs, guide, B * 3, h, w, H, W, st));
         gimg = guide;
     }
-    // Affinities: either streamed as 8*ndil planes per image, or (default where the tiled kernel applies) recomputed in every step
-    // from the guide image and 5 per-pixel statistics: bit-identical weights from a tenth of the bytes (par.hip).
-    const bool recompute = g_excel_par_mode != 1 && n_iter > 0 &&
-                           excel_par_guide_supported(gimg, aff, masks, out, H, W, dilations, ndil) && (((uintptr_t)pp & 15) == 0);
-    TRY(excel_launch_par_affinity(gimg, aff, B, H, W, dilations, ndil, w1, w2, st, recompute ? 1 : 0));
+    // Affinities: either streamed as 8*ndil planes per image (EXCEL_PAR_STREAM_AFFINITIES, or a shape / dilation set the tiled kernel
+    // does not take), or recomputed in every step from the guide image and 5 per-pixel statistics: bit-identical weights from a
+    // tenth of the bytes (par.hip).
+    const TileGeo geo = uniform_geo(B, H, W);
+    const bool recompute = !(flags & EXCEL_PAR_STREAM_AFFINITIES) && n_iter > 0 && (W % 4) == 0 && (((uintptr_t)pp & 15) == 0) &&
+                           excel_par_guide_supported(gimg, aff, masks, out, Cmax, (long long)hw, W, dilations, ndil);
+    TRY(excel_launch_par_affinity(gimg, aff, geo, 0, dilations, ndil, w1, w2, st, recompute ? 1 : 0));
     if (n_iter == 0) {
         hipMemcpyAsync(out, masks, sizeof(float) * (size_t)B * Cmax * hw, hipMemcpyDeviceToDevice, st);
         return EXCEL_OK;
     }
-    // ping-pong so that the LAST step writes `out`: out, pp alternate backwards from the end
-    const float* cur = masks;
-    for (int it = 0; it < n_iter; ++it) {
-        float* dst = (((n_iter - 1 - it) & 1) == 0) ? out : pp;
-        if (recompute) TRY(excel_launch_par_iterate_guide(gimg, aff, cur, dst, nchan, B, Cmax, H, W, dilations, ndil, w1, w2, st));
-        else TRY(excel_launch_par_iterate(aff, cur, dst, nchan, B, Cmax, H, W, dilations, ndil, st));
-        cur = dst;
-    }
-    return EXCEL_OK;
+    if (recompute)
+        return par_jacobi(masks, out, pp, n_iter, [&](const float* cur, float* dst) {
+            return excel_launch_par_iterate_guide(gimg, aff, cur, dst, nchan, Cmax, geo, 0, dilations, ndil, w1, w2, st);
+        });
+    return par_jacobi(masks, out, pp, n_iter, [&](const float* cur, float* dst) {
+        return excel_launch_par_iterate(aff, cur, dst, nchan, B, Cmax, H, W, dilations, ndil, st);
+    });
 }
 
-// 0 (default): recompute the PAR affinities per step where supported; 1: always stream the affinity planes (the two are bit-identical;
-// kept selectable so that tests can compare them and profiles can show both)
-extern "C" int excel_par_set_mode(int mode) {
-    EXCEL_CHECK_ARG(mode == 0 || mode == 1, "excel_par_set_mode: mode must be 0 or 1");
-    g_excel_par_mode = mode;
-    return EXCEL_OK;
+// statistics [5 planes] + ping-pong [Cmax planes] + resized guide [3 planes], all in the pitched ragged layout
+extern "C" size_t excel_par_ragged_workspace_bytes(long long total_pix, int Cmax) {
+    return align_up((size_t)5 * total_pix * sizeof(float), 256) + align_up((size_t)Cmax * total_pix * sizeof(float), 256) +
+           align_up((size_t)3 * total_pix * sizeof(float), 256);
+}
+
+extern "C" int excel_par_forward_ragged(const float* imgs, int h, int w, const float* masks, const int32_t* nchan, const int32_t* table,
+                                        const excel_ragged_info* info, int Cmax, const int32_t* dilations, int ndil, int n_iter, float w1,
+                                        float w2, float* out, void* workspace, void* stream) {
+    EXCEL_CHECK_ARG(imgs && masks && out && workspace && dilations && table && info, "par_forward_ragged: null argument");
+    EXCEL_CHECK_ARG(n_iter >= 1 && Cmax > 0 && h > 0 && w > 0 && info->B > 0, "par_forward_ragged: bad n_iter / shape");
+    const size_t tp = (size_t)info->total_pix;
+    char* base = (char*)workspace;
+    float* stats = (float*)base;
+    float* pp = (float*)(base + align_up(5 * tp * sizeof(float), 256));
+    float* guide = (float*)((char*)pp + align_up((size_t)Cmax * tp * sizeof(float), 256));
+    hipStream_t st = ST(stream);
+    const TileGeo geo = ragged_geo(table, info->B);
+    EXCEL_CHECK_ARG(excel_par_guide_supported(guide, stats, masks, out, Cmax, info->max_plane_pix, 8, dilations, ndil) && (((uintptr_t)pp & 15) == 0),
+                    "par_forward_ragged: needs dilations [1,2,4,8,12,24], 16-byte aligned buffers and Cmax * H * W * 4 < 2^31 per image");
+    // the guide always goes through the align_corners=True resize (PAR.py:67): it is the identity where (H_b, W_b) == (h, w), and it
+    // brings the uniform [B,3,h,w] network input into the pitched per-image layout
+    TRY(excel_launch_bilinear_ac_ragged(imgs, guide, h, w, geo, info->total_tiles, st));
+    TRY(excel_launch_par_affinity(guide, stats, geo, info->total_tiles, dilations, ndil, w1, w2, st, 1));
+    return par_jacobi(masks, out, pp, n_iter, [&](const float* cur, float* dst) {
+        return excel_launch_par_iterate_guide(guide, stats, cur, dst, nchan, Cmax, geo, info->total_tiles, dilations, ndil, w1, w2, st);
+    });
+}
+
+extern "C" int excel_argmax_label_ragged(const float* cams, const int32_t* nchan, const int32_t* cls_idx, const int32_t* table,
+                                         const excel_ragged_info* info, int Smax, int Cmax, uint8_t* labels_u8, void* stream) {
+    EXCEL_CHECK_ARG(cams && table && info && labels_u8, "argmax_label_ragged: null argument");
+    return excel_launch_argmax_label_ragged(cams, nchan, cls_idx, Smax, Cmax, ragged_geo(table, info->B), info->total_tiles, labels_u8, ST(stream));
 }
 
 extern "C" int excel_argmax_label(const float* cams, const int32_t* nchan, const int32_t* cls_idx, int B, int Smax, int Cmax,

@@ -249,35 +249,64 @@ __global__ __launch_bounds__(256) void cam_minmax_norm_kernel(const float* __res
 }
 
 // ---------------------------------------------------------------- cv2.resize(INTER_LINEAR) + background channel
+// OpenCV: fx = (dx + 0.5) * (src/dst) - 0.5 in double; floor; clamp to the edge with weight 0
+struct CvTap { int s0, s1; float f; };
+__device__ __forceinline__ CvTap cv_linear_tap(int d, int g, int D) {
+    const double fd = ((double)d + 0.5) * ((double)g / (double)D) - 0.5;
+    CvTap t;
+    t.s0 = (int)floor(fd);
+    t.f = (float)(fd - t.s0);
+    if (t.s0 < 0) { t.f = 0.f; t.s0 = 0; }
+    if (t.s0 >= g - 1) { t.f = 0.f; t.s0 = g - 1; }
+    t.s1 = min(t.s0 + 1, g - 1);
+    return t;
+}
+// all present classes of one pixel + the background channel (torch.pow(1 - max, 1.), :165); channels above the present ones are
+// zeroed on request (nobody on the path reads them: PAR / arg-max stop at nchan)
+__device__ __forceinline__ void cam_upsample_px(const float* __restrict__ rn_b, float* __restrict__ out, long long HW, int g, int ns, int Smax,
+                                                const CvTap& tx, const CvTap& ty, int zero_unused) {
+    float mx = -INFINITY;
+    for (int s = 0; s < ns; ++s) {
+        const float* m = rn_b + (long long)s * g * g;
+        // horizontal pass first; explicit operations: the uniform and the ragged kernel must round alike
+        const float top = fmaf(m[ty.s0 * g + tx.s1], tx.f, __fmul_rn(m[ty.s0 * g + tx.s0], 1.f - tx.f));
+        const float bot = fmaf(m[ty.s1 * g + tx.s1], tx.f, __fmul_rn(m[ty.s1 * g + tx.s0], 1.f - tx.f));
+        const float v = fmaf(bot, ty.f, __fmul_rn(top, 1.f - ty.f));
+        out[(long long)(s + 1) * HW] = v;
+        mx = fmaxf(mx, v);
+    }
+    out[0] = 1.f - mx;
+    if (zero_unused)
+        for (int s = ns; s < Smax; ++s) out[(long long)(s + 1) * HW] = 0.f;
+}
+
 __global__ __launch_bounds__(256) void cam_upsample_bkg_kernel(const float* __restrict__ rn, const int* __restrict__ ncls,
-                                                               float* __restrict__ cams, int g, int Smax, int H, int W) {
+                                                               float* __restrict__ cams, int g, int Smax, int H, int W, int zero_unused) {
     const int b = blockIdx.z;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
     const int ns = min(ncls[b], Smax);
-    // OpenCV: fx = (dx + 0.5) * (src/dst) - 0.5 in double; floor; clamp to the edge with weight 0
-    double fxd = ((double)x + 0.5) * ((double)g / (double)W) - 0.5;
-    double fyd = ((double)y + 0.5) * ((double)g / (double)H) - 0.5;
-    int sx = (int)floor(fxd), sy = (int)floor(fyd);
-    float fx = (float)(fxd - sx), fy = (float)(fyd - sy);
-    if (sx < 0) { fx = 0.f; sx = 0; }
-    if (sx >= g - 1) { fx = 0.f; sx = g - 1; }
-    if (sy < 0) { fy = 0.f; sy = 0; }
-    if (sy >= g - 1) { fy = 0.f; sy = g - 1; }
-    const int sx1 = min(sx + 1, g - 1), sy1 = min(sy + 1, g - 1);
     const long long HW = (long long)H * W;
-    float* out = cams + (long long)b * (Smax + 1) * HW + (long long)y * W + x;
-    float mx = -INFINITY;
-    for (int s = 0; s < ns; ++s) {
-        const float* m = rn + ((long long)b * Smax + s) * g * g;
-        const float top = m[sy * g + sx] * (1.f - fx) + m[sy * g + sx1] * fx;     // horizontal pass first
-        const float bot = m[sy1 * g + sx] * (1.f - fx) + m[sy1 * g + sx1] * fx;
-        const float v = top * (1.f - fy) + bot * fy;
-        out[(long long)(s + 1) * HW] = v;
-        mx = fmaxf(mx, v);
+    cam_upsample_px(rn + (long long)b * Smax * g * g, cams + (long long)b * (Smax + 1) * HW + (long long)y * W + x, HW, g, ns, Smax,
+                    cv_linear_tap(x, g, W), cv_linear_tap(y, g, H), zero_unused);
+}
+
+// ragged: every image up-sampled to its own (H_b, W_b) into the pitched cams [Smax+1 planes per image]
+__global__ __launch_bounds__(256) void cam_upsample_bkg_ragged_kernel(const float* __restrict__ rn, const int* __restrict__ ncls,
+                                                                      float* __restrict__ cams, int g, int Smax, TileGeo geo, int zero_unused) {
+    const Tile t = tile_of<true>(geo);
+    const int x = t.x0 + (threadIdx.x & 63);
+    if (x >= t.W) return;
+    const int ns = min(ncls[t.b], Smax);
+    const CvTap tx = cv_linear_tap(x, g, t.W);
+    const float* rn_b = rn + (long long)t.b * Smax * g * g;
+    float* cb = cams + (long long)(Smax + 1) * t.base + x;
+#pragma unroll 1
+    for (int r = 0; r < 4; ++r) {
+        const int y = t.y0 + (threadIdx.x >> 6) + 4 * r;
+        if (y < t.H) cam_upsample_px(rn_b, cb + (long long)y * t.Wp, t.HW, g, ns, Smax, tx, cv_linear_tap(y, g, t.H), zero_unused);
     }
-    out[0] = 1.f - mx;     // torch.pow(1 - max, 1.) (:165)
 }
 
 // ---------------------------------------------------------------- launchers
@@ -321,10 +350,19 @@ int excel_launch_matvec(const float* T, const float* v, const int* ncls, float* 
 }
 
 int excel_launch_cam_upsample_bkg(const float* r, const int* ncls, float* rn, float* cams, int B, int g, int Smax, int H, int W,
-                                  hipStream_t st) {
+                                  int zero_unused, hipStream_t st) {
     ProfScope prof__(PROF_UPSAMPLE, st);
     hipLaunchKernelGGL(cam_minmax_norm_kernel, dim3(Smax, B), dim3(256), 0, st, r, ncls, rn, g * g, Smax);
-    hipLaunchKernelGGL(cam_upsample_bkg_kernel, dim3(cdiv(W, 64), cdiv(H, 4), B), dim3(256), 0, st, rn, ncls, cams, g, Smax, H, W);
+    hipLaunchKernelGGL(cam_upsample_bkg_kernel, dim3(cdiv(W, 64), cdiv(H, 4), B), dim3(256), 0, st, rn, ncls, cams, g, Smax, H, W, zero_unused);
     EXCEL_CHECK_LAUNCH("cam_upsample_bkg");
+    return EXCEL_OK;
+}
+
+int excel_launch_cam_upsample_bkg_ragged(const float* r, const int* ncls, float* rn, float* cams, int g, int Smax, const TileGeo& geo,
+                                         int total_tiles, int zero_unused, hipStream_t st) {
+    ProfScope prof__(PROF_UPSAMPLE, st);
+    hipLaunchKernelGGL(cam_minmax_norm_kernel, dim3(Smax, geo.B), dim3(256), 0, st, r, ncls, rn, g * g, Smax);
+    hipLaunchKernelGGL(cam_upsample_bkg_ragged_kernel, dim3(total_tiles), dim3(256), 0, st, rn, ncls, cams, g, Smax, geo, zero_unused);
+    EXCEL_CHECK_LAUNCH("cam_upsample_bkg_ragged");
     return EXCEL_OK;
 }

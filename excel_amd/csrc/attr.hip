@@ -64,27 +64,58 @@ __global__ __launch_bounds__(256) void attr_aggregate_kernel(const float* __rest
     for (int c = tid; c < C; c += 256) out[(long long)c * T + t] = agg[c] / nrm;              // :118
 }
 
+// source index / weights of F.interpolate(mode='bilinear'): ATen area_pixel_compute_source_index (align_corners=False:
+// scale*(dst+0.5)-0.5 clamped at 0) and the two-stage blend, in explicit operations so that every kernel using it rounds alike
+struct BilinearTap { int y0, y1, x0, x1; float ly, lx; };
+__device__ __forceinline__ BilinearTap bilinear_tap(int x, int y, int h, int w, int H, int W, int align_corners) {
+    float fy, fx;
+    if (align_corners) {
+        fy = ((H > 1) ? (float)(h - 1) / (float)(H - 1) : 0.f) * (float)y;
+        fx = ((W > 1) ? (float)(w - 1) / (float)(W - 1) : 0.f) * (float)x;
+    } else {
+        fy = fmaxf(__fsub_rn(__fmul_rn((float)h / (float)H, (float)y + 0.5f), 0.5f), 0.f);
+        fx = fmaxf(__fsub_rn(__fmul_rn((float)w / (float)W, (float)x + 0.5f), 0.5f), 0.f);
+    }
+    BilinearTap t;
+    t.y0 = min((int)fy, h - 1); t.x0 = min((int)fx, w - 1);
+    t.y1 = min(t.y0 + 1, h - 1); t.x1 = min(t.x0 + 1, w - 1);
+    t.ly = fy - (float)t.y0; t.lx = fx - (float)t.x0;
+    return t;
+}
+__device__ __forceinline__ float bilinear_blend(const BilinearTap& t, float p00, float p01, float p10, float p11) {
+    const float top = fmaf(t.lx, p01, __fmul_rn(1.f - t.lx, p00));
+    const float bot = fmaf(t.lx, p11, __fmul_rn(1.f - t.lx, p10));
+    return fmaf(t.ly, bot, __fmul_rn(1.f - t.ly, top));
+}
+
 __global__ __launch_bounds__(256) void bilinear_resize_kernel(const float* __restrict__ in, float* __restrict__ out, long long planes,
                                                               int h, int w, int H, int W, int align_corners) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= planes * H * W) return;
     const int x = (int)(i % W), y = (int)((i / W) % H);
     const long long pl = i / ((long long)W * H);
-    float fy, fx;
-    if (align_corners) {
-        fy = ((H > 1) ? (float)(h - 1) / (float)(H - 1) : 0.f) * (float)y;
-        fx = ((W > 1) ? (float)(w - 1) / (float)(W - 1) : 0.f) * (float)x;
-    } else {   // ATen area_pixel_compute_source_index: scale*(dst+0.5)-0.5 clamped at 0
-        fy = fmaxf(((float)h / (float)H) * ((float)y + 0.5f) - 0.5f, 0.f);
-        fx = fmaxf(((float)w / (float)W) * ((float)x + 0.5f) - 0.5f, 0.f);
-    }
-    const int y0 = min((int)fy, h - 1), x0 = min((int)fx, w - 1);
-    const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
-    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const BilinearTap t = bilinear_tap(x, y, h, w, H, W, align_corners);
     const float* p = in + pl * h * w;
-    const float top = (1.f - lx) * p[y0 * w + x0] + lx * p[y0 * w + x1];
-    const float bot = (1.f - lx) * p[y1 * w + x0] + lx * p[y1 * w + x1];
-    out[i] = (1.f - ly) * top + ly * bot;
+    out[i] = bilinear_blend(t, p[t.y0 * w + t.x0], p[t.y0 * w + t.x1], p[t.y1 * w + t.x0], p[t.y1 * w + t.x1]);
+}
+
+// Ragged input side of the harness: decoded uint8 HWC images of different sizes, packed back to back (image b at byte 3 * loff_b),
+// -> transforms.normalize_img (datasets/transforms.py:7-14, double intermediate) -> F.interpolate(bilinear, align_corners=False) to
+// S x S (tools/infer_lam.py:74) -> out [B,3,S,S].  The same operations as excel_normalize_img_u8 followed by excel_bilinear_resize
+// (same bits), without the full-size fp32 intermediate.  grid (cdiv(S*S,256), 3, B)
+__global__ __launch_bounds__(256) void normalize_resize_u8_ragged_kernel(const unsigned char* __restrict__ hwc, float* __restrict__ out,
+                                                                         const int* __restrict__ tab, int S, double m0, double m1, double m2,
+                                                                         double s0, double s1, double s2) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= S * S) return;
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int h = tab[EXCEL_RAG_REC * b], w = tab[EXCEL_RAG_REC * b + 1];
+    const unsigned char* src = hwc + 3ll * tab[EXCEL_RAG_REC * b + 4] + c;
+    const int x = i % S, y = i / S;
+    const BilinearTap t = bilinear_tap(x, y, h, w, S, S, 0);
+    const double m = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+    auto px = [&](int yy, int xx) { return (float)(((double)src[((long long)yy * w + xx) * 3] - m) / sd); };
+    out[((long long)b * 3 + c) * S * S + i] = bilinear_blend(t, px(t.y0, t.x0), px(t.y0, t.x1), px(t.y1, t.x0), px(t.y1, t.x1));
 }
 
 // attr [2B,P,F] (second half computed from horizontally flipped inputs) -> out [B,P,F]:
@@ -295,6 +326,15 @@ int excel_launch_bilinear_resize(const float* in, float* out, long long planes, 
     const long long n = planes * H * W;
     hipLaunchKernelGGL(bilinear_resize_kernel, dim3((unsigned)cdivl(n, 256)), dim3(256), 0, st, in, out, planes, h, w, H, W, align_corners);
     EXCEL_CHECK_LAUNCH("bilinear_resize");
+    return EXCEL_OK;
+}
+
+int excel_launch_normalize_resize_u8_ragged(const unsigned char* hwc, float* out, const TileGeo& geo, int S, const double* mean, const double* stdv,
+                                            hipStream_t st) {
+    ProfScope prof__(PROF_OTHER, st);
+    hipLaunchKernelGGL(normalize_resize_u8_ragged_kernel, dim3(cdiv(S * S, 256), 3, geo.B), dim3(256), 0, st, hwc, out, geo.tab, S, mean[0], mean[1],
+                       mean[2], stdv[0], stdv[1], stdv[2]);
+    EXCEL_CHECK_LAUNCH("normalize_resize_u8_ragged");
     return EXCEL_OK;
 }
 

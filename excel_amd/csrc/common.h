@@ -73,6 +73,54 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
     return base + loc;
 }
 
+// ---------------------------------------------------------------- launch geometry: uniform batch or ragged batch (tile map)
+// Ragged batches (include/excel_hip.h, "ragged batches"): B images of different sizes in one launch.  Planes are PITCHED (row pitch
+// Wp = W rounded up to 4 floats, so every row and plane starts 16-byte aligned), image b of a K-plane tensor starts at element
+// K * poff_b; u8 label maps are tight, image b at loff_b.  Work is cut into 64 x 16 pixel tiles numbered image-major, row-major;
+// `tab` (device, int32) = (B + 1) records of 8 ints {H, W, poff, tile_off, loff, 0, 0, 0} (record B holds the totals) followed by the
+// image index of every tile.  tab == nullptr: a uniform batch of [H, W] planes without padding (Wp = W).
+#define EXCEL_RAG_REC 8
+struct TileGeo {
+    const int* tab;      // ragged table, or nullptr
+    int B;
+    int H, W;            // uniform geometry (tab == nullptr)
+};
+struct Tile {
+    int b, x0, y0, H, W, Wp;
+    long long base;      // element offset of image b in a ONE-plane tensor (multiply by the plane count of the tensor)
+    long long HW;        // plane stride of image b
+    long long lab;       // offset of image b in a tight u8 label tensor
+};
+// blockIdx -> tile.  Uniform launches use grid (cdiv(W,64), cdiv(H,16), B); ragged launches grid.x = total tiles.  All values are
+// wave-uniform (scalar loads / SALU only).
+template <bool RAGGED>
+__device__ __forceinline__ Tile tile_of(const TileGeo& g) {
+    Tile t;
+    if (RAGGED) {
+        const int* __restrict__ tab = g.tab;
+        const int tile = blockIdx.x;
+        t.b = tab[EXCEL_RAG_REC * (g.B + 1) + tile];
+        const int* rec = tab + EXCEL_RAG_REC * t.b;
+        t.H = rec[0]; t.W = rec[1];
+        t.Wp = (t.W + 3) & ~3;
+        t.base = rec[2];
+        t.lab = rec[4];
+        const int loc = tile - rec[3];
+        const int ntx = (t.W + 63) >> 6;
+        const int ty = loc / ntx;
+        t.x0 = (loc - ty * ntx) * 64;
+        t.y0 = ty * 16;
+        t.HW = (long long)t.H * t.Wp;
+    } else {
+        t.b = blockIdx.z; t.x0 = blockIdx.x * 64; t.y0 = blockIdx.y * 16;
+        t.H = g.H; t.W = g.W; t.Wp = g.W;
+        t.HW = (long long)g.H * g.W;
+        t.base = (long long)t.b * t.HW;
+        t.lab = t.base;
+    }
+    return t;
+}
+
 // ---------------------------------------------------------------- optional per-category HIP-event profiling
 // (bench.py enables it to get live per-kernel durations on the launch stream; off by default: zero overhead)
 enum ExcelProfCat {

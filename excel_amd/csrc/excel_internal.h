@@ -74,14 +74,23 @@ int excel_launch_bbox_mask(const float* attr, const int* cls_idx, const int* ncl
                            float* v_out, unsigned char* mask_out, hipStream_t st);
 int excel_launch_matvec(const float* T, const float* v, const int* ncls, float* u, int B, int P, int Smax, hipStream_t st);
 int excel_launch_cam_upsample_bkg(const float* r, const int* ncls, float* rn, float* cams, int B, int g, int Smax, int H, int W,
-                                  hipStream_t st);
-int excel_launch_par_affinity(const float* img, float* aff, int B, int H, int W, const int* dil, int ndil, float w1, float w2,
+                                  int zero_unused, hipStream_t st);
+struct TileGeo;
+int excel_launch_par_affinity(const float* img, float* aff, const TileGeo& geo, int total_tiles, const int* dil, int ndil, float w1, float w2,
                               hipStream_t st, int compact = 0);
-int excel_par_guide_supported(const float* guide, const float* stats, const float* in, const float* out, int H, int W, const int* dil, int ndil);
-int excel_launch_par_iterate_guide(const float* guide, const float* stats, const float* in, float* out, const int* nchan, int B, int Cmax,
-                                   int H, int W, const int* dil, int ndil, float w1, float w2, hipStream_t st);
+int excel_par_guide_supported(const void* guide, const void* stats, const void* in, const void* out, int Cmax, long long max_plane, int Wp,
+                              const int* dil, int ndil);
+int excel_launch_par_iterate_guide(const float* guide, const float* stats, const float* in, float* out, const int* nchan, int Cmax,
+                                   const TileGeo& geo, int total_tiles, const int* dil, int ndil, float w1, float w2, hipStream_t st);
 int excel_launch_par_iterate(const float* aff, const float* in, float* out, const int* nchan, int B, int Cmax, int H, int W,
                              const int* dil, int ndil, hipStream_t st);
+int excel_launch_bilinear_ac_ragged(const float* in, float* out, int h, int w, const TileGeo& geo, int total_tiles, hipStream_t st);
+int excel_launch_argmax_label_ragged(const float* cams, const int* nchan, const int* cls_idx, int Smax, int Cmax, const TileGeo& geo,
+                                     int total_tiles, unsigned char* lab8, hipStream_t st);
+int excel_launch_cam_upsample_bkg_ragged(const float* r, const int* ncls, float* rn, float* cams, int g, int Smax, const TileGeo& geo,
+                                         int total_tiles, int zero_unused, hipStream_t st);
+int excel_launch_normalize_resize_u8_ragged(const unsigned char* hwc, float* out, const TileGeo& geo, int S, const double* mean, const double* stdv,
+                                            hipStream_t st);
 int excel_launch_bilinear_ac(const float* in, float* out, int planes, int h, int w, int H, int W, hipStream_t st);
 int excel_launch_argmax_label(const float* cams, const int* nchan, const int* cls_idx, int B, int Smax, int Cmax, long long HW,
                               unsigned char* lab8, long long* lab64, hipStream_t st);

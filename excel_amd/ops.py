@@ -613,30 +613,130 @@ def refine_cams_with_aff_batched(attr, w_aff, cls_idx, ncls, g, caa_thre=0.79):
     return out
 
 
-def cam_upsample_bkg(refined, ncls, g, H, W):
-    """refined [B,Smax,P] -> cams [B,Smax+1,H,W] (channel 0 background; channels > ncls[b] are zero)."""
+def _out(out, shape, dtype, device, zero=False):
+    """A caller-provided output buffer (the pipeline keeps its buffers across steps: no allocator traffic, no fill launches) or a fresh one."""
+    if out is not None:
+        if tuple(out.shape) != tuple(shape) or out.dtype != dtype or not out.is_contiguous():
+            raise ValueError(f"out= must be a contiguous {dtype} tensor of shape {tuple(shape)}, got {out.dtype} {tuple(out.shape)}")
+        return out
+    return (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=device)
+
+
+def cam_upsample_bkg(refined, ncls, g, H, W, out=None, zero_unused=True):
+    """refined [B,Smax,P] -> cams [B,Smax+1,H,W] (channel 0 background; channels > ncls[b] are zero unless zero_unused=False:
+    nothing on the path reads them)."""
     refined = f32c(refined)
     B, smax, P = refined.shape
-    cams = torch.zeros((B, smax + 1, H, W), dtype=torch.float32, device=refined.device)
+    cams = _out(out, (B, smax + 1, H, W), torch.float32, refined.device)
     ws = _ws(B * smax * P * 4, refined.device)
     check(lib().excel_cam_upsample_bkg(_p(refined), _p(ncls, torch.int32), B, g, smax, H, W, _p(cams), _p(ws, torch.uint8),
-                                       _stream()), "excel_cam_upsample_bkg")
+                                       1 if zero_unused else 0, _stream()), "excel_cam_upsample_bkg")
     return cams
 
 
 # ------------------------------------------------------------------ PAR / labels / metric
-def par_forward(imgs, masks, dilations=PAR_DILATIONS, num_iter=20, nchan=None, w1=0.3, w2=0.01):
+def par_forward(imgs, masks, dilations=PAR_DILATIONS, num_iter=20, nchan=None, w1=0.3, w2=0.01, stream_affinities=False, out=None, ws=None):
+    """stream_affinities: stream the 8*ndil affinity planes instead of recomputing them per step (bit-identical outputs; the
+    reference form of the recomputing kernel, and what shapes / dilation sets outside its envelope use anyway).
+    Channels >= nchan[b] of `out` are not written (zero in a fresh tensor)."""
     imgs = f32c(imgs)
     masks = f32c(masks)
     B, Cmax, H, W = masks.shape
     assert imgs.shape[0] == B and imgs.shape[1] == 3
     h, w = imgs.shape[-2:]
-    out = torch.zeros_like(masks)
+    out = _out(out, masks.shape, torch.float32, masks.device, zero=nchan is not None)
     dil = (C.c_int32 * len(dilations))(*dilations)
-    ws = _ws(lib().excel_par_workspace_bytes(B, Cmax, H, W, len(dilations)), masks.device)
+    need = lib().excel_par_workspace_bytes(B, Cmax, H, W, len(dilations))
+    if ws is None or ws.numel() < need:
+        ws = _ws(need, masks.device)
     check(lib().excel_par_forward(_p(imgs), h, w, _p(masks), _p(nchan, torch.int32), B, Cmax, H, W, dil, len(dilations), num_iter,
-                                  w1, w2, _p(out), _p(ws, torch.uint8), _stream()), "excel_par_forward")
+                                  w1, w2, _p(out), _p(ws, torch.uint8), 1 if stream_affinities else 0, _stream()), "excel_par_forward")
     return out
+
+
+# ------------------------------------------------------------------ ragged batches (images of different label sizes in one launch)
+class RaggedPlan:
+    """Tile map + offsets of a batch of images with different (H_b, W_b) (include/excel_hip.h, "ragged batches").
+    `hw`: sequence of (H, W).  The table is built on the host by the library (excel_ragged_plan) and copied to the device once."""
+
+    def __init__(self, hw, device):
+        import numpy as np
+        hw = np.ascontiguousarray(np.asarray(hw, np.int32).reshape(-1, 2))
+        self.hw = hw
+        self.B = int(hw.shape[0])
+        self.info = _lib.RaggedInfo()
+        ptr = hw.ctypes.data_as(C.POINTER(C.c_int32))
+        check(lib().excel_ragged_plan(ptr, self.B, C.byref(self.info), None), "excel_ragged_plan")
+        table = np.empty(int(self.info.table_ints), np.int32)
+        check(lib().excel_ragged_plan(ptr, self.B, C.byref(self.info), table.ctypes.data_as(C.POINTER(C.c_int32))), "excel_ragged_plan")
+        self.table_host = table
+        rec = table[:8 * (self.B + 1)].reshape(self.B + 1, 8)
+        self.poff = rec[:, 2].astype(np.int64)          # [B+1] element offsets of the images in a one-plane pitched tensor
+        self.loff = rec[:, 4].astype(np.int64)          # [B+1] pixel offsets in a tight u8 map
+        self.total_pix = int(self.info.total_pix)
+        self.total_label_pix = int(self.info.total_label_pix)
+        self.total_tiles = int(self.info.total_tiles)
+        self.table = torch.from_numpy(table).to(device, non_blocking=True) if device is not None else None
+
+    def planes(self, packed, b, K):
+        """View of image b of a packed K-plane pitched tensor: [K, H_b, W_b] (the row padding sliced off)."""
+        H, W = int(self.hw[b, 0]), int(self.hw[b, 1])
+        Wp = (W + 3) // 4 * 4
+        o = K * int(self.poff[b])
+        return packed[o:o + K * H * Wp].view(K, H, Wp)[:, :, :W]
+
+    def label(self, packed_u8, b):
+        H, W = int(self.hw[b, 0]), int(self.hw[b, 1])
+        o = int(self.loff[b])
+        return packed_u8[o:o + H * W].view(H, W)
+
+
+def normalize_resize_u8_ragged(hwc_packed, plan, S, mean=(123.675, 116.28, 103.53), std=(58.395, 57.12, 57.375), out=None):
+    """decoded uint8 HWC images of different sizes, packed back to back -> normalised, bilinearly resized network input [B,3,S,S]
+    (datasets/transforms.normalize_img + tools/infer_lam.py:74)."""
+    if hwc_packed.dtype != torch.uint8 or hwc_packed.numel() != 3 * plan.total_label_pix:
+        raise ValueError(f"hwc_packed must hold {3 * plan.total_label_pix} uint8 values")
+    out = _out(out, (plan.B, 3, S, S), torch.float32, hwc_packed.device)
+    m, s = (C.c_double * 3)(*mean), (C.c_double * 3)(*std)
+    check(lib().excel_normalize_resize_u8_ragged(_p(hwc_packed, torch.uint8), _p(plan.table, torch.int32), plan.B, S, m, s, _p(out), _stream()),
+          "excel_normalize_resize_u8_ragged")
+    return out
+
+
+def cam_upsample_bkg_ragged(refined, ncls, g, plan, out=None, zero_unused=True):
+    """refined [B,Smax,P] -> packed cams: (Smax+1) pitched planes per image at its own (H_b, W_b)."""
+    refined = f32c(refined)
+    B, smax, P = refined.shape
+    assert B == plan.B
+    cams = _out(out, ((smax + 1) * plan.total_pix,), torch.float32, refined.device)
+    ws = _ws(B * smax * P * 4, refined.device)
+    check(lib().excel_cam_upsample_bkg_ragged(_p(refined), _p(ncls, torch.int32), _p(plan.table, torch.int32), C.byref(plan.info), g, smax,
+                                              _p(cams), _p(ws, torch.uint8), 1 if zero_unused else 0, _stream()), "excel_cam_upsample_bkg_ragged")
+    return cams
+
+
+def par_forward_ragged(imgs, masks, plan, Cmax, dilations=PAR_DILATIONS, num_iter=20, nchan=None, w1=0.3, w2=0.01, out=None, ws=None):
+    """imgs [B,3,h,w] (uniform), masks = Cmax pitched planes per image -> refined masks, same layout."""
+    imgs = f32c(imgs)
+    assert imgs.shape[0] == plan.B and imgs.shape[1] == 3 and masks.numel() == Cmax * plan.total_pix
+    h, w = imgs.shape[-2:]
+    out = _out(out, masks.shape, torch.float32, masks.device, zero=True)
+    dil = (C.c_int32 * len(dilations))(*dilations)
+    need = lib().excel_par_ragged_workspace_bytes(plan.total_pix, Cmax)
+    if ws is None or ws.numel() < need:
+        ws = _ws(need, masks.device)
+    check(lib().excel_par_forward_ragged(_p(imgs), h, w, _p(masks), _p(nchan, torch.int32), _p(plan.table, torch.int32), C.byref(plan.info), Cmax,
+                                         dil, len(dilations), num_iter, w1, w2, _p(out), _p(ws, torch.uint8), _stream()), "excel_par_forward_ragged")
+    return out
+
+
+def argmax_label_ragged(cams, plan, Cmax, nchan=None, cls_idx=None, out=None):
+    """packed cams (Cmax pitched planes per image) -> tight uint8 labels [sum H_b*W_b], valid_key lookup applied."""
+    smax = cls_idx.shape[1] if cls_idx is not None else Cmax - 1
+    lab = _out(out, (plan.total_label_pix,), torch.uint8, cams.device)
+    check(lib().excel_argmax_label_ragged(_p(cams), _p(nchan, torch.int32), _p(cls_idx, torch.int32), _p(plan.table, torch.int32), C.byref(plan.info),
+                                          smax, Cmax, _p(lab, torch.uint8), _stream()), "excel_argmax_label_ragged")
+    return lab
 
 
 def argmax_label(cams, nchan=None, cls_idx=None, want_i64=False):
@@ -751,12 +851,6 @@ def dcrf_inference(image_u8, prob, iters, pos_w, pos_xy_std, bi_w, bi_xy_std, bi
     check(lib().excel_dcrf_inference(_p(image_u8, torch.uint8), _p(prob), 1 if is_energy else 0, H, W, Cn, int(iters), float(pos_w), float(pos_xy_std),
                                      float(bi_w), float(bi_xy_std), float(bi_rgb_std), _p(out), _p(ws, torch.uint8), _stream()), "excel_dcrf_inference")
     return out
-
-
-def par_set_mode(mode):
-    """"recompute" (default): PAR affinities recomputed inside every Jacobi step from the guide image + 5 per-pixel statistics;
-    "stream": the 8*ndil affinity planes are streamed from HBM.  Bit-identical outputs (same arithmetic, same order)."""
-    check(lib().excel_par_set_mode({"recompute": 0, "stream": 1}[mode]), "excel_par_set_mode")
 
 
 def prof_collect():

@@ -21,10 +21,22 @@ class TrainingFreePipeline:
         self.caa_thre = caa_thre
         self.smax = smax
         self.hist = None
+        self._bufs = {}
 
     def reset(self):
         self.drain()
         self.hist = None
+
+    def _buf(self, name, numel, dtype=torch.float32, device=None):
+        """Step-persistent scratch (cams, PAR output, PAR workspace): one grow-only flat buffer per (name, launch stream), so a step
+        allocates nothing and launches no fill kernels.  Only buffers nobody outside the step keeps are taken from here."""
+        key = (name, torch.cuda.current_stream().cuda_stream)
+        b = self._bufs.get(key)
+        if b is None or b.numel() < numel or b.dtype != dtype:
+            self._bufs.pop(key, None)
+            b = None
+            b = self._bufs[key] = torch.empty(int(numel), dtype=dtype, device=device)
+        return b[:int(numel)]
 
     @torch.no_grad()
     def run_batch(self, inputs, cls_labels, gts=None, label_hw=None, return_intermediates=False):
@@ -36,13 +48,54 @@ class TrainingFreePipeline:
         _, _, attr, attn_w, _ = self.model(inputs)                                                  # infer_lam.py:79
         idx, ncls, nchan = ops.cls_compact(cls_labels, self.smax, want_nchan=True)                  # affutils.py:203
         refined = ops.refine_cams_with_aff_batched(attr, attn_w.w_aff, idx, ncls, g, self.caa_thre)  # infer_lam.py:93
-        cams = ops.cam_upsample_bkg(refined, ncls, g, H, W)                                         # affutils.py:164-166
-        par_out = ops.par_forward(inputs, cams, self.dilations, self.num_iter, nchan=nchan)        # affutils.py:84
+        C = self.smax + 1
+        if return_intermediates:            # the caller keeps these: fresh tensors, unused channels zeroed
+            cams = ops.cam_upsample_bkg(refined, ncls, g, H, W)                                     # affutils.py:164-166
+            par_out = ops.par_forward(inputs, cams, self.dilations, self.num_iter, nchan=nchan)    # affutils.py:84
+        else:
+            dev = inputs.device
+            cams = ops.cam_upsample_bkg(refined, ncls, g, H, W, out=self._buf("cams", B * C * H * W, device=dev).view(B, C, H, W),
+                                        zero_unused=False)
+            ws = self._buf("par_ws", ops.lib().excel_par_workspace_bytes(B, C, H, W, len(self.dilations)), torch.uint8, dev)
+            par_out = ops.par_forward(inputs, cams, self.dilations, self.num_iter, nchan=nchan, ws=ws,
+                                      out=self._buf("par_out", B * C * H * W, device=dev).view(B, C, H, W))
         labels = ops.argmax_label(par_out, nchan, idx)                                              # affutils.py:86-87
         if gts is not None:
             self.hist = ops.confusion_accumulate(gts, labels, self.num_classes, self.hist)          # evaluate.py:9-20
         if return_intermediates:
             return labels, dict(attr=attr, w_aff=attn_w.w_aff, refined=refined, cams=cams, par_out=par_out,
+                                cls_idx=idx, ncls=ncls)
+        return labels
+
+    # ------------------------------------------------------------------ ragged batches: every image at its OWN label size
+    # The reference resizes the input to S x S but refines and scores at the image's original size (tools/infer_lam.py:74,94:
+    # labels.shape[-2:]), batch 1.  Here the size-uniform half (ViT, CAM, random walk) runs as one batch as before, and the
+    # size-dependent half (input resize, up-sampling, PAR, arg-max) runs over packed, pitched planes through a tile map
+    # (ops.RaggedPlan; include/excel_hip.h "ragged batches"): one launch per stage whatever the mix of sizes.
+    @torch.no_grad()
+    def run_batch_ragged(self, hwc_packed, plan, cls_labels, gts_packed=None, S=448, return_intermediates=False):
+        """hwc_packed: the decoded uint8 [H_b,W_b,3] images back to back (device); plan = ops.RaggedPlan of their sizes;
+        cls_labels [B,F] f32 one-hot; gts_packed: the uint8 [H_b,W_b] ground-truth maps back to back (255 = ignore) or None.
+        Returns the labels as one flat uint8 tensor (image b = plan.label(labels, b))."""
+        dev = hwc_packed.device
+        B = plan.B
+        g = S // 16
+        inputs = ops.normalize_resize_u8_ragged(hwc_packed, plan, S, out=self._buf("inputs", B * 3 * S * S, device=dev).view(B, 3, S, S))  # voc.py:115, infer_lam.py:74
+        _, _, attr, attn_w, _ = self.model(inputs)                                                  # infer_lam.py:79
+        idx, ncls, nchan = ops.cls_compact(cls_labels, self.smax, want_nchan=True)                  # affutils.py:203
+        refined = ops.refine_cams_with_aff_batched(attr, attn_w.w_aff, idx, ncls, g, self.caa_thre)  # infer_lam.py:93
+        C = self.smax + 1
+        keep = return_intermediates
+        cams = ops.cam_upsample_bkg_ragged(refined, ncls, g, plan, zero_unused=keep,
+                                           out=None if keep else self._buf("cams", C * plan.total_pix, device=dev))   # affutils.py:164-166
+        ws = self._buf("par_ws", ops.lib().excel_par_ragged_workspace_bytes(plan.total_pix, C), torch.uint8, dev)
+        par_out = ops.par_forward_ragged(inputs, cams, plan, C, self.dilations, self.num_iter, nchan=nchan, ws=ws,
+                                         out=None if keep else self._buf("par_out", C * plan.total_pix, device=dev))   # affutils.py:84
+        labels = ops.argmax_label_ragged(par_out, plan, C, nchan, idx)                              # affutils.py:86-87
+        if gts_packed is not None:
+            self.hist = ops.confusion_accumulate(gts_packed, labels, self.num_classes, self.hist)   # evaluate.py:9-20
+        if return_intermediates:
+            return labels, dict(inputs=inputs.clone(), attr=attr, w_aff=attn_w.w_aff, refined=refined, cams=cams, par_out=par_out,
                                 cls_idx=idx, ncls=ncls)
         return labels
 

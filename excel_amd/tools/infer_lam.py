@@ -2,7 +2,11 @@
 
 Differences from the reference, all deliberate:
   * batches of B > 1 images run through the device-resident TrainingFreePipeline (the reference is batch 1 with
-    per-class host round trips); `--api_path` runs the reference's per-image call sequence instead;
+    per-class host round trips); `--api_path` runs the reference's per-image call sequence instead.  Real data (`--data_folder`:
+    every image has its own size, and the path refines and scores at that size, :74,:94) and `--ragged true` synthetic data run
+    as RAGGED batches: background worker processes decode whole batches (`--num_workers`, the reference's DataLoader workers, :167),
+    the device resizes every image to the network size and runs the size-dependent half (up-sampling, PAR, arg-max) over packed
+    planes through a tile map - one launch per stage for any mix of sizes (pipeline.run_batch_ragged);
   * ranks take images r, r+R, ... exactly like :166, accumulate a device-side [nc,nc] int64 confusion matrix and
     exchange it ONCE with an all_gather over RCCL (the reference scores each shard separately and never aggregates);
   * weights: `--model` is a CLIP checkpoint path or a model name found under --clip_root / $EXCEL_CLIP_ROOT / ~/.cache/clip
@@ -58,6 +62,8 @@ def get_parser():
     p.add_argument("--synthetic", default=64, type=int, help="number of seeded synthetic samples")
     p.add_argument("--seed", default=1234, type=int)
     p.add_argument("--api_path", default=False, type=_bool, help="per-image reference call sequence instead of the batched pipeline")
+    p.add_argument("--ragged", default=False, type=_bool, help="synthetic samples with VOC-like, per-image sizes (uint8 images), fed as ragged batches like real data")
+    p.add_argument("--num_workers", default=8, type=int, help="background decode processes of the ragged path (the reference's DataLoader uses 2, :167); 0 = decode in the loop")
     p.add_argument("--clip_root", default=None, type=str, help="directory holding the published CLIP archive (ViT-B-16.pt); default $EXCEL_CLIP_ROOT, ~/.cache/clip")
     p.add_argument("--bpe_path", default=None, type=str, help="CLIP's bpe_simple_vocab_16e6.txt.gz (default $EXCEL_BPE_VOCAB)")
     p.add_argument("--gemm_mode", default=None, type=str, help="bf16x3 (default) | f32")
@@ -113,7 +119,28 @@ def build_validation(model=None, par=None, dataset=None, indices=None, device="c
     hist = torch.zeros((args.num_classes, args.num_classes), dtype=torch.int64, device=device)
     t0 = time.time()
     nimg = 0
-    bs = 1 if args.api_path else args.batch_size
+    training_free = bool(getattr(args, "training_free", True))
+    per_image = args.api_path or not training_free
+    if getattr(args, "ragged_batches", False) and not per_image:
+        # every sample at its own size: decode in background workers, everything else on the device, one launch per stage
+        from ..datasets.loader import ragged_batches
+        from ..utils import imutils
+        pipe.hist = hist
+        keep = bool(getattr(args, "crf_post", False))
+        for rb in ragged_batches(dataset, indices, args.batch_size, num_workers=int(getattr(args, "num_workers", 2))):
+            plan = ops.RaggedPlan(rb.hw, device)
+            out = pipe.run_batch_ragged(rb.images.to(device, non_blocking=True), plan, rb.cls.to(device, non_blocking=True),
+                                        rb.labels.to(device, non_blocking=True), S=S, return_intermediates=keep)
+            if keep:                                                                        # :116-119 record for the CRF stage
+                inter = out[1]
+                cls_idx, ncls = inter["cls_idx"].cpu().numpy(), inter["ncls"].cpu().numpy()
+                for b, name in enumerate(rb.names):
+                    k = int(ncls[b])
+                    imutils.save_logits(args.logits_dir, name, plan.planes(inter["cams"], b, pipe.smax + 1)[:k + 1], cls_idx[b, :k].astype(np.int64))
+            nimg += len(rb)
+        torch.cuda.synchronize()
+        return pipe.hist, nimg, time.time() - t0
+    bs = 1 if per_image else args.batch_size
     for s in range(0, len(indices), bs):
         names, imgs, gts, cls = dataset.batch(indices[s:s + bs])
         inputs = torch.from_numpy(imgs).to(device, non_blocking=True)
@@ -123,8 +150,7 @@ def build_validation(model=None, par=None, dataset=None, indices=None, device="c
             inputs = ops.bilinear_resize(inputs, S, S, align_corners=False)                 # :74
         cls_labels = torch.from_numpy(cls).to(device, non_blocking=True)
         gt_dev = torch.from_numpy(gts).to(device, non_blocking=True)
-        training_free = bool(getattr(args, "training_free", True))
-        if args.api_path or not training_free:
+        if per_image:
             if training_free:
                 _, _, attr_maps_raw, attn_weights, attn_pred = model(inputs)                # :79
             else:
@@ -218,7 +244,11 @@ def crf_proc(args, rank=0, world=1, device="cuda"):
     hist = torch.zeros((args.num_classes, args.num_classes), dtype=torch.int64, device=device)
     for i in shard_indices(len(name_list), rank, world):
         name = name_list[i]
-        lams, keys = imutils.load_logits(os.path.join(args.logits_dir, name + ".npy"))      # :203-206
+        rec = os.path.join(args.logits_dir, name + ".npy")
+        if not os.path.isfile(rec) or os.path.getmtime(rec) < getattr(args, "run_started", 0.0) - 1.0:
+            raise RuntimeError(f"crf_proc: {rec} was not written by this run (missing or stale): the CRF stage scores the records of the "
+                               "main loop (tools/infer_lam.py:116-119), never those of an earlier one")
+        lams, keys = imutils.load_logits(rec)                                               # :203-206
         image = np.asarray(Image.open(os.path.join(images_path, name + ".jpg")).convert("RGB")).astype(np.uint8)   # :209-210, :220
         if "test" in args.infer_set:
             label = image[:, :, 0]                                                          # :213-214
@@ -247,13 +277,15 @@ def validate(args=None):
     if world > 1 and not dist.is_initialized():
         dist.init_process_group(backend=args.backend)                                       # :133
     device = torch.device("cuda", args.local_rank)
+    args.run_started = time.time()
     if getattr(args, "data_folder", None):
-        from ..datasets import voc                                                          # :156-163 (variable image sizes -> batch 1, :167)
+        from ..datasets import voc                                                          # :156-163: every image has its own size
         dataset = voc.VOC12SegDataset(root_dir=args.data_folder, name_list_dir=args.list_folder, split=args.infer_set, stage="val")
-        args.batch_size = 1
+        args.ragged_batches = True
     else:
-        dataset = synthetic.SyntheticSegDataset(args.synthetic, (args.resize_size, args.resize_size),
-                                                num_classes=args.num_classes, seed=args.seed, u8_images=getattr(args, "u8_input", False))
+        args.ragged_batches = bool(getattr(args, "ragged", False))
+        dataset = synthetic.SyntheticSegDataset(args.synthetic, (args.resize_size, args.resize_size), num_classes=args.num_classes,
+                                                seed=args.seed, u8_images=getattr(args, "u8_input", False), ragged=args.ragged_batches)
     model = ExCEL_model(clip_model=args.model, embedding_dim=args.embedding_dim, in_channels=args.in_channels,
                         dataset_name=args.dataset_name, num_classes=args.num_classes, num_atrr_clusters=args.num_attri,
                         json_file=args.attr_json, img_size=args.resize_size, mode=args.infer_set, device=device,

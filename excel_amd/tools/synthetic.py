@@ -60,14 +60,32 @@ def draw_k(rs, hist=VOC_K_HIST):
     return int(rs.choice(ks, p=p / p.sum()))
 
 
+# Image sizes of a VOC-like data set: PASCAL VOC images have their longer side at 500; most are 500 x 375 (landscape) or 375 x 500
+# (portrait), the rest varies.  (H, W, weight) - the last entry draws a uniform random size with the longer side at 500.
+VOC_LIKE_SIZES = [(375, 500, 0.55), (500, 375, 0.17), (333, 500, 0.10), (500, 333, 0.04), (334, 500, 0.03), (374, 500, 0.03), (None, None, 0.08)]
+
+
+def draw_voc_like_size(rs):
+    r, acc = rs.rand(), 0.0
+    for h, w, p in VOC_LIKE_SIZES:
+        acc += p
+        if r < acc and h is not None:
+            return h, w
+    short = int(rs.randint(180, 501))
+    return (short, 500) if rs.rand() < 0.7 else (500, short)
+
+
 class SyntheticSegDataset:
     """Index -> (name, image [3,h,w] f32, label [H,W] u8, cls_label [F] f32), like VOC12SegDataset.__getitem__
     (datasets/voc.py:212-230).  Every sample is generated from its own seed, so shards are order independent."""
 
-    def __init__(self, n, image_hw=(448, 448), label_hw=None, num_classes=21, seed=1234, fixed_k=None, u8_images=False):
+    def __init__(self, n, image_hw=(448, 448), label_hw=None, num_classes=21, seed=1234, fixed_k=None, u8_images=False, ragged=False):
         """u8_images: samples carry the DECODED image (uint8 [h,w,3], what imageio.imread returns, datasets/voc.py:52) instead of
-        the normalised float tensor; the harness then normalises on the device (ops.normalize_img_u8)."""
-        self.u8_images = u8_images
+        the normalised float tensor; the harness then normalises on the device (ops.normalize_img_u8).
+        ragged: every sample has its own VOC-like size (draw_voc_like_size; image and label of one size, uint8 images) - what real
+        VOC data looks like to the harness (image_hw / label_hw are ignored)."""
+        self.u8_images = u8_images or ragged
+        self.ragged = ragged
         self.n = n
         self.image_hw = tuple(image_hw)
         self.label_hw = tuple(label_hw or image_hw)
@@ -81,14 +99,31 @@ class SyntheticSegDataset:
     def max_k(self):
         return self.fixed_k or max(VOC_K_HIST)
 
+    def size_of(self, i):
+        """(H, W) of sample i without generating it."""
+        if not self.ragged:
+            return self.label_hw
+        return draw_voc_like_size(np.random.RandomState((self.seed * 7919 + 31 * i + 5) % (2 ** 31 - 1)))
+
     def __getitem__(self, i):
         rs = np.random.RandomState((self.seed * 1000003 + i) % (2 ** 31 - 1))
         F = self.num_classes - 1
-        img = rs.standard_normal((3,) + self.image_hw).astype(np.float32)
-        if self.u8_images:
-            img = np.clip(img.transpose(1, 2, 0) * 58.0 + 116.0, 0, 255).astype(np.uint8)      # same stream of random numbers
-        gt = rs.randint(0, self.num_classes, self.label_hw).astype(np.uint8)
-        gt[rs.rand(*self.label_hw) < 0.02] = 255
+        image_hw = label_hw = self.size_of(i) if self.ragged else None
+        if not self.ragged:
+            image_hw, label_hw = self.image_hw, self.label_hw
+        if self.ragged:
+            # smooth-ish content (a coarse random field, up-sampled) + noise: JPEG-like statistics at a fraction of the cost of
+            # drawing h*w*3 normals per sample
+            h, w = image_hw
+            coarse = rs.randint(0, 256, (h // 8 + 2, w // 8 + 2, 3)).astype(np.int16)
+            img = np.repeat(np.repeat(coarse, 8, 0), 8, 1)[:h, :w]
+            img = np.clip(img + rs.randint(-24, 25, (h, w, 1)), 0, 255).astype(np.uint8)
+        else:
+            img = rs.standard_normal((3,) + image_hw).astype(np.float32)
+            if self.u8_images:
+                img = np.clip(img.transpose(1, 2, 0) * 58.0 + 116.0, 0, 255).astype(np.uint8)      # same stream of random numbers
+        gt = rs.randint(0, self.num_classes, label_hw).astype(np.uint8)
+        gt[rs.rand(*label_hw) < 0.02] = 255
         k = self.fixed_k or draw_k(rs)
         cls = np.zeros(F, np.float32)
         cls[rs.choice(F, size=k, replace=False)] = 1

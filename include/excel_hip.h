@@ -289,23 +289,26 @@ int excel_refine_cams_with_aff(const float* attr, const float* w_aff, const int3
 
 /* generate_cam_label/scale_cam_image + background channel (utils/affutils.py:55-78, :164-166):
  *   refined [B,Smax,P] -> cams [B,Smax+1,H,W]: channel 0 = 1 - max_c, channels 1..ncls[b] = min-max normalised,
- *   bilinearly (cv2.resize INTER_LINEAR rule) up-sampled maps.  workspace: B*Smax*P floats. */
+ *   bilinearly (cv2.resize INTER_LINEAR rule) up-sampled maps.  workspace: B*Smax*P floats.
+ *   flags: EXCEL_CAMS_ZERO_UNUSED = also write zeros to channels ncls[b]+1..Smax (nothing on the path reads them). */
+#define EXCEL_CAMS_ZERO_UNUSED 1
 int excel_cam_upsample_bkg(const float* refined, const int32_t* ncls, int B, int g, int Smax, int H, int W, float* cams,
-                           void* workspace, void* stream);
+                           void* workspace, int flags, void* stream);
 
 /* ------------------------------------------------------------------ PAR + labels + metric */
 
 /* PAR.forward (utils/PAR.py:64-92): imgs [B,3,h,w], masks [B,Cmax,H,W] -> out [B,Cmax,H,W] after n_iter steps.
  * nchan (optional) [B]: only channels < nchan[b] of image b are refined (ragged class counts).
- * workspace: excel_par_workspace_bytes (aff planes + ping-pong + resized guide). */
+ * workspace: excel_par_workspace_bytes (aff planes + ping-pong + resized guide).
+ * Affinities: by default the 8*ndil weights of a pixel are recomputed inside every Jacobi step from the guide image and 5 per-pixel
+ * statistics (20 B/pixel instead of 192 B/pixel of HBM traffic per step) where the tiled kernel applies (dilations [1,2,4,8,12,24] -
+ * the only set the reference uses: tools/infer_lam.py:168 - W % 4 == 0, 16-byte aligned buffers); otherwise, or with
+ * flags & EXCEL_PAR_STREAM_AFFINITIES, they are streamed as planes.  Same arithmetic in the same order: the outputs are bit-identical. */
+#define EXCEL_PAR_STREAM_AFFINITIES 1
 size_t excel_par_workspace_bytes(int B, int Cmax, int H, int W, int ndil);
 int excel_par_forward(const float* imgs, int h, int w, const float* masks, const int32_t* nchan, int B, int Cmax, int H, int W,
                       const int32_t* dilations /*host*/, int ndil, int n_iter, float w1, float w2, float* out,
-                      void* workspace, void* stream);
-/* PAR affinities: mode 0 (default) recomputes the 8*ndil weights of a pixel inside every Jacobi step from the guide image and 5
- * per-pixel statistics (20 B/pixel instead of 192 B/pixel of HBM traffic per step); mode 1 streams them as planes.  Same arithmetic
- * in the same order: the outputs are bit-identical.  Process-wide. */
-int excel_par_set_mode(int mode);
+                      void* workspace, int flags, void* stream);
 
 /* refined.argmax(1) -> valid_key lookup (utils/affutils.py:86-87, :168).  cls_idx may be NULL (identity keys). */
 int excel_argmax_label(const float* cams, const int32_t* nchan, const int32_t* cls_idx, int B, int Smax, int Cmax,
@@ -313,6 +316,48 @@ int excel_argmax_label(const float* cams, const int32_t* nchan, const int32_t* c
 
 /* _fast_hist accumulated on device (utils/evaluate.py:9-20): hist[nc*gt+pred] += 1 for gt < nc; hist is int64 [nc*nc]. */
 int excel_confusion_accumulate(const uint8_t* gt, const uint8_t* pred, long long n, int num_classes, int64_t* hist, void* stream);
+
+/* ------------------------------------------------------------------ ragged batches: B images of DIFFERENT label sizes in one launch
+ * The reference evaluates at every image's own label size (tools/infer_lam.py:74,94: the input is resized to S x S, everything after
+ * the random walk runs at labels.shape[-2:]) with batch 1; these entry points run the size-dependent half of the path (input resize,
+ * CAM up-sampling, PAR, arg-max) for a whole batch at once.  The ViT / CAM / random-walk half is size-uniform (S x S) already.
+ *
+ * Layout ("pitched planes"): image b has H_b x W_b pixels; rows are padded to Wp_b = W_b rounded up to 4 floats, a plane is
+ * H_b * Wp_b floats; image b of a K-plane fp32 tensor starts at element K * poff_b (poff_b = sum_{i<b} H_i * Wp_i) with its planes
+ * back to back.  uint8 maps (decoded HWC images, ground truth, labels) are TIGHT: image b at pixel loff_b = sum_{i<b} H_i * W_i, so
+ * excel_confusion_accumulate runs over the flat label arrays unchanged.  Work is cut into 64 x 16 pixel tiles, numbered image-major.
+ * excel_ragged_plan (a HOST function: no device work) fills `info` and, when `table` != NULL, the int32 table the kernels read:
+ *   (B+1) records of 8 ints {H, W, poff, tile_off, loff, 0, 0, 0} (record B = totals), then the image index of every tile;
+ * the caller copies `table` (info->table_ints int32) to the device.  Offsets are 32-bit: total padded pixels < 2^31. */
+typedef struct {
+    int32_t B, total_tiles;
+    int64_t total_pix;         /* sum H_b * Wp_b: elements of a one-plane pitched tensor */
+    int64_t total_label_pix;   /* sum H_b * W_b:  elements of a tight u8 map */
+    int64_t max_plane_pix;     /* max H_b * Wp_b */
+    int64_t table_ints;
+} excel_ragged_info;
+int excel_ragged_plan(const int32_t* hw /*host [B,2] = (H_b, W_b)*/, int B, excel_ragged_info* info /*host*/, int32_t* table /*host or NULL*/);
+
+/* datasets/transforms.normalize_img + HWC->CHW + the harness' input resize (tools/infer_lam.py:74: F.interpolate bilinear,
+ * align_corners=False, no antialias) for decoded images of different sizes: hwc = the uint8 [H_b,W_b,3] images back to back
+ * (image b at byte 3 * loff_b) -> out [B,3,S,S] f32.  Same operations (same bits) as excel_normalize_img_u8 + excel_bilinear_resize. */
+int excel_normalize_resize_u8_ragged(const uint8_t* hwc, const int32_t* table, int B, int S, const double* mean3 /*host*/,
+                                     const double* std3 /*host*/, float* out, void* stream);
+
+/* excel_cam_upsample_bkg for a ragged batch: refined [B,Smax,P] -> cams = (Smax+1) pitched planes per image. workspace: B*Smax*P floats. */
+int excel_cam_upsample_bkg_ragged(const float* refined, const int32_t* ncls, const int32_t* table, const excel_ragged_info* info, int g,
+                                  int Smax, float* cams, void* workspace, int flags, void* stream);
+
+/* PAR.forward for a ragged batch: imgs [B,3,h,w] (the uniform network input; resized per image with align_corners=True like
+ * PAR.py:67), masks / out = Cmax pitched planes per image.  Dilations must be [1,2,4,8,12,24] (the recomputing kernel). */
+size_t excel_par_ragged_workspace_bytes(long long total_pix, int Cmax);
+int excel_par_forward_ragged(const float* imgs, int h, int w, const float* masks, const int32_t* nchan, const int32_t* table,
+                             const excel_ragged_info* info, int Cmax, const int32_t* dilations /*host*/, int ndil, int n_iter, float w1,
+                             float w2, float* out, void* workspace, void* stream);
+
+/* excel_argmax_label for a ragged batch: cams = Cmax pitched planes per image -> tight uint8 labels (info->total_label_pix). */
+int excel_argmax_label_ragged(const float* cams, const int32_t* nchan, const int32_t* cls_idx, const int32_t* table,
+                              const excel_ragged_info* info, int Smax, int Cmax, uint8_t* labels_u8, void* stream);
 
 /* ------------------------------------------------------------------ one-time / auxiliary */
 

@@ -427,26 +427,127 @@ def test_confusion(ops, nc, n):
 
 
 @pytest.mark.parametrize("B,C,H,W,dil,it", [(2, 3, 64, 80, (1, 2, 4, 8, 12, 24), 5), (1, 7, 96, 96, (1, 2, 4, 8, 12, 24), 20),
-                                            (3, 2, 50, 36, (1, 2, 4, 8), 3), (2, 4, 448, 448, (1, 2, 4, 8, 12, 24), 2)])
+                                            (3, 2, 52, 36, (1, 2, 4, 8, 12, 24), 3), (2, 4, 448, 448, (1, 2, 4, 8, 12, 24), 2)])
 def test_par_recompute_equals_streamed_affinities(ops, B, C, H, W, dil, it):
     """The default PAR step recomputes its 48 weights per pixel from the guide image and 5 per-pixel statistics (same operations in
-    the same order as the affinity kernel); streaming the 48 planes must give the SAME BITS, ragged channel counts included."""
+    the same order as the affinity kernel); streaming the 48 planes (a per-call flag) must give the SAME BITS, ragged channel counts
+    included."""
     rs = np.random.RandomState(H + C)
     img = dev(rs.standard_normal((B, 3, H, W)).astype(np.float32))
     masks = dev(rs.rand(B, C, H, W).astype(np.float32))
     nchan = dev(np.array([max(1, C - b) for b in range(B)], np.int32))
-    try:
-        ops.par_set_mode("stream")
-        ref = ops.par_forward(img, masks, dil, it, nchan=nchan)
-        ops.par_set_mode("recompute")
-        got = ops.par_forward(img, masks, dil, it, nchan=nchan)
-    finally:
-        ops.par_set_mode("recompute")
+    ref = ops.par_forward(img, masks, dil, it, nchan=nchan, stream_affinities=True)
+    got = ops.par_forward(img, masks, dil, it, nchan=nchan)
     for b in range(B):
         k = int(host(nchan)[b])
         assert torch.equal(got[b, :k], ref[b, :k])
     lo = oracle.par.PAR(list(dil), it)(host(img)[:1], host(masks)[:1, :int(host(nchan)[0])])
     assert maxabs(host(got)[0, :int(host(nchan)[0])], lo[0]) < 2e-4
+
+
+def test_par_other_dilation_sets_use_the_streamed_kernel(ops):
+    """Dilation sets other than the reference's [1,2,4,8,12,24] (1..8 entries, any values) go through the streamed-plane kernel."""
+    rs = np.random.RandomState(9)
+    img = rs.standard_normal((2, 3, 33, 47)).astype(np.float32)
+    masks = rs.rand(2, 3, 33, 47).astype(np.float32)
+    for dil in ((1, 2, 4, 8), (3,), (1, 2, 3, 5, 6, 7, 9, 11)):
+        ref = oracle.par.PAR(list(dil), 3)(img, masks)
+        assert maxabs(host(ops.par_forward(dev(img), dev(masks), dil, 3)), ref) < 5e-5
+
+
+# ------------------------------------------------------------------ ragged batches (images of different label sizes in one launch)
+RAGGED_SIZES = [(375, 500), (500, 375), (333, 500), (96, 64), (17, 29), (448, 448), (500, 334), (281, 500)]
+
+
+def _pack_planes(plan, arrs, K):
+    """list of [K,H,W] arrays -> packed pitched float tensor (padding columns filled with NaN: nothing may read them as data)."""
+    out = np.full(K * plan.total_pix, np.nan, np.float32)
+    for b, a in enumerate(arrs):
+        H, W = a.shape[-2:]
+        Wp = (W + 3) // 4 * 4
+        v = out[K * plan.poff[b]:K * plan.poff[b] + K * H * Wp].reshape(K, H, Wp)
+        v[:, :, :W] = a
+    return out
+
+
+def test_ragged_plan_matches_the_documented_layout(ops):
+    plan = ops.RaggedPlan(RAGGED_SIZES, "cuda")
+    rec = plan.table_host[:8 * (plan.B + 1)].reshape(-1, 8)
+    pix = lab = tiles = 0
+    for b, (H, W) in enumerate(RAGGED_SIZES):
+        assert tuple(rec[b, :5]) == (H, W, pix, tiles, lab)
+        nt = -(-W // 64) * -(-H // 16)
+        assert np.all(plan.table_host[8 * (plan.B + 1) + tiles:8 * (plan.B + 1) + tiles + nt] == b)
+        pix += H * ((W + 3) // 4 * 4); lab += H * W; tiles += nt
+    assert (plan.total_pix, plan.total_label_pix, plan.total_tiles) == (pix, lab, tiles)
+    assert tuple(rec[plan.B, 2:5]) == (pix, tiles, lab)
+
+
+def test_ragged_normalize_resize_equals_two_step(ops):
+    """excel_normalize_resize_u8_ragged == excel_normalize_img_u8 + excel_bilinear_resize per image, bit for bit; and the oracle."""
+    rs = np.random.RandomState(4)
+    imgs = [rs.randint(0, 256, (H, W, 3)).astype(np.uint8) for H, W in RAGGED_SIZES]
+    plan = ops.RaggedPlan(RAGGED_SIZES, "cuda")
+    packed = dev(np.concatenate([im.reshape(-1) for im in imgs]))
+    S = 128
+    got = ops.normalize_resize_u8_ragged(packed, plan, S)
+    for b, im in enumerate(imgs):
+        two = ops.bilinear_resize(ops.normalize_img_u8(dev(im[None])), S, S, align_corners=False)
+        assert torch.equal(got[b], two[0])
+    mean, std = np.array([123.675, 116.28, 103.53]), np.array([58.395, 57.12, 57.375])
+    x = ((imgs[0].astype(np.float64) - mean) / std).astype(np.float32).transpose(2, 0, 1)
+    ref = torch.nn.functional.interpolate(torch.from_numpy(x)[None], size=(S, S), mode="bilinear", align_corners=False)[0].numpy()
+    assert maxabs(host(got[0]), ref) < 2e-5
+
+
+def test_ragged_upsample_par_argmax_equal_per_image_calls(ops):
+    """The ragged entry points (cam_upsample_bkg / PAR / arg-max over packed, pitched planes of 8 different sizes, odd widths included)
+    give the SAME BITS as the uniform entry points called per image - streamed-plane PAR included for widths that are not multiples
+    of 4 - and the confusion matrix over the flat label arrays equals the sum of the per-image ones."""
+    rs = np.random.RandomState(11)
+    B, smax, g, S = len(RAGGED_SIZES), 3, 8, 128
+    plan = ops.RaggedPlan(RAGGED_SIZES, "cuda")
+    refined = dev(rs.rand(B, smax, g * g).astype(np.float32))
+    onehot = np.zeros((B, 20), np.float32)
+    for b in range(B):
+        onehot[b, rs.choice(20, 1 + b % smax, replace=False)] = 1
+    idx, ncls, nchan = ops.cls_compact(dev(onehot), smax, want_nchan=True)
+    imgs = dev(rs.standard_normal((B, 3, S, S)).astype(np.float32))
+    gts = [rs.randint(0, 21, hw).astype(np.uint8) for hw in RAGGED_SIZES]
+    gt_packed = dev(np.concatenate([x.reshape(-1) for x in gts]))
+    cams = ops.cam_upsample_bkg_ragged(refined, ncls, g, plan)
+    par = ops.par_forward_ragged(imgs, cams, plan, smax + 1, num_iter=3, nchan=nchan)
+    lab = ops.argmax_label_ragged(par, plan, smax + 1, nchan, idx)
+    hist = ops.confusion_accumulate(gt_packed, lab, 21)
+    hist_ref = None
+    for b, (H, W) in enumerate(RAGGED_SIZES):
+        k = int(host(nchan)[b])
+        c1 = ops.cam_upsample_bkg(refined[b:b + 1], ncls[b:b + 1], g, H, W)
+        assert torch.equal(plan.planes(cams, b, smax + 1)[:k], c1[0, :k])
+        p1 = ops.par_forward(imgs[b:b + 1], c1, num_iter=3, nchan=nchan[b:b + 1])
+        assert torch.equal(plan.planes(par, b, smax + 1)[:k], p1[0, :k]), (H, W)
+        l1 = ops.argmax_label(p1, nchan[b:b + 1], idx[b:b + 1])
+        assert torch.equal(plan.label(lab, b), l1[0])
+        hist_ref = ops.confusion_accumulate(dev(gts[b]), l1[0], 21, hist_ref)
+    assert torch.equal(hist, hist_ref)
+    # ... and the oracle, on the smallest image
+    b = 4
+    k = int(host(nchan)[b])
+    ref = oracle.par.PAR([1, 2, 4, 8, 12, 24], 3)(host(imgs[b:b + 1]), host(plan.planes(cams, b, smax + 1))[None, :k])
+    assert maxabs(host(plan.planes(par, b, smax + 1))[:k], ref[0]) < 5e-5
+
+
+def test_ragged_par_ignores_row_padding(ops):
+    """The padding columns of the pitched layout are never read as data: NaN there must not reach a pixel."""
+    rs = np.random.RandomState(12)
+    sizes = [(40, 30), (33, 61), (64, 64)]
+    plan = ops.RaggedPlan(sizes, "cuda")
+    masks = [rs.rand(2, H, W).astype(np.float32) for H, W in sizes]
+    imgs = dev(rs.standard_normal((3, 3, 32, 32)).astype(np.float32))
+    out = ops.par_forward_ragged(imgs, dev(_pack_planes(plan, masks, 2)), plan, 2, num_iter=2)
+    for b, (H, W) in enumerate(sizes):
+        ref = ops.par_forward(imgs[b:b + 1], dev(masks[b][None]), num_iter=2)
+        assert torch.equal(plan.planes(out, b, 2), ref[0])
 
 
 @pytest.mark.parametrize("H,W,C,params", [(24, 30, 3, (10, 3, 1, 4, 67, 3)), (37, 29, 5, (5, 3, 3, 10, 80, 13)), (50, 64, 2, (10, 3, 1, 4, 67, 3))])
@@ -608,7 +709,7 @@ def test_abi_error_conventions(ops):
     assert rc < 0 and b"multiple of 4" in L.excel_last_error()
     # null pointers
     assert L.excel_compute_trans_mat(None, 1, 36, a.data_ptr(), a.data_ptr(), st) < 0
-    assert L.excel_par_forward(None, 8, 8, None, None, 1, 1, 8, 8, (C.c_int32 * 1)(1), 1, 1, 0.3, 0.01, None, None, st) < 0
+    assert L.excel_par_forward(None, 8, 8, None, None, 1, 1, 8, 8, (C.c_int32 * 1)(1), 1, 1, 0.3, 0.01, None, None, 0, st) < 0
     # bad layer range
     assert L.excel_attn_layer_mean(a.data_ptr(), 2, 1, 4, 1, 5, a.data_ptr(), st) < 0 and b"layer" in L.excel_last_error()
     # a good call after failures returns 0 (errors are not sticky)

@@ -847,6 +847,127 @@ def test_infer_lam_on_disk_voc(gpu, tmp_path):
     assert np.mean(np.all(rgb_png == imutils.encode_cmap(ref_lab), axis=-1)) > 0.995
 
 
+RAGGED_HW = [(60, 80), (75, 50), (33, 47), (96, 96), (50, 64), (41, 30)]
+
+
+def _ragged_samples(seed=5, num_fg=4):
+    rs = np.random.RandomState(seed)
+    imgs = [rs.randint(0, 256, (h, w, 3)).astype(np.uint8) for h, w in RAGGED_HW]
+    gts = []
+    for h, w in RAGGED_HW:
+        gt = rs.randint(0, num_fg + 1, (h, w)).astype(np.uint8)
+        gt[rs.rand(h, w) < 0.03] = 255
+        gts.append(gt)
+    cls = np.zeros((len(RAGGED_HW), num_fg), np.float32)
+    for b in range(len(RAGGED_HW)):
+        cls[b, rs.choice(num_fg, size=1 + b % 3, replace=False)] = 1
+    return imgs, gts, cls
+
+
+@pytest.mark.parametrize("gemm_mode", ["f32", "bf16x3"])
+def test_ragged_batch_equals_per_image_api_and_oracle(gpu, gemm_mode):
+    """ONE ragged batch of 6 images with 6 different label sizes (tools/infer_lam.py:74,94: the input is resized to S x S, the path
+    refines and scores at labels.shape[-2:]) through pipeline.run_batch_ragged: labels and confusion matrix equal the per-image API
+    path (the reference's call sequence, batch 1) BIT FOR BIT, and the oracle at the label budget of the mode."""
+    from excel_amd import ops
+    from excel_amd.pipeline import TrainingFreePipeline
+    from excel_amd.utils.affutils import refine_cams_with_aff, refine_cams_with_bkg_weclip
+    from excel_amd.utils.PAR import PAR
+    S, F_ = 96, 4
+    rs = np.random.RandomState(3)
+    text = rs.standard_normal((9, 64)).astype(np.float32)
+    text /= np.linalg.norm(text, axis=1, keepdims=True)
+    model, w = tiny_model(text.T.copy(), gemm_mode=gemm_mode)
+    imgs, gts, cls = _ragged_samples()
+    plan = ops.RaggedPlan(RAGGED_HW, "cuda")
+    pipe = TrainingFreePipeline(model, num_classes=F_ + 1, smax=3)
+    lab = pipe.run_batch_ragged(dev(np.concatenate([i.reshape(-1) for i in imgs])), plan, dev(cls),
+                                dev(np.concatenate([g.reshape(-1) for g in gts])), S=S)
+    hist = host(pipe.hist)
+    par = PAR(num_iter=20, dilations=[1, 2, 4, 8, 12, 24])
+    opar = oracle.par.PAR([1, 2, 4, 8, 12, 24], 20)
+    wo = oracle.vit.reload_self_attn(w, TINY, S // 16, "train")
+    mean, std = np.array([123.675, 116.28, 103.53]), np.array([58.395, 57.12, 57.375])
+    ref_hist = np.zeros((F_ + 1, F_ + 1), np.int64)
+    for b, (h, wd) in enumerate(RAGGED_HW):
+        x = ops.bilinear_resize(ops.normalize_img_u8(dev(imgs[b][None])), S, S, align_corners=False)          # voc.py:115-116, infer_lam.py:74
+        _, _, attr, attn, _ = model(x)                                                                           # :79
+        refined, cls_lst = refine_cams_with_aff(attr[0], attn[:, 0], dev(cls[b]), size=(S, S), caa_thre=0.79)   # :93
+        l1, _ = refine_cams_with_bkg_weclip(refined, x[0], cls_lst, par, (h, wd))                                # :94
+        mine = host(plan.label(lab, b))
+        assert np.array_equal(mine, host(l1[0]).astype(np.uint8)), (b, int((mine != host(l1[0])).sum()))
+        ref_hist += oracle.evaluate.fast_hist(gts[b].flatten(), mine.flatten(), F_ + 1)
+        xin = ((imgs[b].astype(np.float64) - mean) / std).astype(np.float32).transpose(2, 0, 1)
+        r = oracle.pipeline.run_sample(xin, cls[b], (h, wd), wo, TINY, text.T.copy(), F_, opar, S)
+        assert int((mine != r).sum()) <= _label_budget(r.size, gemm_mode), (b, int((mine != r).sum()), r.size)
+    assert np.array_equal(hist, ref_hist)
+
+
+def _write_voc_tree(tmp_path, sizes, seed=3):
+    from PIL import Image
+    from excel_amd.utils import imutils
+    root, lists = tmp_path / "VOC2012", tmp_path / "lists"
+    (root / "JPEGImages").mkdir(parents=True)
+    (root / "SegmentationClassAug").mkdir()
+    lists.mkdir()
+    rs = np.random.RandomState(seed)
+    ids, onehot, npix = [], {}, 0
+    for k, (h, w) in enumerate(sizes):
+        name = f"2008_{k:06d}"
+        ids.append(name)
+        coarse = rs.randint(0, 256, (h // 8 + 2, w // 8 + 2, 3)).astype(np.uint8)
+        Image.fromarray(np.repeat(np.repeat(coarse, 8, 0), 8, 1)[:h, :w]).save(root / "JPEGImages" / (name + ".jpg"), quality=90)
+        lab = rs.randint(0, 21, (h, w)).astype(np.uint8)
+        lab[:2] = 255
+        npix += int((lab < 21).sum())
+        im = Image.fromarray(lab, mode="P")
+        im.putpalette(imutils.colormap().flatten().tolist())
+        im.save(root / "SegmentationClassAug" / (name + ".png"))
+        oh = np.zeros(20, np.float32)
+        oh[[k % 20, (3 * k + 7) % 20]] = 1
+        onehot[name] = oh
+    (lists / "val.txt").write_text("\n".join(ids) + "\n")
+    np.save(lists / "cls_labels_onehot.npy", onehot)
+    return root, lists, ids, npix
+
+
+def test_infer_lam_data_folder_runs_ragged_batches_of_32(gpu, tmp_path):
+    """`infer_lam --data_folder` over an on-disk VOC tree of 40 images with 7 different sizes at --batch_size 32 (2 ragged batches,
+    background decode workers): the aggregated confusion matrix equals the per-image API path's exactly; --crf_post on the batched
+    path writes this run's records (it used to read records that were never written) and refuses stale ones."""
+    from _clip_files import write_tiny_clip
+    from excel_amd.tools import infer_lam
+    from excel_amd.utils import imutils
+    sizes = [(90 + 7 * (k % 7), 120 - 9 * (k % 5)) for k in range(40)]
+    root, lists, ids, npix = _write_voc_tree(tmp_path, sizes)
+    ckpt, bpe_path, _ = write_tiny_clip(tmp_path)
+    common = ["--data_folder", str(root), "--list_folder", str(lists), "--infer_set", "val", "--resize_size", "128", "--model", ckpt,
+              "--bpe_path", bpe_path, "--batch_size", "32", "--num_workers", "2"]
+    score, total = infer_lam.validate(infer_lam.get_parser().parse_args(common))
+    assert int(host(total).sum()) == npix and 0.0 <= score["miou"] <= 1.0
+    score1, total1 = infer_lam.validate(infer_lam.get_parser().parse_args(common + ["--api_path", "true"]))
+    assert np.array_equal(host(total), host(total1))
+    # CRF stage on the batched path: records of THIS run, one per image, cams [k+1,h,w] + keys
+    logits = tmp_path / "logits"
+    crf = common + ["--crf_post", "true", "--logits_dir", str(logits)]
+    infer_lam.validate(infer_lam.get_parser().parse_args(crf))
+    crf_score, crf_total = infer_lam.validate.last_crf
+    assert int(host(crf_total).sum()) == npix
+    lam, keys = imutils.load_logits(str(logits / (ids[5] + ".npy")))
+    assert lam.shape == (3,) + sizes[5] and list(keys) == sorted([5 % 20, (3 * 5 + 7) % 20])
+    lam1, keys1 = None, None
+    infer_lam.validate(infer_lam.get_parser().parse_args(crf + ["--api_path", "true", "--logits_dir", str(tmp_path / "logits_api")]))
+    lam1, keys1 = imutils.load_logits(str(tmp_path / "logits_api" / (ids[5] + ".npy")))
+    assert np.array_equal(lam, lam1) and list(keys) == list(keys1)
+    # a stale record (older than the run) is refused instead of being scored
+    import os
+    import time
+    args = infer_lam.get_parser().parse_args(crf)
+    args.run_started = time.time() + 3600
+    with pytest.raises(RuntimeError, match="stale"):
+        infer_lam.crf_proc(args, 0, 1, "cuda")
+
+
 @pytest.mark.parametrize("gemm_mode", ["f32", "bf16x3"])
 @pytest.mark.parametrize("case", range(6))
 def test_random_shapes_soak_vs_oracle(gpu, case, gemm_mode):

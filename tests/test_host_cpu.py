@@ -38,6 +38,26 @@ def test_header_symbols_exported_and_bound():
     assert lib.excel_prof_num_categories() >= 10
 
 
+def test_ragged_plan_is_a_host_function():
+    """excel_ragged_plan builds the tile map of a ragged batch without touching a device (include/excel_hip.h, "ragged batches")."""
+    from excel_amd import ops
+    sizes = [(375, 500), (500, 333), (1, 1), (16, 64), (17, 65)]
+    plan = ops.RaggedPlan(sizes, None)
+    rec = plan.table_host[:8 * 6].reshape(6, 8)
+    assert [tuple(r[:2]) for r in rec[:5]] == sizes
+    tiles = [-(-w // 64) * -(-h // 16) for h, w in sizes]
+    assert tiles == [24 * 8, 32 * 6, 1, 1, 4]
+    assert list(rec[:, 3]) == list(np.concatenate([[0], np.cumsum(tiles)]))
+    assert list(rec[:, 2]) == list(np.concatenate([[0], np.cumsum([h * ((w + 3) // 4 * 4) for h, w in sizes])]))
+    assert list(rec[:, 4]) == list(np.concatenate([[0], np.cumsum([h * w for h, w in sizes])]))
+    tile_img = plan.table_host[8 * 6:]
+    assert len(tile_img) == sum(tiles) == plan.total_tiles
+    assert np.array_equal(tile_img, np.repeat(np.arange(5), tiles))
+    assert plan.info.max_plane_pix == 375 * 500
+    with pytest.raises(RuntimeError, match="size"):
+        ops.RaggedPlan([(0, 5)], None)
+
+
 def test_product_fails_loudly_without_gpu():
     """No CPU fallback: handing CPU tensors to an op raises instead of silently computing elsewhere."""
     from excel_amd import ops
