@@ -21,7 +21,7 @@ extern "C" int excel_abi_version(void) { return 2; }
 
 // ------------------------------------------------------------------------------------ profiling hooks
 bool g_excel_prof_on = false;
-int g_excel_prof_gemm_cat = -1;
+thread_local int g_excel_prof_gemm_cat = -1;    // per host thread: concurrent forwards on different threads do not race on it
 unsigned long long g_excel_prof_mask = ~0ull;
 int g_excel_prof_every = 1;
 unsigned g_excel_prof_seen[PROF_NCAT];
@@ -480,7 +480,7 @@ static int vit_forward_impl(excel_vit_t h, const float* img, int B, int S, void*
         float* attn_l = (n_attn_out && l >= L - n_attn_out) ? attn_out + (size_t)(l - (L - n_attn_out)) * B * N * N : nullptr;
         // bf16x3 mode: the strip-resident kernel (attn_strip.hip) owns the softmax statistics of q.q / k.k / v.v and of the
         // q.k weights, so the row pass only runs its flash part (attention output of the original path)
-        const bool strip = bf && N <= 40 * 32;
+        const bool strip = bf && excel_attn_strip_supported(N);
         TRY(excel_launch_attn_rowpass(ws.qkvh, ws.ao, ws.stats, B, H, N, 64, scale, (surgery && !strip) ? 4 : 1, st, bf, qkvs,
                                       cls_only ? 1 : (1 << 30), bf ? (const unsigned short*)ws.vt : nullptr, ws.KP));
         if (surgery || in_aff || attn_l) {

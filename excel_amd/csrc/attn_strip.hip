@@ -380,13 +380,15 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
 }
 
 // Strip-resident accumulate pass; returns EXCEL_ERR_ARG-free "not applicable" (1) when the shape does not fit (caller falls back).
+bool excel_attn_strip_supported(int N) { return cdiv(N, 32) <= 40; }       // 8 waves x 5 key tiles: beyond that the two-pass kernels run
+
 int excel_launch_attn_strip(const unsigned short* qkvs, unsigned short* a_sum, float* w_aff, float* attn_out, int B, int H, int N,
                             int KP, int hd, float scale, int surgery, float w_scale, float aff_scale, int aff_init, const float* ex_attn,
                             hipStream_t st) {
     EXCEL_CHECK_ARG(hd == 64, "attention: head_dim must be 64 (got %d)", hd);
     EXCEL_CHECK_ARG(qkvs && (!surgery || (a_sum && KP == cdiv(N, 32) * 32)), "attn_strip: bad a_sum/KP");
     const int ntiles = cdiv(N, 32);
-    if (ntiles > 40) return 1;                                  // > 8 waves x 5 tiles: not resident, use the two-pass kernels
+    EXCEL_CHECK_ARG(excel_attn_strip_supported(N), "attn_strip: N=%d exceeds the strip-resident envelope (ask excel_attn_strip_supported)", N);
     ProfScope prof__(PROF_ATTN_ACCUM, st);
     const int ntw = cdiv(ntiles, 8);
     const int nw = cdiv(ntiles, ntw);                          // 25 tiles: 7 waves x (4,4,4,4,3,3,3)

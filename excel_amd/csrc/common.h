@@ -128,7 +128,7 @@ enum ExcelProfCat {
     PROF_CAM_EPILOGUE, PROF_SINKHORN, PROF_BBOX, PROF_MATVEC, PROF_UPSAMPLE, PROF_PAR_AFFINITY, PROF_PAR_ITERATE,
     PROF_ARGMAX, PROF_CONFUSION, PROF_OTHER, PROF_CAM_PROJ, PROF_CAM_FUSED, PROF_NCAT
 };
-extern int g_excel_prof_gemm_cat;               // >= 0: the next GEMM launches are booked under this category (the CAM's projection GEMM)
+extern thread_local int g_excel_prof_gemm_cat;               // >= 0: the next GEMM launches are booked under this category (the CAM's projection GEMM)
 extern bool g_excel_prof_on;
 extern unsigned long long g_excel_prof_mask;   // bit c set: category c is bracketed with events
 extern int g_excel_prof_every;                 // bracket every n-th launch of a category (an event pair costs ~10 us of GPU idle)

@@ -61,6 +61,8 @@ int excel_launch_attn_rowpass(const float* qkvh, float* out, float* stats, int B
 int excel_launch_attn_accum(const float* qkvh, const float* stats, float* a_sum, float* w_aff, float* attn_out, int B, int H,
                             int N, int NP, int hd, float scale, int surgery, float w_scale, float aff_scale, int aff_init,
                             hipStream_t st, const unsigned short* qkvs = nullptr, int a_sum_split = 0, const float* ex_attn = nullptr);
+// the strip-resident kernel keeps 32 query rows x ALL keys of an image in registers: at most 8 waves x 5 key tiles of 32
+bool excel_attn_strip_supported(int N);
 int excel_launch_attn_strip(const unsigned short* qkvs, unsigned short* a_sum, float* w_aff, float* attn_out, int B, int H, int N,
                             int KP, int hd, float scale, int surgery, float w_scale, float aff_scale, int aff_init, const float* ex_attn,
                             hipStream_t st);

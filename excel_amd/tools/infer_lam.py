@@ -67,6 +67,7 @@ def get_parser():
     p.add_argument("--clip_root", default=None, type=str, help="directory holding the published CLIP archive (ViT-B-16.pt); default $EXCEL_CLIP_ROOT, ~/.cache/clip")
     p.add_argument("--bpe_path", default=None, type=str, help="CLIP's bpe_simple_vocab_16e6.txt.gz (default $EXCEL_BPE_VOCAB)")
     p.add_argument("--gemm_mode", default=None, type=str, help="bf16x3 (default) | f32")
+    p.add_argument("--json_out", default=None, type=str, help="rank 0 writes a one-line JSON record of the run here (rate, ranks, per-rank mass)")
     return p
 
 
@@ -107,15 +108,17 @@ def format_scores_table(score, cat_list, metric_names=("confusion", "precision",
 
 
 # ------------------------------------------------------------------ the loop
-def build_validation(model=None, par=None, dataset=None, indices=None, device="cuda", args=None):
+def build_validation(model=None, par=None, dataset=None, indices=None, device="cuda", args=None, pipe=None):
     """-> (hist [nc,nc] int64 on device, images processed, seconds).  Mirrors :63-128."""
     from ..pipeline import TrainingFreePipeline
     from ..utils import evaluate
     from ..utils.affutils import refine_cams_with_aff, refine_cams_with_bkg_weclip
     from .. import ops
     S = args.resize_size
-    pipe = TrainingFreePipeline(model, num_classes=args.num_classes, dilations=par.dilations, num_iter=par.num_iter,
-                                caa_thre=0.79, smax=dataset.max_k())
+    on_gpu = torch.device(device).type == "cuda"
+    if pipe is None:
+        pipe = TrainingFreePipeline(model, num_classes=args.num_classes, dilations=par.dilations, num_iter=par.num_iter,
+                                    caa_thre=0.79, smax=dataset.max_k())
     hist = torch.zeros((args.num_classes, args.num_classes), dtype=torch.int64, device=device)
     t0 = time.time()
     nimg = 0
@@ -138,7 +141,8 @@ def build_validation(model=None, par=None, dataset=None, indices=None, device="c
                     k = int(ncls[b])
                     imutils.save_logits(args.logits_dir, name, plan.planes(inter["cams"], b, pipe.smax + 1)[:k + 1], cls_idx[b, :k].astype(np.int64))
             nimg += len(rb)
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
         return pipe.hist, nimg, time.time() - t0
     bs = 1 if per_image else args.batch_size
     for s in range(0, len(indices), bs):
@@ -266,19 +270,25 @@ def crf_proc(args, rank=0, world=1, device="cuda"):
     return evaluate.scores_from_hist(total), total                                          # :233
 
 
-def validate(args=None):
-    from ..model.model_excel import ExCEL_model
+def validate(args=None, dataset=None, pipe=None):
+    """tools/infer_lam.py:130-176.  `dataset` / `pipe` are injection points for the multi-rank control-flow tests (a stub pipeline on
+    CPU tensors over gloo): with `pipe` given no model is built and the device is pipe.device; the product path passes neither."""
     from ..utils import evaluate
     from ..utils.PAR import PAR
     from . import synthetic
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
-    torch.cuda.set_device(args.local_rank)
+    if pipe is None:
+        torch.cuda.set_device(args.local_rank)
+        device = torch.device("cuda", args.local_rank)
+    else:
+        device = torch.device(pipe.device)
     if world > 1 and not dist.is_initialized():
         dist.init_process_group(backend=args.backend)                                       # :133
-    device = torch.device("cuda", args.local_rank)
     args.run_started = time.time()
-    if getattr(args, "data_folder", None):
+    if dataset is not None:
+        args.ragged_batches = True
+    elif getattr(args, "data_folder", None):
         from ..datasets import voc                                                          # :156-163: every image has its own size
         dataset = voc.VOC12SegDataset(root_dir=args.data_folder, name_list_dir=args.list_folder, split=args.infer_set, stage="val")
         args.ragged_batches = True
@@ -286,20 +296,33 @@ def validate(args=None):
         args.ragged_batches = bool(getattr(args, "ragged", False))
         dataset = synthetic.SyntheticSegDataset(args.synthetic, (args.resize_size, args.resize_size), num_classes=args.num_classes,
                                                 seed=args.seed, u8_images=getattr(args, "u8_input", False), ragged=args.ragged_batches)
-    model = ExCEL_model(clip_model=args.model, embedding_dim=args.embedding_dim, in_channels=args.in_channels,
-                        dataset_name=args.dataset_name, num_classes=args.num_classes, num_atrr_clusters=args.num_attri,
-                        json_file=args.attr_json, img_size=args.resize_size, mode=args.infer_set, device=device,
-                        gemm_mode=getattr(args, "gemm_mode", None), **resolve_model_inputs(args))
+    model = None
+    if pipe is None:
+        from ..model.model_excel import ExCEL_model
+        model = ExCEL_model(clip_model=args.model, embedding_dim=args.embedding_dim, in_channels=args.in_channels,
+                            dataset_name=args.dataset_name, num_classes=args.num_classes, num_atrr_clusters=args.num_attri,
+                            json_file=args.attr_json, img_size=args.resize_size, mode=args.infer_set, device=device,
+                            gemm_mode=getattr(args, "gemm_mode", None), **resolve_model_inputs(args))
     par = PAR(num_iter=20, dilations=[1, 2, 4, 8, 12, 24])                                  # :168
     idx = shard_indices(len(dataset), rank, world)                                          # :166
-    hist, nimg, secs = build_validation(model, par, dataset, idx, device, args)
+    hist, nimg, secs = build_validation(model, par, dataset, idx, device, args, pipe=pipe)
     validate.last_model = model                                                             # handle for callers / tests
     per_rank, total = gather_hists(hist)
+    validate.last_per_rank = per_rank
     score = evaluate.scores_from_hist(total)
     if rank == 0:
         logging.info(f"Training_free:{args.training_free}, LAM_score:")
         logging.info("\n" + format_scores_table(score, VOC_CLASSES))
         logging.info(f"mIoU {score['miou'] * 100:.3f}  images {int(nimg) * world}  ({nimg / secs:.1f} img/s/rank)")
+        if getattr(args, "json_out", None):
+            # one self-checking record per run (tools_dev/scale.sh): wall time, rate and every rank's scored-pixel mass
+            import json
+            with open(args.json_out, "w") as f:
+                json.dump({"world": world, "rccl_ranks": int(dist.get_world_size()) if world > 1 else 1, "images_rank0": int(nimg),
+                           "images_total": int(len(dataset)), "seconds_rank0": round(secs, 3), "images_per_s_rank0": round(nimg / secs, 2),
+                           "images_per_s_job": round(len(dataset) / secs, 2), "miou": float(score["miou"]),
+                           "per_rank_hist_mass": [int(x) for x in per_rank.reshape(per_rank.shape[0], -1).sum(1).tolist()],
+                           "batch_size": args.batch_size, "ragged": bool(args.ragged_batches), "resize_size": args.resize_size}, f)
     if getattr(args, "crf_post", False) and getattr(args, "data_folder", None):             # :173-174
         crf_score, crf_total = crf_proc(args, rank, world, device)
         validate.last_crf = (crf_score, crf_total)

@@ -133,3 +133,32 @@ class SyntheticSegDataset:
         items = [self[i] for i in indices]
         return ([it[0] for it in items], np.stack([it[1] for it in items]), np.stack([it[2] for it in items]),
                 np.stack([it[3] for it in items]))
+
+
+def write_voc_tree(root, lists, n, seed=1234, split="train", num_classes=21, quality=90):
+    """Write `n` ragged synthetic samples as an on-disk PASCAL-VOC-format tree (what datasets/voc.VOC12SegDataset reads):
+    <root>/JPEGImages/<id>.jpg, <root>/SegmentationClassAug/<id>.png (palette PNG, 255 = ignore), <lists>/<split>.txt and
+    <lists>/cls_labels_onehot.npy (pickled {id: one-hot[20]}).  -> (ids, number of scored pixels)."""
+    import os
+    from PIL import Image
+    from ..utils import imutils
+    os.makedirs(os.path.join(root, "JPEGImages"), exist_ok=True)
+    os.makedirs(os.path.join(root, "SegmentationClassAug"), exist_ok=True)
+    os.makedirs(lists, exist_ok=True)
+    ds = SyntheticSegDataset(n, num_classes=num_classes, seed=seed, ragged=True)
+    palette = imutils.colormap().flatten().tolist()
+    ids, onehot, npix = [], {}, 0
+    for i in range(n):
+        name, img, gt, cls = ds[i]
+        name = "2008_%06d" % i
+        ids.append(name)
+        Image.fromarray(img).save(os.path.join(root, "JPEGImages", name + ".jpg"), quality=quality)
+        im = Image.fromarray(gt, mode="P")
+        im.putpalette(palette)
+        im.save(os.path.join(root, "SegmentationClassAug", name + ".png"))
+        onehot[name] = cls
+        npix += int((gt < num_classes).sum())
+    with open(os.path.join(lists, split + ".txt"), "w") as f:
+        f.write("\n".join(ids) + "\n")
+    np.save(os.path.join(lists, "cls_labels_onehot.npy"), onehot)
+    return ids, npix

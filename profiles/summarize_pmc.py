@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Fold rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (csv output) into per-kernel fabric bytes per launch.
-Usage: summarize_pmc.py fetch_counter_collection.csv write_counter_collection.csv > hbm_traffic.json
+Usage: summarize_pmc.py fetch_counter_collection.csv write_counter_collection.csv [head] > hbm_traffic.json
 
 bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KB; FETCH_SIZE is doubled per
 /opt/skills/guides/MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced read).  Infinity-Cache hits are counted,
@@ -29,7 +29,17 @@ def fold(path, counter):
     return acc
 
 
-def main(fetch_csv, write_csv):
+def source_stamp(head):
+    """Which code the counters were collected on: git head (as given), date, and the sha of the kernel sources (bench.py compares it)."""
+    import datetime
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from bench import csrc_sha16
+    return {"head": head, "date": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"), "csrc_sha16": csrc_sha16(),
+            "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace -- python bench.py --steps 2 --warmup 1 --cpu-images 0 --ragged-images 0"}
+
+
+def main(fetch_csv, write_csv, head=None):
     fe, wr = fold(fetch_csv, "FETCH_SIZE"), fold(write_csv, "WRITE_SIZE")
     out = {}
     for k in sorted(set(fe) | set(wr)):
@@ -44,8 +54,8 @@ def main(fetch_csv, write_csv):
         n = sum(v["launches"] for v in ks)
         if n:        # launch-weighted mean over the template instances of one bench category
             top[cat + "_bytes_per_launch"] = int(sum(v["bytes_per_launch"] * v["launches"] for v in ks) / n)
-    print(json.dumps({**top, "_note": __doc__.split("\n\n")[1].replace("\n", " "), "kernels": out}, indent=1))
+    print(json.dumps({**top, "_source": source_stamp(head), "_note": __doc__.split("\n\n")[1].replace("\n", " "), "kernels": out}, indent=1))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else None)

@@ -207,6 +207,85 @@ def test_sharded_confusion_allgather_world2():
         assert np.array_equal(per_rank.sum(0), ref)
 
 
+class _TinyRaggedSet:
+    """(name, image u8 [h,w,3], label u8 [h,w], cls f32 [20]) with a different size per sample."""
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def max_k(self):
+        return 2
+
+    def __getitem__(self, i):
+        rs = np.random.RandomState(500 + i)
+        h, w = 5 + i % 7, 4 + (3 * i) % 5
+        gt = rs.randint(0, 21, (h, w)).astype(np.uint8)
+        gt[rs.rand(h, w) < 0.1] = 255
+        cls = np.zeros(20, np.float32)
+        cls[i % 20] = 1
+        return f"s{i:03d}", rs.randint(0, 256, (h, w, 3)).astype(np.uint8), gt, cls
+
+
+class _StubPipe:
+    """Stands in for TrainingFreePipeline in the control-flow test: `labels` = a deterministic function of the image bytes."""
+    device, smax = "cpu", 2
+
+    def __init__(self):
+        self.hist, self.batches = None, []
+
+    def run_batch_ragged(self, images, plan, cls, gts, S=448, return_intermediates=False):
+        assert images.numel() == 3 * plan.total_label_pix and gts.numel() == plan.total_label_pix and cls.shape[0] == plan.B
+        pred = (images.view(-1, 3)[:, 0].to(torch.int64) % 21).numpy()
+        self.hist += torch.from_numpy(oracle.evaluate.fast_hist(gts.numpy(), pred, 21))
+        self.batches.append(plan.B)
+        return torch.from_numpy(pred.astype(np.uint8))
+
+
+def _validate_worker(rank, world, port, n, bs, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from excel_amd.tools import infer_lam
+    args = infer_lam.get_parser().parse_args(["--batch_size", str(bs), "--num_workers", "0", "--backend", "gloo"])
+    pipe = _StubPipe()
+    score, total = infer_lam.validate(args, dataset=_TinyRaggedSet(n), pipe=pipe)
+    q.put((rank, pipe.batches, infer_lam.validate.last_per_rank.numpy(), total.numpy(), float(score["miou"])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_validate_control_flow_world4_uneven_tail():
+    """tools/infer_lam.validate's own control flow (rank-strided shards :166, ragged batches, last partial batch, ONE all_gather) on
+    4 gloo ranks with an uneven tail - 46 = 4 * 11 + 2 samples, batch 5: ranks 0,1 run 12 images (5+5+2), ranks 2,3 run 11 (5+5+1),
+    like 10 582 = 8 * 1 322 + 6 on the 8-GPU node - through a stub pipeline: every rank ends with the matrix of ALL samples."""
+    import torch.multiprocessing as mp
+    n, world, bs = 46, 4, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_validate_worker, args=(r, world, port, n, bs, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r for r in [q.get(timeout=180) for _ in range(world)]}
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    ds = _TinyRaggedSet(n)
+    per_sample = []
+    for i in range(n):
+        _, img, gt, _ = ds[i]
+        per_sample.append(oracle.evaluate.fast_hist(gt.flatten(), img.reshape(-1, 3)[:, 0].astype(np.int64) % 21, 21))
+    ref = np.sum(per_sample, 0)
+    for rank in range(world):
+        _, batches, per_rank, total, miou = res[rank]
+        assert batches == ([5, 5, 2] if rank < 2 else [5, 5, 1])
+        assert np.array_equal(total, ref)
+        for r in range(world):
+            assert np.array_equal(per_rank[r], np.sum(per_sample[r::world], 0))
+        assert abs(miou - oracle.evaluate.scores_from_hist(ref)["miou"]) < 1e-12
+
+
 def test_gather_hists_single_process_identity():
     from excel_amd.tools.infer_lam import gather_hists
     h = torch.arange(9, dtype=torch.int64).reshape(3, 3)

@@ -18,13 +18,19 @@ for N in 1 2 4 8; do
   fi
   tail -c 400 "$OUT/bench_n$N.json"; echo
 done
-# configs[3]: VOC train_aug-sized evaluation (10 582 images, rank r takes r, r+R, ...; one RCCL all-gather of the confusion matrix)
-N=$MAXN
-python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port $((PORT + 20)) \
-    -m excel_amd.tools.infer_lam --synthetic 10582 --batch_size 32 --resize_size 448 > "$OUT/infer_lam_voc_n$N.log" 2>&1
-tail -3 "$OUT/infer_lam_voc_n$N.log"
+# configs[3]: VOC train_aug-sized evaluation (10 582 images with VOC-like per-image sizes - ragged batches of 32, background decode
+# workers -, rank r takes r, r+R, ...; one RCCL all-gather of the confusion matrix); one JSON record per N with wall time, img/s and
+# the gathered per-rank mass (a rank that did not run shows as a zero)
+for N in 1 2 4 8; do
+  [ "$N" -gt "$MAXN" ] && break
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port $((PORT + 20 + N)) \
+      -m excel_amd.tools.infer_lam --synthetic 10582 --ragged true --batch_size 32 --num_workers 12 --resize_size 448 \
+      --json_out "$OUT/infer_lam_voc_n$N.json" > "$OUT/infer_lam_voc_n$N.log" 2>&1
+  cat "$OUT/infer_lam_voc_n$N.json"; echo
+done
 # configs[4]: COCO-shaped (81 classes, 512x512, batch 16)
-python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port $((PORT + 21)) \
+N=$MAXN
+python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port $((PORT + 40)) \
     -m excel_amd.tools.infer_lam --synthetic 4999 --batch_size 16 --resize_size 512 --num_classes 81 --dataset_name ms_coco --num_attri 224 \
-    > "$OUT/infer_lam_coco_n$N.log" 2>&1
-tail -3 "$OUT/infer_lam_coco_n$N.log"
+    --json_out "$OUT/infer_lam_coco_n$N.json" > "$OUT/infer_lam_coco_n$N.log" 2>&1
+cat "$OUT/infer_lam_coco_n$N.json"; echo
