@@ -576,22 +576,31 @@ extern "C" int excel_clip_feature_surgery(const float* image_features, const flo
     return excel_launch_cam_epilogue(S, out_full, out_slice, B, N, T, ldT, F, temperature, ST(stream));
 }
 
-// Fused path (cam.hip: patch_text_cam_kernel): token-axis norm + similarity on the matrix core + surgery epilogue in one launch,
-// straight from the un-normalised token features excel_vit_forward returns as x_raw.
-extern "C" size_t excel_patch_text_cam_workspace_bytes(int B, int N, int C, int T) {
-    return align_up((size_t)B * N * ((T + 3) / 4 * 4) * sizeof(float), 256) + align_up((size_t)T * C * sizeof(float), 256);
+// Fused path (cam.hip): token-axis norm + similarity on the matrix core + surgery epilogue, straight from the un-normalised token
+// features excel_vit_forward returns as x_raw (+ their token-axis sums of squares x_colsq when the forward produced them).
+struct PtcWs { float *sim, *part, *colsq; unsigned short* ts; size_t total; };
+static PtcWs ptc_ws_layout(int B, int N, int C, int T, char* base) {
+    PtcWs w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base + off; off += align_up(bytes, 256); return p; };
+    w.sim = (float*)take(excel_patch_text_cam_ws_floats(B, N, C, T, 0) * sizeof(float));
+    w.ts = (unsigned short*)take((size_t)T * C * sizeof(float));
+    w.part = (float*)take(excel_patch_text_cam_ws_floats(B, N, C, T, 1) * sizeof(float));
+    w.colsq = (float*)take(excel_patch_text_cam_ws_floats(B, N, C, T, 2) * sizeof(float));
+    w.total = off;
+    return w;
 }
+extern "C" size_t excel_patch_text_cam_workspace_bytes(int B, int N, int C, int T) { return ptc_ws_layout(B, N, C, T, nullptr).total; }
 
 extern "C" int excel_patch_text_cam(const float* x_raw, const float* text, int B, int N, int C, int T, int F, float temperature, int mode,
                                     float* out_full, float* out_slice, float* image_features, void* workspace, void* stream) {
     EXCEL_CHECK_ARG(x_raw && text && workspace && (out_full || out_slice), "patch_text_cam: null argument");
     EXCEL_CHECK_ARG(mode == 0 || mode == 1, "patch_text_cam: mode must be 0 (exact fp32) or 1 (bf16x3)");
+    EXCEL_CHECK_ARG(B > 0 && N > 0 && C > 0 && T > 0, "patch_text_cam: bad shape");
     const int ldT = (T + 3) / 4 * 4;
-    float* sim = (float*)workspace;
-    unsigned short* ts = (unsigned short*)((char*)workspace + align_up((size_t)B * N * ldT * sizeof(float), 256));
-    if (mode == 1) TRY(excel_launch_split_bf16(text, ts, T, C, ST(stream)));       // [T][2C] blocked hi|lo (a few KB, once per call)
-    return excel_launch_patch_text_cam(x_raw, text, mode == 1 ? ts : nullptr, sim, out_full, out_slice, image_features, B, N, C, T, F, ldT,
-                                       temperature, mode, ST(stream));
+    const PtcWs w = ptc_ws_layout(B, N, C, T, (char*)workspace);
+    return excel_launch_patch_text_cam(x_raw, text, mode == 1 ? w.ts : nullptr, w.sim, w.part, w.colsq, out_full, out_slice, image_features, B, N, C,
+                                       T, F, ldT, temperature, mode, ST(stream));
 }
 
 // ------------------------------------------------------------------------------------ affinity

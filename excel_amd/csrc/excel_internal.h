@@ -68,8 +68,10 @@ int excel_launch_attn_strip(const unsigned short* qkvs, unsigned short* a_sum, f
                             hipStream_t st);
 int excel_launch_cam_epilogue(float* S, float* out_full, float* out_slice, int B, int N, int T, int ldS, int F, float temp,
                               hipStream_t st);
-int excel_launch_patch_text_cam(const float* x_raw, const float* text, const unsigned short* text_split, float* sim_ws, float* out_full,
-                                float* out_slice, float* feats, int B, int N, int C, int T, int F, int ldT, float temp, int bf, hipStream_t st);
+size_t excel_patch_text_cam_ws_floats(int B, int N, int C, int T, int which);     // which: 0 sim, 1 min/max partials, 2 column-norm partials
+int excel_launch_patch_text_cam(const float* x_raw, const float* text, unsigned short* text_split_out, float* sim_ws, float* part_ws,
+                                float* colsq_ws, float* out_full, float* out_slice, float* feats, int B, int N, int C, int T, int F, int ldT,
+                                float temp, int bf, hipStream_t st);
 int excel_launch_trans_mat_sym(const float* W, float* T, float* Tsym, float* cs, int B, int P, hipStream_t st);
 int excel_launch_cls_compact(const float* onehot, int B, int F, int Smax, int* cls_idx, int* ncls, int* nchan, hipStream_t st);
 int excel_launch_bbox_mask(const float* attr, const int* cls_idx, const int* ncls, int B, int g, int F, int Smax, double thre,

@@ -234,10 +234,14 @@ size_t excel_cam_workspace_bytes(int B, int N, int T);
 int excel_clip_feature_surgery(const float* image_features, const float* text, int B, int N, int C, int T, int F,
                                float temperature, float* out_full, float* out_slice, void* workspace, void* stream);
 
-/* The same attribute maps in ONE launch from the UN-normalised token features (x_raw of excel_vit_forward): token-axis L2 norm
- * (clip/clip.py:353) + similarity GEMM on the matrix core + the surgery epilogue (clip/clip.py:288-310) -- model/model_excel.py:57-58
- * back to back.  mode 1: bf16x3 (fp32 operands as bf16 hi+lo, 3 MFMAs per product), mode 0: exact fp32 MFMA.
- * image_features [B,N,C] (optional): the normalised features generate_clip_fts returns.  T <= 128, C % 32 == 0, C <= 1024. */
+/* The same attribute maps from the UN-normalised token features (x_raw of excel_vit_forward): token-axis L2 norm (clip/clip.py:353) +
+ * similarity GEMM on the matrix core + the surgery epilogue (clip/clip.py:288-310) -- model/model_excel.py:57-58 back to back.  Three
+ * launches, each over the whole chip: column sums of squares in image-aligned row blocks (fixed order: an image's maps do not depend
+ * on its position in the batch), the similarity tiles (one wave per 32-token tile, >= 7 workgroups per image), and the min-max
+ * normalisation over a two-stage (exact) min / max reduction.
+ *   mode 1: bf16x3 (fp32 operands as bf16 hi+lo, 3 MFMAs per product), mode 0: exact fp32 MFMA.
+ *   image_features [B,N,C] (optional): the normalised features generate_clip_fts returns.
+ * T <= 128, C % 32 == 0, C <= 1024; x_raw, text, image_features and the workspace 16-byte aligned. */
 size_t excel_patch_text_cam_workspace_bytes(int B, int N, int C, int T);
 int excel_patch_text_cam(const float* x_raw, const float* text, int B, int N, int C, int T, int F, float temperature, int mode,
                          float* out_full, float* out_slice, float* image_features, void* workspace, void* stream);

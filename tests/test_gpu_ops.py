@@ -204,6 +204,22 @@ def test_patch_text_cam_fused(ops, B, N, C, T, F, mode, tol):
     assert none is None and torch.equal(sl_only, sl)
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "f32"])
+def test_patch_text_cam_is_batch_invariant(ops, mode):
+    """The attribute maps of an image do not depend on its position in the batch or on the batch size, bit for bit: the token-axis
+    norms are reduced over image-aligned blocks in a fixed order, the class-prior weights in fixed fp32 chains, min / max exactly."""
+    rs = np.random.RandomState(21)
+    x = dev((rs.standard_normal((5, 785, 512)) * (1 + rs.rand(1, 1, 512) * 3)).astype(np.float32))
+    t = rs.standard_normal((45, 512)).astype(np.float32)
+    t = dev(t / np.linalg.norm(t, axis=1, keepdims=True))
+    full, sl, _ = ops.patch_text_cam(x, t, num_fg=20, want_full=True, mode=mode)
+    for b in (0, 3, 4):
+        f1, s1, _ = ops.patch_text_cam(x[b:b + 1].contiguous(), t, num_fg=20, want_full=True, mode=mode)
+        assert torch.equal(f1[0], full[b]) and torch.equal(s1[0], sl[b])
+    full2, _, _ = ops.patch_text_cam(x, t, num_fg=20, want_full=True, mode=mode)
+    assert torch.equal(full2, full)                                                     # run to run
+
+
 def test_clip_feature_surgery_redundant_feats_branch(ops):
     """clip.py:289-290: similarity = image_features @ (text_features - redundant_feats).t() (the reference then returns an
     unassigned name, :310; the evident intent - the similarity - is returned here)."""
