@@ -4,8 +4,8 @@ Differences from the reference, all deliberate:
   * batches of B > 1 images run through the device-resident TrainingFreePipeline (the reference is batch 1 with
     per-class host round trips); `--api_path` runs the reference's per-image call sequence instead.  Real data (`--data_folder`:
     every image has its own size, and the path refines and scores at that size, :74,:94) and `--ragged true` synthetic data run
-    as RAGGED batches: background worker processes decode whole batches (`--num_workers`, the reference's DataLoader workers, :167),
-    the device resizes every image to the network size and runs the size-dependent half (up-sampling, PAR, arg-max) over packed
+    as RAGGED batches: a background decode pool (`--num_workers` threads; `--decode processes` = the reference's DataLoader worker
+    processes, :167) fills a pinned staging ring, a copy stream moves the batches to the device ahead of the compute stream, the device resizes every image to the network size and runs the size-dependent half (up-sampling, PAR, arg-max) over packed
     planes through a tile map - one launch per stage for any mix of sizes (pipeline.run_batch_ragged);
   * ranks take images r, r+R, ... exactly like :166, accumulate a device-side [nc,nc] int64 confusion matrix and
     exchange it ONCE with an all_gather over RCCL (the reference scores each shard separately and never aggregates);
@@ -63,7 +63,11 @@ def get_parser():
     p.add_argument("--seed", default=1234, type=int)
     p.add_argument("--api_path", default=False, type=_bool, help="per-image reference call sequence instead of the batched pipeline")
     p.add_argument("--ragged", default=False, type=_bool, help="synthetic samples with VOC-like, per-image sizes (uint8 images), fed as ragged batches like real data")
-    p.add_argument("--num_workers", default=8, type=int, help="background decode processes of the ragged path (the reference's DataLoader uses 2, :167); 0 = decode in the loop")
+    p.add_argument("--num_workers", default=8, type=int, help="background decoders of the ragged path (the reference's DataLoader uses 2 worker processes, :167)")
+    p.add_argument("--decode", default="threads", choices=["threads", "processes"],
+                   help="threads: a decode thread pool in this process (Pillow releases the GIL; default); processes: forked DataLoader "
+                        "workers like the reference - after such workers exit, host-side GPU event waits of this process were measured "
+                        "at ~350 ms each on ROCm 7.2, so the default avoids fork")
     p.add_argument("--clip_root", default=None, type=str, help="directory holding the published CLIP archive (ViT-B-16.pt); default $EXCEL_CLIP_ROOT, ~/.cache/clip")
     p.add_argument("--bpe_path", default=None, type=str, help="CLIP's bpe_simple_vocab_16e6.txt.gz (default $EXCEL_BPE_VOCAB)")
     p.add_argument("--gemm_mode", default=None, type=str, help="bf16x3 (default) | f32")
@@ -130,17 +134,26 @@ def build_validation(model=None, par=None, dataset=None, indices=None, device="c
         from ..utils import imutils
         pipe.hist = hist
         keep = bool(getattr(args, "crf_post", False))
-        for rb in ragged_batches(dataset, indices, args.batch_size, num_workers=int(getattr(args, "num_workers", 2))):
-            plan = ops.RaggedPlan(rb.hw, device)
-            out = pipe.run_batch_ragged(rb.images.to(device, non_blocking=True), plan, rb.cls.to(device, non_blocking=True),
-                                        rb.labels.to(device, non_blocking=True), S=S, return_intermediates=keep)
+        nw = int(getattr(args, "num_workers", 8))
+        if getattr(args, "decode", "threads") == "processes" and nw > 0:    # the reference's mechanism (DataLoader worker processes, :167)
+            batches = ragged_batches(dataset, indices, args.batch_size, num_workers=nw, pin_memory=False)
+        else:                                                               # default: a thread pool (datasets/loader.threaded_batches)
+            from ..datasets.loader import threaded_batches
+            batches = threaded_batches(dataset, indices, args.batch_size, num_threads=max(nw, 1))
+        if on_gpu:
+            from ..datasets.loader import DeviceFeeder
+            feed = DeviceFeeder(batches, device)              # H2D on a copy stream, a few batches ahead
+        else:                                                  # (control-flow tests: a stub pipeline on CPU tensors)
+            feed = ((rb.names, ops.RaggedPlan(rb.hw, None), rb.images, rb.cls, rb.labels) for rb in batches)
+        for names, plan, images, cls_t, labels_t in feed:
+            out = pipe.run_batch_ragged(images, plan, cls_t, labels_t, S=S, return_intermediates=keep)
             if keep:                                                                        # :116-119 record for the CRF stage
                 inter = out[1]
                 cls_idx, ncls = inter["cls_idx"].cpu().numpy(), inter["ncls"].cpu().numpy()
-                for b, name in enumerate(rb.names):
+                for b, name in enumerate(names):
                     k = int(ncls[b])
                     imutils.save_logits(args.logits_dir, name, plan.planes(inter["cams"], b, pipe.smax + 1)[:k + 1], cls_idx[b, :k].astype(np.int64))
-            nimg += len(rb)
+            nimg += len(names)
         if on_gpu:
             torch.cuda.synchronize()
         return pipe.hist, nimg, time.time() - t0

@@ -947,6 +947,8 @@ def test_infer_lam_data_folder_runs_ragged_batches_of_32(gpu, tmp_path):
     assert int(host(total).sum()) == npix and 0.0 <= score["miou"] <= 1.0
     score1, total1 = infer_lam.validate(infer_lam.get_parser().parse_args(common + ["--api_path", "true"]))
     assert np.array_equal(host(total), host(total1))
+    _, total_p = infer_lam.validate(infer_lam.get_parser().parse_args(common + ["--decode", "processes"]))     # the reference's DataLoader workers
+    assert np.array_equal(host(total), host(total_p))
     # CRF stage on the batched path: records of THIS run, one per image, cams [k+1,h,w] + keys
     logits = tmp_path / "logits"
     crf = common + ["--crf_post", "true", "--logits_dir", str(logits)]

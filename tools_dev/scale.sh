@@ -24,7 +24,7 @@ done
 for N in 1 2 4 8; do
   [ "$N" -gt "$MAXN" ] && break
   python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port $((PORT + 20 + N)) \
-      -m excel_amd.tools.infer_lam --synthetic 10582 --ragged true --batch_size 32 --num_workers 12 --resize_size 448 \
+      -m excel_amd.tools.infer_lam --synthetic 10582 --ragged true --batch_size 32 --num_workers 8 --resize_size 448 \
       --json_out "$OUT/infer_lam_voc_n$N.json" > "$OUT/infer_lam_voc_n$N.log" 2>&1
   cat "$OUT/infer_lam_voc_n$N.json"; echo
 done
