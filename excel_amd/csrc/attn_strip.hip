@@ -165,6 +165,44 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
         __builtin_amdgcn_s_barrier();                              // ... and are visible to every wave
         int gc = 0;
 
+        // The probabilities of a phase are folded into the accumulators (block F: all waves' (m, l) -> M, L -> per-tile factors ->
+        // acc += p f) INSIDE the next phase, and the two waves that share a SIMD (w, w + 4) do it on opposite sides of tile 0's
+        // MFMAs: F is ~200 cycles of VALU work, so the pair leaves the barrier half a tile out of step and stays that way - while
+        // one wave's 12 dependent MFMAs own the matrix pipe the other runs its softmax on the VALU.  In step (round 2), both waves
+        // of a SIMD queued their MFMA blocks, then their softmax blocks, on one pipe each (matrix pipe 25 % busy, VALU 38 %).
+        f32x16 s[NTW];
+        float mref[NTW];                                           // running maximum (log2 units) tile j was exponentiated against
+        bool pending = false;
+        const bool late_f = (wave & 4) != 0;
+        auto apply_phase = [&](int tp) {
+            const unsigned ls = lstat_addr + (tp & 1) * (8 * 32 * 8);
+            float M, L = 0.f;
+            {
+                float2 st[8];
+#pragma unroll
+                for (int w2 = 0; w2 < 8; ++w2) st[w2] = lds_read8(ls + r * 8 + (w2 < nw ? w2 : 0) * (32 * 8));
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(st[0]), "+v"(st[1]), "+v"(st[2]), "+v"(st[3]), "+v"(st[4]), "+v"(st[5]), "+v"(st[6]), "+v"(st[7])::"memory");
+                M = fmaxf(fmaxf(st[0].x, st[1].x), st[2].x);                              // slots >= nw repeat slot 0
+                M = fmaxf(fmaxf(M, st[3].x), st[4].x);
+                M = fmaxf(fmaxf(M, st[5].x), fmaxf(st[6].x, st[7].x));
+#pragma unroll
+                for (int w2 = 0; w2 < 8; ++w2)
+                    if (w2 < nw) L = fmaf(st[w2].y, __builtin_amdgcn_exp2f(st[w2].x - M), L);
+            }
+            const float rl = 1.f / L;
+#pragma unroll
+            for (int j = 0; j < NTW; ++j)
+                if (j < NTW - 1 || full) {
+                    const float f = __builtin_amdgcn_exp2f(mref[j] - M) * rl;
+                    const f32x2 f2 = {f, f};
+#pragma unroll
+                    for (int e = 0; e < 16; e += 2) {
+                        const f32x2 a = __builtin_elementwise_fma(f32x2{s[j][e], s[j][e + 1]}, f2, f32x2{acc[j][e], acc[j][e + 1]});
+                        acc[j][e] = a[0];
+                        acc[j][e + 1] = a[1];
+                    }
+                }
+        };
         for (int t = t0; t < t1; ++t) {
             const int par = (t - t0) & 1;
             // query-strip fragments (B operand): row r, k-step s4 -> chunk (2 s4 + kh) of hi, 8 + (2 s4 + kh) of lo
@@ -178,8 +216,7 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
                 }
                 lds_wait8(xh, xl);
             }
-            f32x16 s[NTW];
-            float mref[NTW];                                       // running maximum (log2 units) tile j was exponentiated against
+            if (pending && !late_f) apply_phase(t - 1);            // early F: before tile 0
             // finite "minus infinity": a lane whose 16 keys of the (ragged) last tile are all padding must not form (-inf) - (-inf)
             float m_run = -1e30f, l_run = 0.f;
             auto softmax_tile = [&](int j) {
@@ -241,6 +278,7 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
                         for (int e = 0; e < 16; ++e)
                             if ((e & 3) + 8 * (e >> 2) >= lim) sj[e] = -INFINITY;
                     }
+                    if (j == 0 && pending && late_f) apply_phase(t - 1);                    // late F: behind tile 0's MFMAs, before s[0] is replaced
                     s[j] = sj;
                 }
             }
@@ -271,34 +309,10 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
             asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                    // (a key tile was issued after it)
             __builtin_amdgcn_s_barrier();                                                   // raw: no vmcnt(0) drain of the tile stream
             if (!(DBG & 2)) issue_x(min(t + 2, t1 - 1), par);                               // slot of phase t: every wave has its fragments
-            // (m, l) of all waves -> this lane's per-tile factors 2^(m_j - M) / L
-            float M, L = 0.f;
-            {
-                float2 st[8];
-#pragma unroll
-                for (int w2 = 0; w2 < 8; ++w2) st[w2] = lds_read8(ls + r * 8 + (w2 < nw ? w2 : 0) * (32 * 8));
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(st[0]), "+v"(st[1]), "+v"(st[2]), "+v"(st[3]), "+v"(st[4]), "+v"(st[5]), "+v"(st[6]), "+v"(st[7])::"memory");
-                M = fmaxf(fmaxf(st[0].x, st[1].x), st[2].x);                              // slots >= nw repeat slot 0
-                M = fmaxf(fmaxf(M, st[3].x), st[4].x);
-                M = fmaxf(fmaxf(M, st[5].x), fmaxf(st[6].x, st[7].x));
-#pragma unroll
-                for (int w2 = 0; w2 < 8; ++w2)
-                    if (w2 < nw) L = fmaf(st[w2].y, __builtin_amdgcn_exp2f(st[w2].x - M), L);
-            }
-            const float rl = 1.f / L;
-#pragma unroll
-            for (int j = 0; j < NTW; ++j)
-                if (j < NTW - 1 || full) {
-                    const float f = __builtin_amdgcn_exp2f(mref[j] - M) * rl;
-                    const f32x2 f2 = {f, f};
-#pragma unroll
-                    for (int e = 0; e < 16; e += 2) {
-                        const f32x2 a = __builtin_elementwise_fma(f32x2{s[j][e], s[j][e + 1]}, f2, f32x2{acc[j][e], acc[j][e + 1]});
-                        acc[j][e] = a[0];
-                        acc[j][e + 1] = a[1];
-                    }
-                }
+            if (NTW < 5) pending = true;                                                    // F(t) runs inside phase t+1 (or after the loop)
+            else apply_phase(t);                                                            // (5 tiles per wave: no registers to carry a phase)
         }
+        if (pending) apply_phase(t1 - 1);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     };
 

@@ -286,7 +286,24 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16x3_kernel(GemmBfArgs
         }
     };
 
-    if (NSTAGE == 2) {
+    if (EXCEL_DBG(p.dbg) & 4) {
+        // dev arm "MFMA only": the kernel's own MFMA count per k-step, operands in registers, no LDS, no DMA, no barrier - the
+        // power-limited ceiling of this instruction mix on this part (profiles/r03_gemm_ceiling.json)
+        bf16x8 fa, fb;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { fa[q] = (__bf16)(0.001f * (float)(lane + q)); fb[q] = (__bf16)(0.002f * (float)(lane ^ q)); }
+        for (int kt = 0; kt < nk; ++kt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, fa, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fa, acc[i][j], 0, 0, 0);
+                    }
+    } else if (NSTAGE == 2) {
         issue_tile(0, 0);
         __syncthreads();                  // drains the LDS-DMA (vmcnt(0)) and publishes the tile
         for (int kt = 0; kt < nk; ++kt) {

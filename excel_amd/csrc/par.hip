@@ -187,7 +187,6 @@ __global__ __launch_bounds__(256, 2) void par_iterate_guide_kernel(const float* 
     const int tid = threadIdx.x, lane = tid & 63, tx = tid & 15, ty = tid >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int px = x0 + 4 * tx, py = y0 + ty;
-    const bool valid = px < W && py < H;
     const int nch = nchan ? min(nchan[b], Cmax) : Cmax;
     const long long pix = (long long)min(py, H - 1) * Wp + min(px, Wp - 4);
     const float* st_b = stats + 5 * tg.base + pix;
@@ -244,8 +243,9 @@ __global__ __launch_bounds__(256, 2) void par_iterate_guide_kernel(const float* 
     auto taps = [&](int buf, auto&& fn) {
         // opaque per plane: otherwise the ~50 per-lane LDS tap addresses (x 2 buffers) are hoisted out of the plane loop and compete
         // with the pinned weight registers (spills)
-        int cbo = cb, tyo = ty;
-        asm volatile("" : "+v"(cbo), "+v"(tyo));
+        int tq = threadIdx.x;                                    // (recomputed from the thread index: cb / ty carried from the top of
+        asm volatile("" : "+v"(tq));                              //  the kernel were live across the weight registers and spilled)
+        const int cbo = HALO + 4 * (tq & 15), tyo = tq >> 4;
         const unsigned base = tile_b + buf * (TR * TP * 4);
 #pragma unroll
         for (int di = 0; di < ND; ++di) {
@@ -301,7 +301,6 @@ __global__ __launch_bounds__(256, 2) void par_iterate_guide_kernel(const float* 
 
     const int np = 3 + nch;
     stage(0, 0);
-    float* out_px = out + (long long)Cmax * tg.base + (long long)py * Wp + px;
     // phase 1 in its own loop (one body: with two different bodies in one rolled loop the 192 in-place accumulators were copied / spilled)
 #pragma unroll 1
     for (int p = 0; p < 3; ++p) {
@@ -334,7 +333,13 @@ __global__ __launch_bounds__(256, 2) void par_iterate_guide_kernel(const float* 
                 wall[di][k] = __builtin_elementwise_fma(e, is4, f32x4{ps, ps, ps, ps});
             }
     }
-    // phase 2: the weights are loop invariant
+    // phase 2: the weights are loop invariant.  The output position is recomputed here from the thread index (opaque to the optimiser):
+    // carried from the top of the kernel it was live across the 192 pinned weight registers and went to scratch.
+    int tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));
+    const int px2 = x0 + 4 * (tid2 & 15), py2 = y0 + (tid2 >> 4);
+    const bool valid2 = px2 < W && py2 < H;
+    float* out_px = out + (long long)Cmax * tg.base + (long long)py2 * Wp + px2;
     for (int p = 3; p < np; ++p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -342,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void par_iterate_guide_kernel(const float* 
         if (EXCEL_DBG(dbg) & 4) continue;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         taps(p & 1, [&](int di, int k, const f32x4 nb) { acc = __builtin_elementwise_fma(nb, wall[di][k], acc); });   // tap order, fused
-        if (valid) *reinterpret_cast<f32x4*>(out_px + (long long)(p - 3) * HW) = acc;
+        if (valid2) *reinterpret_cast<f32x4*>(out_px + (long long)(p - 3) * HW) = acc;
     }
 }
 
