@@ -163,61 +163,120 @@ __global__ __launch_bounds__(256) void crf_neighbors_kernel(const CrfKey* __rest
     nbr[(long long)j * Mcap + i] = make_int2(crf_find(n1, keys, table, mask, latidx), crf_find(n2, keys, table, mask, latidx));
 }
 
-// splat: acc[o][k] += w * (in[n][k] * norm[n]) in 2^-40 fixed point (integer sums commute: deterministic)
-__global__ __launch_bounds__(256) void crf_splat_kernel(const float* __restrict__ in, const float* __restrict__ norm, const int* __restrict__ offset,
-                                                        const float* __restrict__ bary, long long npv, int Dp1, int C, long long* __restrict__ acc) {
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= npv * C) return;
-    const long long pv = t / C;
-    const int k = (int)(t - pv * C);
-    const long long n = pv / Dp1;
-    float v = in[n * C + k];
-    if (norm) v = __fmul_rn(v, norm[n]);
-    const float wv = __fmul_rn(bary[pv], v);
-    atomicAdd(reinterpret_cast<unsigned long long*>(&acc[(long long)offset[pv] * C + k]), (unsigned long long)(long long)__double2ll_rn((double)wv * CRF_FIX));
-}
-__global__ __launch_bounds__(256) void crf_fix2float_kernel(const long long* __restrict__ acc, const int* __restrict__ counter, int C, float* __restrict__ lat) {
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t < (long long)(*counter) * C) lat[t] = (float)((double)acc[t] * (1.0 / CRF_FIX));
-}
-__global__ __launch_bounds__(256) void crf_blur_kernel(const float* __restrict__ old, float* __restrict__ nw, const int2* __restrict__ nbr,
-                                                       const int* __restrict__ counter, int C) {
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (long long)(*counter) * C) return;
-    const int i = (int)(t / C), k = (int)(t - (long long)i * C);
-    const int2 nb = nbr[i];
-    const float a = nb.x >= 0 ? old[(long long)nb.x * C + k] : 0.f, b = nb.y >= 0 ? old[(long long)nb.y * C + k] : 0.f;
-    nw[t] = old[t] + 0.5f * (a + b);
-}
-// slice (+ symmetric normalisation, + optional "1/sqrt" finish when building the normaliser itself)
-__global__ __launch_bounds__(256) void crf_slice_kernel(const float* __restrict__ lat, const int* __restrict__ offset, const float* __restrict__ bary,
-                                                        const float* __restrict__ norm, long long N, int Dp1, int C, float alpha, int make_norm,
-                                                        float* __restrict__ out) {
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= N * C) return;
-    const long long n = t / C;
-    const int k = (int)(t - n * C);
-    float s = 0.f;
-    for (int j = 0; j < Dp1; ++j) {
-        const long long pv = n * Dp1 + j;
-        s += __fmul_rn(__fmul_rn(bary[pv], lat[(long long)offset[pv] * C + k]), alpha);
-    }
-    if (make_norm) s = 1.0f / sqrtf(s + 1e-20f);
-    else if (norm) s = __fmul_rn(s, norm[n]);
-    out[t] = s;
-}
+// ---- message passing of one mean-field step: BOTH kernels (Gaussian: lattice g, bilateral: lattice b) ride in the same launches
+//   splat (1 launch) -> blur passes (max(D_g, D_b) + 1 launches; pass 0 reads the fixed-point accumulators, pass 1 re-zeroes them for
+//   the next step) -> slice + mean-field update (1 launch): 8 launches per step instead of 18 (a memset, splat, fixed->float, D+1 blurs
+//   and a slice per kernel, then the update).  Same operations in the same order as the per-kernel form: same bits.
+struct CrfSide {                 // one lattice as the message-passing kernels see it
+    const int* offset;           // [npv] vertex -> lattice point
+    const float* bary;           // [npv]
+    const float* norm;           // [N] symmetric normaliser (may be null while it is being built)
+    const int2* nbr;             // [D+1][npv] blur neighbours
+    const int* counter;          // number of lattice points
+    long long* acc;              // [npv*C] fixed-point splat accumulators
+    float *lat0, *lat1;          // [npv*C] ping-pong
+    long long npv;
+    int Dp1;
+    float alpha;                 // 1 / (1 + 2^-D)
+};
 
-// U [C,N] (plane-major, as unary_from_softmax lays it out) ; Q, msg [N,C]
-__global__ __launch_bounds__(256) void crf_meanfield_kernel(const float* __restrict__ prob, int is_energy, long long N, int C, const float* __restrict__ mg, float wg,
-                                                            const float* __restrict__ mb, float wb, float* __restrict__ Q, float* __restrict__ out_cn) {
+// splat: acc[o][k] += w * (in[n][k] * norm[n]) in 2^-40 fixed point (integer sums commute: deterministic).  Grid-stride over one side.
+__device__ __forceinline__ void crf_splat_side(const float* __restrict__ in, int use_norm, const CrfSide& L, int C) {
+    const long long total = L.npv * C, stride = (long long)gridDim.x * 256;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
+        const long long pv = t / C;
+        const int k = (int)(t - pv * C);
+        const long long n = pv / L.Dp1;
+        float v = in[n * C + k];
+        if (use_norm) v = __fmul_rn(v, L.norm[n]);
+        const float wv = __fmul_rn(L.bary[pv], v);
+        atomicAdd(reinterpret_cast<unsigned long long*>(&L.acc[(long long)L.offset[pv] * C + k]), (unsigned long long)(long long)__double2ll_rn((double)wv * CRF_FIX));
+    }
+}
+__global__ __launch_bounds__(256) void crf_splat2_kernel(const float* __restrict__ in, int use_norm, CrfSide g, CrfSide b, int C) {
+    crf_splat_side(in, use_norm, g, C);
+    crf_splat_side(in, use_norm, b, C);
+}
+__device__ __forceinline__ float crf_fix(long long a) { return (float)((double)a * (1.0 / CRF_FIX)); }
+// blur pass j of one lattice: grid-stride over its M lattice points (M is read on the device: the bilateral lattice of
+// tools/infer_lam.py's parameters (sxy 67) has a few thousand points, the launch capacity would be 6 N).  Pass 0 converts the
+// accumulators on the fly, pass 1 clears them (nobody reads them after pass 0).
+__device__ __forceinline__ void crf_blur_side(const CrfSide& L, int j, int C) {
+    if (j >= L.Dp1) return;
+    const long long total = (long long)(*L.counter) * C, stride = (long long)gridDim.x * 256;
+    float* nw = (j & 1) ? L.lat0 : L.lat1;             // pass 0: acc -> lat1, pass 1: lat1 -> lat0, ...
+    const float* old = (j & 1) ? L.lat1 : L.lat0;
+    const int2* nbr = L.nbr + (long long)j * L.npv;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += stride) {
+        const int i = (int)(t / C), k = (int)(t - (long long)i * C);
+        const int2 nb = nbr[i];
+        if (j == 0) {
+            const float a = nb.x >= 0 ? crf_fix(L.acc[(long long)nb.x * C + k]) : 0.f, c = nb.y >= 0 ? crf_fix(L.acc[(long long)nb.y * C + k]) : 0.f;
+            nw[t] = crf_fix(L.acc[t]) + 0.5f * (a + c);
+        } else {
+            const float a = nb.x >= 0 ? old[(long long)nb.x * C + k] : 0.f, c = nb.y >= 0 ? old[(long long)nb.y * C + k] : 0.f;
+            nw[t] = old[t] + 0.5f * (a + c);
+            if (j == 1) L.acc[t] = 0;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void crf_blur2_kernel(CrfSide g, CrfSide b, int j, int C) {
+    crf_blur_side(g, j, C);
+    crf_blur_side(b, j, C);
+}
+// the Dp1 vertices of pixel n (lattice point, barycentric weight x alpha... kept separate: same roundings as the per-kernel form) in
+// registers: a pixel's C classes reuse them
+template <int DP1>
+struct CrfVerts {
+    long long off[DP1];
+    float w[DP1];
+    __device__ __forceinline__ void load(const CrfSide& L, long long n, int C) {
+#pragma unroll
+        for (int j = 0; j < DP1; ++j) { off[j] = (long long)L.offset[n * DP1 + j] * C; w[j] = L.bary[n * DP1 + j]; }
+    }
+    __device__ __forceinline__ float slice(const float* __restrict__ lat, int k, float alpha) const {
+        float v[DP1];
+#pragma unroll
+        for (int j = 0; j < DP1; ++j) v[j] = lat[off[j] + k];          // independent gathers, all in flight
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < DP1; ++j) s += __fmul_rn(__fmul_rn(w[j], v[j]), alpha);
+        return s;
+    }
+};
+__device__ __forceinline__ const float* crf_final_lat(const CrfSide& L) { return (L.Dp1 & 1) ? L.lat1 : L.lat0; }   // buffer the last pass wrote
+
+// normalisers of both lattices from K 1: norm = 1 / sqrt(K 1 + 1e-20)   (DenseKernel::initLattice, NORMALIZE_SYMMETRIC); C = 1
+__global__ __launch_bounds__(256) void crf_make_norm2_kernel(CrfSide g, CrfSide b, long long N, float* __restrict__ norm_g, float* __restrict__ norm_b) {
     const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
+    CrfVerts<3> vg;
+    CrfVerts<6> vb;
+    vg.load(g, n, 1);
+    vb.load(b, n, 1);
+    norm_g[n] = 1.0f / sqrtf(vg.slice(crf_final_lat(g), 0, g.alpha) + 1e-20f);
+    norm_b[n] = 1.0f / sqrtf(vb.slice(crf_final_lat(b), 0, b.alpha) + 1e-20f);
+}
+// slice both messages + the mean-field update of one pixel:  Q = softmax(-U + w_g K_g Q + w_b K_b Q).  U [C,N] (plane-major, as
+// unary_from_softmax lays it out); Q [N,C].  have_msg = 0: the initial Q = softmax(-U).
+__global__ __launch_bounds__(256) void crf_update_kernel(const float* __restrict__ prob, int is_energy, long long N, int C, int have_msg, CrfSide g, float wg,
+                                                         CrfSide b, float wb, float* __restrict__ Q, float* __restrict__ out_cn) {
+    const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    CrfVerts<3> vg;
+    CrfVerts<6> vb;
+    float ng = 0.f, nb = 0.f;
+    const float *lg = crf_final_lat(g), *lb = crf_final_lat(b);
+    if (have_msg) { vg.load(g, n, C); vb.load(b, n, C); ng = g.norm[n]; nb = b.norm[n]; }
     float mx = -INFINITY;
     for (int k = 0; k < C; ++k) {
         const float pv = prob[(long long)k * N + n];
         const float u = is_energy ? pv : -logf(fminf(fmaxf(pv, 1e-5f), 1.0f));                  // unary_from_softmax (clip 1e-5)
         float t = -u;
-        if (mg) t = t + wg * mg[n * C + k] + wb * mb[n * C + k];
+        if (have_msg) {
+            const float mg = __fmul_rn(vg.slice(lg, k, g.alpha), ng), mb = __fmul_rn(vb.slice(lb, k, b.alpha), nb);
+            t = t + wg * mg + wb * mb;
+        }
         Q[n * C + k] = t;
         mx = fmaxf(mx, t);
     }
@@ -266,9 +325,9 @@ static CrfLattice crf_lattice_layout(char*& p, long long N, int D) {
 
 extern "C" size_t excel_dcrf_workspace_bytes(int H, int W, int C) {
     const long long N = (long long)H * W;
-    const long long mmax = N * 6;                                                      // lattice points <= vertices of the 5-D lattice
-    return crf_lattice_bytes(N, 2, nullptr) + crf_lattice_bytes(N, 5, nullptr) + crf_al(8 * mmax * C) + 2 * crf_al(4 * mmax * C) +
-           3 * crf_al(4 * N * C) + crf_al(4 * N);
+    // per lattice: build tables + fixed-point accumulators [npv*C] + two float lattices [npv*C]; Q [N,C]; ones [N]
+    return crf_lattice_bytes(N, 2, nullptr) + crf_lattice_bytes(N, 5, nullptr) + crf_al(8 * (N * 3) * C) + 2 * crf_al(4 * (N * 3) * C) +
+           crf_al(8 * (N * 6) * C) + 2 * crf_al(4 * (N * 6) * C) + crf_al(4 * N * C) + crf_al(4 * N);
 }
 
 template <int D>
@@ -285,60 +344,57 @@ static int crf_build(const CrfLattice& L, const unsigned char* rgb, int H, int W
     return EXCEL_OK;
 }
 
-// out[N,C] = (norm .*) K (norm .* in)   (or the normaliser itself when make_norm)
-static int crf_filter(const CrfLattice& L, const float* in, float* out, long long N, int C, int make_norm, long long* acc, float* lat0, float* lat1,
-                      hipStream_t st) {
-    const int Dp1 = L.D + 1;
-    hipMemsetAsync(acc, 0, 8ull * L.npv * C, st);                                   // (only M*C entries are used; M <= npv)
-    hipLaunchKernelGGL(crf_splat_kernel, dim3((unsigned)cdivl(L.npv * C, 256)), dim3(256), 0, st, in, make_norm ? nullptr : L.norm, L.offset, L.bary, L.npv, Dp1, C, acc);
-    const unsigned gm = (unsigned)cdivl(L.npv * C, 256);
-    hipLaunchKernelGGL(crf_fix2float_kernel, dim3(gm), dim3(256), 0, st, acc, L.counter, C, lat0);
-    float *a = lat0, *b = lat1;
-    for (int j = 0; j < Dp1; ++j) {
-        hipLaunchKernelGGL(crf_blur_kernel, dim3(gm), dim3(256), 0, st, a, b, L.nbr + (long long)j * L.npv, L.counter, C);
-        float* t = a; a = b; b = t;
-    }
-    const float alpha = 1.0f / (1.0f + powf(2.0f, (float)-L.D));
-    hipLaunchKernelGGL(crf_slice_kernel, dim3((unsigned)cdivl(N * C, 256)), dim3(256), 0, st, a, L.offset, L.bary, make_norm ? nullptr : L.norm, N, Dp1, C, alpha,
-                       make_norm, out);
-    EXCEL_CHECK_LAUNCH("dcrf filter");
+// messages of BOTH kernels for `in` [N,C]: splat, blur passes; the caller slices (crf_make_norm2 / crf_update)
+static int crf_pass(const CrfSide& g, const CrfSide& b, const float* in, int use_norm, int C, hipStream_t st) {
+    const long long work = (g.npv + b.npv) * C;
+    const unsigned gm = (unsigned)(cdivl(work, 256) < 4096 ? cdivl(work, 256) : 4096);      // grid-stride kernels
+    hipLaunchKernelGGL(crf_splat2_kernel, dim3(gm), dim3(256), 0, st, in, use_norm, g, b, C);
+    const int passes = g.Dp1 > b.Dp1 ? g.Dp1 : b.Dp1;
+    for (int j = 0; j < passes; ++j) hipLaunchKernelGGL(crf_blur2_kernel, dim3(gm), dim3(256), 0, st, g, b, j, C);
+    EXCEL_CHECK_LAUNCH("dcrf message passing");
     return EXCEL_OK;
 }
 
 extern "C" int excel_dcrf_inference(const unsigned char* rgb_hwc, const float* prob, int prob_is_energy, int H, int W, int C, int iters, float pos_w,
                                     float pos_xy_std, float bi_w, float bi_xy_std, float bi_rgb_std, float* q_out, void* workspace, void* stream) {
     EXCEL_CHECK_ARG(rgb_hwc && prob && q_out && workspace && H > 0 && W > 0 && C >= 1 && iters >= 0, "dcrf_inference: bad argument");
+    static_assert(true, "the message-passing kernels are written for the D = 2 (Gaussian) and D = 5 (bilateral) lattices of DenseCRF2D");
     EXCEL_CHECK_ARG(pos_xy_std > 0.f && bi_xy_std > 0.f && bi_rgb_std > 0.f, "dcrf_inference: standard deviations must be positive");
     hipStream_t st = (hipStream_t)stream;
     const long long N = (long long)H * W;
     char* p = (char*)workspace;
     CrfLattice Lg = crf_lattice_layout(p, N, 2), Lb = crf_lattice_layout(p, N, 5);
-    const long long mmax = N * 6;
-    long long* acc = (long long*)p; p += crf_al(8 * mmax * C);
-    float* lat0 = (float*)p; p += crf_al(4 * mmax * C);
-    float* lat1 = (float*)p; p += crf_al(4 * mmax * C);
+    CrfSide sg, sb;
+    auto side = [&](CrfSide& s, const CrfLattice& L) {
+        s.offset = L.offset; s.bary = L.bary; s.norm = L.norm; s.nbr = L.nbr; s.counter = L.counter; s.npv = L.npv; s.Dp1 = L.D + 1;
+        s.alpha = 1.0f / (1.0f + powf(2.0f, (float)-L.D));
+        s.acc = (long long*)p; p += crf_al(8 * L.npv * C);
+        s.lat0 = (float*)p; p += crf_al(4 * L.npv * C);
+        s.lat1 = (float*)p; p += crf_al(4 * L.npv * C);
+    };
+    side(sg, Lg);
+    side(sb, Lb);
     float* Q = (float*)p; p += crf_al(4 * N * C);
-    float* mg = (float*)p; p += crf_al(4 * N * C);
-    float* mb = (float*)p; p += crf_al(4 * N * C);
     float* ones = (float*)p; p += crf_al(4 * N);
     TRY(crf_build<2>(Lg, rgb_hwc, H, W, pos_xy_std, 1.f, st));
     TRY(crf_build<5>(Lb, rgb_hwc, H, W, bi_xy_std, bi_rgb_std, st));
-    // normalisers: norm = 1 / sqrt(K 1 + 1e-20)   (DenseKernel::initLattice, NORMALIZE_SYMMETRIC)
+    // the accumulators are cleared once; every message pass leaves them cleared (blur pass 1)
+    hipMemsetAsync(sg.acc, 0, 8ull * Lg.npv * C, st);
+    hipMemsetAsync(sb.acc, 0, 8ull * Lb.npv * C, st);
     {
-        // ones <- softmax of a single class = 1: reuse the mean-field kernel? simpler: fill through hipMemset pattern of 1.0f
         const float one = 1.0f;
         unsigned pattern;
         memcpy(&pattern, &one, 4);
         hipMemsetD32Async((hipDeviceptr_t)ones, (int)pattern, (size_t)N, st);
     }
-    TRY(crf_filter(Lg, ones, Lg.norm, N, 1, 1, acc, lat0, lat1, st));
-    TRY(crf_filter(Lb, ones, Lb.norm, N, 1, 1, acc, lat0, lat1, st));
     const unsigned gn = (unsigned)cdivl(N, 256);
-    hipLaunchKernelGGL(crf_meanfield_kernel, dim3(gn), dim3(256), 0, st, prob, prob_is_energy, N, C, (const float*)nullptr, 0.f, (const float*)nullptr, 0.f, Q, iters == 0 ? q_out : nullptr);
+    // normalisers: norm = 1 / sqrt(K 1 + 1e-20)
+    TRY(crf_pass(sg, sb, ones, 0, 1, st));
+    hipLaunchKernelGGL(crf_make_norm2_kernel, dim3(gn), dim3(256), 0, st, sg, sb, N, Lg.norm, Lb.norm);
+    hipLaunchKernelGGL(crf_update_kernel, dim3(gn), dim3(256), 0, st, prob, prob_is_energy, N, C, 0, sg, 0.f, sb, 0.f, Q, iters == 0 ? q_out : nullptr);
     for (int it = 0; it < iters; ++it) {
-        TRY(crf_filter(Lg, Q, mg, N, C, 0, acc, lat0, lat1, st));
-        TRY(crf_filter(Lb, Q, mb, N, C, 0, acc, lat0, lat1, st));
-        hipLaunchKernelGGL(crf_meanfield_kernel, dim3(gn), dim3(256), 0, st, prob, prob_is_energy, N, C, mg, pos_w, mb, bi_w, Q, it == iters - 1 ? q_out : nullptr);
+        TRY(crf_pass(sg, sb, Q, 1, C, st));
+        hipLaunchKernelGGL(crf_update_kernel, dim3(gn), dim3(256), 0, st, prob, prob_is_energy, N, C, 1, sg, pos_w, sb, bi_w, Q, it == iters - 1 ? q_out : nullptr);
     }
     EXCEL_CHECK_LAUNCH("dcrf mean field");
     return EXCEL_OK;

@@ -587,6 +587,45 @@ def test_dcrf_vs_oracle(ops, H, W, C, params):
     assert np.array_equal(got, again)                                             # fixed-point splat: bit-reproducible
 
 
+def test_dcrf_device_properties(ops):
+    """Properties of the device mean field that hold for the model whatever the implementation (parity with pydensecrf itself stays
+    UNPINNED: the package is absent from the reference snapshot and from this image, tests/test_oracle_golden.py says the same):
+      * both pairwise weights 0                -> Q = softmax(-U) = the (clipped, renormalised) input probabilities, at any iteration count
+      * Potts compatibility is label-symmetric -> permuting the classes of the input permutes the output
+      * a class that is nowhere likely stays nowhere likely; marginals are a distribution at every pixel
+      * smoothing: on a two-region image with noisy unaries the label map gets more homogeneous inside a region, never less
+      * the launch-batched message passing (both kernels per launch, 8 launches per step) is bit-reproducible"""
+    rs = np.random.RandomState(31)
+    H, W, C = 36, 44, 4
+    img = np.zeros((H, W, 3), np.uint8)
+    img[:, : W // 2] = (40, 60, 200)
+    img[:, W // 2:] = (220, 180, 30)
+    img = (img.astype(np.int16) + rs.randint(-6, 7, img.shape)).clip(0, 255).astype(np.uint8)
+    p = rs.rand(C, H, W).astype(np.float32) + 0.05
+    p[0, :, : W // 2] += 0.6                                   # class 0 on the left, class 1 on the right, noisy
+    p[1, :, W // 2:] += 0.6
+    p[3] = 1e-4                                                # class 3 nowhere likely
+    p /= p.sum(0, keepdims=True)
+    par = (10, 3, 1, 4, 67, 3)
+    q = host(ops.dcrf_inference(dev(img, torch.uint8), dev(p), *par))
+    np.testing.assert_allclose(q.sum(0), 1.0, atol=1e-5)
+    assert q[3].max() < 1e-3
+    # zero pairwise weights: the unary alone
+    q0 = host(ops.dcrf_inference(dev(img, torch.uint8), dev(p), 5, 0.0, 1, 0.0, 67, 3))
+    pc = np.clip(p, 1e-5, 1.0)
+    assert maxabs(q0, pc / pc.sum(0, keepdims=True)) < 1e-6
+    # label permutation
+    perm = np.array([2, 0, 3, 1])
+    qp = host(ops.dcrf_inference(dev(img, torch.uint8), dev(np.ascontiguousarray(p[perm])), *par))
+    assert maxabs(qp, q[perm]) < 2e-6
+    # smoothing inside the regions
+    lab_in, lab_out = p.argmax(0), q.argmax(0)
+    left_in, left_out = (lab_in[:, : W // 2 - 2] == 0).mean(), (lab_out[:, : W // 2 - 2] == 0).mean()
+    right_in, right_out = (lab_in[:, W // 2 + 2:] == 1).mean(), (lab_out[:, W // 2 + 2:] == 1).mean()
+    assert left_out >= left_in and right_out >= right_in and left_out > 0.99 and right_out > 0.99
+    assert np.array_equal(q, host(ops.dcrf_inference(dev(img, torch.uint8), dev(p), *par)))
+
+
 def test_dcrf_mirror_api(ops):
     """excel_amd.utils.dcrf keeps the reference module's surface (DenseCRF class, crf_inference, crf_inference_label) on numpy inputs."""
     from excel_amd.utils import dcrf
