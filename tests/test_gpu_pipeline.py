@@ -207,6 +207,35 @@ def test_baseline_batch32_properties(gpu, b16_model):
         assert torch.equal(l1[0], labels[b])
 
 
+def test_ragged_batch32_full_size_properties(gpu, b16_model):
+    """BASELINE configs[3]'s shape of work: ONE ragged batch of 32 images with VOC-like sizes (375x500, 500x375, 333x500 ... every image
+    refined and scored at its own size, tools/infer_lam.py:74,94), ViT-B/16 at 448x448.  The oracle cannot finish this in seconds, so
+    size-independent properties: labels drawn from the image's own key set, histogram mass == the non-ignored pixels, and an image run
+    ALONE as a one-image ragged batch gives the same labels bit for bit (batch- and position-invariance of the whole ragged chain)."""
+    from excel_amd import ops
+    from excel_amd.datasets.loader import pack_samples
+    from excel_amd.pipeline import TrainingFreePipeline
+    from excel_amd.tools import synthetic
+    model, _, _ = b16_model
+    ds = synthetic.SyntheticSegDataset(32, num_classes=21, seed=77, ragged=True)
+    items = [ds[i] for i in range(32)]
+    assert len({it[1].shape for it in items}) >= 4
+    rb = pack_samples(items)
+    plan = ops.RaggedPlan(rb.hw, "cuda")
+    pipe = TrainingFreePipeline(model, num_classes=21, smax=ds.max_k())
+    lab = pipe.run_batch_ragged(rb.images.cuda(), plan, rb.cls.cuda(), rb.labels.cuda(), S=448)
+    assert int(host(pipe.hist).sum()) == int(sum((it[2] < 21).sum() for it in items))
+    for b, it in enumerate(items):
+        keys = np.concatenate([[0], np.where(it[3])[0] + 1])
+        assert np.isin(host(plan.label(lab, b)), keys).all()
+    for b in (0, 7, 31):
+        one = pack_samples([items[b]])
+        p1 = ops.RaggedPlan(one.hw, "cuda")
+        pipe1 = TrainingFreePipeline(model, num_classes=21, smax=ds.max_k())
+        l1 = pipe1.run_batch_ragged(one.images.cuda(), p1, one.cls.cuda(), one.labels.cuda(), S=448)
+        assert torch.equal(l1, plan.label(lab, b).reshape(-1))
+
+
 def test_par_linearity_full_size(gpu):
     """PAR is linear in the masks for a fixed guide image: PAR(a*m1 + m2) == a*PAR(m1) + PAR(m2)."""
     from excel_amd import ops
