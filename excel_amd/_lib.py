@@ -152,6 +152,9 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: its wheel bundles its own libamdhip64; if this library is loaded before it, the process ends up with two HIP
+    # runtimes and the second one cannot see the device ("no ROCm-capable device is detected" on the first launch)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"excel_amd: {LIB_PATH} is missing - the HIP extension is the only compute path. "
