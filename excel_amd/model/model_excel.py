@@ -99,7 +99,7 @@ class ExCEL_model:
         want_feats = want_feats or self.feature_head is not None or self._dec is not None
         # the decoder consumes the list exactly as the reference stacks it (in-place aliasing quirk, include/excel_hip.h)
         # :57-58 back to back -> the fused kernel: the tower hands over the un-normalised token features, the token-axis norm,
-        # the similarity GEMM and the surgery epilogue are one launch (excel_patch_text_cam)
+        # the similarity GEMM and the surgery epilogue are one C-ABI call (excel_patch_text_cam)
         r = self.encoder.encode_image(img, True, None, want_w_aff=True, aff_layers=6, n_attn_out=n_attn_out, want_feats=want_feats,
                                       feats_as_reference=self._dec is not None, want_raw=True, want_features=False)
         attn_weights, all_feats = clip.clip.LazyAttnWeights(r["w_aff"], r["attn"], 6), r["feats"]

@@ -509,7 +509,7 @@ def clip_feature_surgery(image_features, text_features, num_fg=None, t=2.0, want
 
 def patch_text_cam(x_raw, text_features, num_fg=None, t=2.0, want_full=False, want_features=False, mode="bf16x3"):
     """Fused path (excel_patch_text_cam): un-normalised token features x_raw [B,N,C] (VitHandle.forward(want_raw=True)) + text [T,C]
-    -> (full [B,N,T] | None, slice [B,N-1,F] | None, image_features [B,N,C] | None): clip.py:353 + :288-310 in one launch."""
+    -> (full [B,N,T] | None, slice [B,N-1,F] | None, image_features [B,N,C] | None): clip.py:353 + :288-310 (column-norm pass, similarity tiles, finish)."""
     x_raw = f32c(x_raw)
     text_features = f32c(text_features)
     B, N, Cc = x_raw.shape
