@@ -302,8 +302,14 @@ def validate(args=None, dataset=None, pipe=None):
     if dataset is not None:
         args.ragged_batches = True
     elif getattr(args, "data_folder", None):
-        from ..datasets import voc                                                          # :156-163: every image has its own size
-        dataset = voc.VOC12SegDataset(root_dir=args.data_folder, name_list_dir=args.list_folder, split=args.infer_set, stage="val")
+        # :156-163: every image has its own size.  The reference's harness always builds the VOC data set (:132); a COCO tree
+        # (--dataset_name ms_coco, BASELINE configs[4]) gets the COCO reader of datasets/coco.py here
+        if "coco" in args.dataset_name:
+            from ..datasets import coco
+            dataset = coco.CocoSegDataset(root_dir=args.data_folder, name_list_dir=args.list_folder, split=args.infer_set, stage="val")
+        else:
+            from ..datasets import voc
+            dataset = voc.VOC12SegDataset(root_dir=args.data_folder, name_list_dir=args.list_folder, split=args.infer_set, stage="val")
         args.ragged_batches = True
     else:
         args.ragged_batches = bool(getattr(args, "ragged", False))
@@ -323,9 +329,13 @@ def validate(args=None, dataset=None, pipe=None):
     per_rank, total = gather_hists(hist)
     validate.last_per_rank = per_rank
     score = evaluate.scores_from_hist(total)
+    cat_list = VOC_CLASSES                                                                  # :123
+    if "voc" not in args.dataset_name:
+        from ..datasets import coco
+        cat_list = coco.class_list
     if rank == 0:
         logging.info(f"Training_free:{args.training_free}, LAM_score:")
-        logging.info("\n" + format_scores_table(score, VOC_CLASSES))
+        logging.info("\n" + format_scores_table(score, cat_list))
         logging.info(f"mIoU {score['miou'] * 100:.3f}  images {int(nimg) * world}  ({nimg / secs:.1f} img/s/rank)")
         if getattr(args, "json_out", None):
             # one self-checking record per run (tools_dev/scale.sh): wall time, rate and every rank's scored-pixel mass
@@ -341,7 +351,7 @@ def validate(args=None, dataset=None, pipe=None):
         validate.last_crf = (crf_score, crf_total)
         if rank == 0:
             logging.info("crf_seg_score:")
-            logging.info("\n" + format_scores_table(crf_score, VOC_CLASSES))
+            logging.info("\n" + format_scores_table(crf_score, cat_list))
     return score, total
 
 
