@@ -286,6 +286,27 @@ def test_validate_control_flow_world4_uneven_tail():
         assert abs(miou - oracle.evaluate.scores_from_hist(ref)["miou"]) < 1e-12
 
 
+def test_ragged_loaders_pack_in_order():
+    """datasets/loader: threaded_batches (decode thread pool, the harness default) and ragged_batches (DataLoader worker processes, the
+    reference's mechanism) hand out the same RaggedBatches, in index order, last batch partial, images / labels packed back to back."""
+    from excel_amd.datasets.loader import pack_samples, ragged_batches, threaded_batches
+    ds = _TinyRaggedSet(23)
+    order = list(range(22, -1, -1))
+    ref = [pack_samples([ds[j] for j in order[s0:s0 + 5]]) for s0 in range(0, 23, 5)]
+    for batches in (threaded_batches(ds, order, 5, num_threads=3, ahead=2), ragged_batches(ds, order, 5, num_workers=0, pin_memory=False)):
+        got = list(batches)
+        assert [len(b) for b in got] == [5, 5, 5, 5, 3]
+        for a, b in zip(got, ref):
+            assert a.names == b.names and np.array_equal(a.hw, b.hw)
+            assert torch.equal(a.images, b.images) and torch.equal(a.labels, b.labels) and torch.equal(a.cls, b.cls)
+    b0 = ref[0]
+    assert b0.images.numel() == 3 * int((b0.hw[:, 0] * b0.hw[:, 1]).sum()) and b0.labels.numel() == int((b0.hw[:, 0] * b0.hw[:, 1]).sum())
+    _, img, lab, _ = ds[22]
+    assert np.array_equal(b0.images[: img.size].numpy().reshape(img.shape), img) and np.array_equal(b0.labels[: lab.size].numpy().reshape(lab.shape), lab)
+    with pytest.raises(ValueError, match="one size"):
+        pack_samples([("x", np.zeros((4, 5, 3), np.uint8), np.zeros((4, 6), np.uint8), np.zeros(20, np.float32))])
+
+
 def test_gather_hists_single_process_identity():
     from excel_amd.tools.infer_lam import gather_hists
     h = torch.arange(9, dtype=torch.int64).reshape(3, 3)
