@@ -553,6 +553,35 @@ def test_ragged_upsample_par_argmax_equal_per_image_calls(ops):
     assert maxabs(host(plan.planes(par, b, smax + 1))[:k], ref[0]) < 5e-5
 
 
+def test_ragged_tiny_images(ops):
+    """Degenerate sizes in a ragged batch (1x1, a single row, a single column, widths below one float4): the tile map has one tile per
+    image and every stage still equals the uniform entry points (which take the streamed PAR kernel for these shapes), bit for bit."""
+    rs = np.random.RandomState(17)
+    sizes = [(1, 1), (3, 2), (1, 9), (11, 1), (5, 7), (2, 3)]
+    B, smax, g = len(sizes), 2, 4
+    plan = ops.RaggedPlan(sizes, "cuda")
+    assert plan.total_tiles == B
+    refined = dev(rs.rand(B, smax, g * g).astype(np.float32))
+    onehot = np.zeros((B, 20), np.float32)
+    for b in range(B):
+        onehot[b, rs.choice(20, 1 + b % smax, replace=False)] = 1
+    idx, ncls, nchan = ops.cls_compact(dev(onehot), smax, want_nchan=True)
+    imgs = dev(rs.standard_normal((B, 3, 16, 16)).astype(np.float32))
+    cams = ops.cam_upsample_bkg_ragged(refined, ncls, g, plan)
+    par = ops.par_forward_ragged(imgs, cams, plan, smax + 1, num_iter=2, nchan=nchan)
+    lab = ops.argmax_label_ragged(par, plan, smax + 1, nchan, idx)
+    for b, (H, W) in enumerate(sizes):
+        k = int(host(nchan)[b])
+        c1 = ops.cam_upsample_bkg(refined[b:b + 1], ncls[b:b + 1], g, H, W)
+        p1 = ops.par_forward(imgs[b:b + 1], c1, num_iter=2, nchan=nchan[b:b + 1])
+        assert torch.equal(plan.planes(cams, b, smax + 1)[:k], c1[0, :k]) and torch.equal(plan.planes(par, b, smax + 1)[:k], p1[0, :k]), (H, W)
+        assert torch.equal(plan.label(lab, b), ops.argmax_label(p1, nchan[b:b + 1], idx[b:b + 1])[0])
+    u8 = [rs.randint(0, 256, (H, W, 3)).astype(np.uint8) for H, W in sizes]
+    x = ops.normalize_resize_u8_ragged(dev(np.concatenate([a.reshape(-1) for a in u8])), plan, 32)
+    for b, a in enumerate(u8):
+        assert torch.equal(x[b], ops.bilinear_resize(ops.normalize_img_u8(dev(a[None])), 32, 32, align_corners=False)[0])
+
+
 def test_ragged_par_ignores_row_padding(ops):
     """The padding columns of the pitched layout are never read as data: NaN there must not reach a pixel."""
     rs = np.random.RandomState(12)
