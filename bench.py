@@ -394,13 +394,14 @@ def main():
                 tf = cam_flops / (cam_ms * 1e-3) / 1e12
                 vpeak = BF16_MFMA_PEAK_TF if mode == "bf16x3" else F32_MATRIX_PEAK_TF
                 out["roofline_sim_gemm"] = {
-                    "kernel": "final projection GEMM [B*N,768]x[768,512] + patch_text_cam_kernel (token-axis L2 norm + patch x text similarity "
-                              "on the matrix core + class-prior / redundancy / min-max epilogue, one workgroup per image)",
+                    "kernel": "final projection GEMM [B*N,768]x[768,512] + the patch-text CAM kernels (token-axis norm pass, patch x text similarity "
+                              "tiles on the matrix core with class-prior / redundancy epilogue, min-max finish: three whole-chip launches)",
                     "bound": "mfma", "achieved": round(tf, 3), "peak": vpeak, "unit": "TFLOP/s", "frac": round(tf / vpeak, 4),
                     "mfma_issue_frac": round((3 if mode == "bf16x3" else 1) * tf / vpeak, 4),
                     "algorithmic_gflop_per_image": round(cam_flops / steps / B / 1e9, 4), "survey_gflop_per_image": 0.653,
                     "ms_per_step": round(cam_ms / steps, 4),
-                    "note": "the similarity GEMM alone is HBM-bound (arithmetic intensity ~45 flop/B, SURVEY 8d); ln_post is timed under 'layernorm'"}
+                    "note": "bound: 97 % of these flops are the projection GEMM (198 tiles on 256 CUs: 77 % of one round); the similarity part is HBM / "
+                            "latency-bound (arithmetic intensity ~45 flop/B, SURVEY 8d; x_raw is read twice: norm pass + similarity pass); ln_post is timed under 'layernorm'"}
             out["kernel_ms_per_step"] = {k: round(v, 4) for k, v in sorted(ms.items(), key=lambda kv: -kv[1])}
         if world == 1 and args.cpu_images > 0:
             ncpu = min(args.cpu_images, n_batches * B)
