@@ -276,7 +276,7 @@ __device__ __forceinline__ void rowpass_body_bf(const RowpassArgs& p, float* sme
     const u16* Ysp = p.qkvs + (((long long)b * 3 + ty) * p.H + h) * (long long)N * 128;
     const u16* VT = FLASH ? p.vt + (((long long)b * p.H + h) * 64) * 2 * p.vt_kp : nullptr;
     u16* ring = reinterpret_cast<u16*>(smem);            // [3][K tile | V^T tile]
-    const unsigned ring_b = lds_addr(ring);
+    const unsigned ring_b = __builtin_amdgcn_readfirstlane(lds_addr(ring));      // (provably wave-uniform: it goes into m0)
 
     const int q0 = qblk * 128 + wave * 32;
     const int qrow = min(q0 + r, N - 1);
@@ -290,31 +290,32 @@ __device__ __forceinline__ void rowpass_body_bf(const RowpassArgs& p, float* sme
     // consume the query fragments once BEFORE any LDS-DMA is in flight: the compiler then places its wait for these ordinary loads
     // here and not (as vmcnt(0), draining the DMA queue) in front of their first use inside the key loop
     asm volatile("" : "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]), "+v"(xl[0]), "+v"(xl[1]), "+v"(xl[2]), "+v"(xl[3]));
-    // per-lane source offsets of this wave's loads: K rows 8w..8w+7 (2 instr x 4 rows), V^T rows 16w..16w+15 (2 instr x 8 rows)
-    int koff[2], krow[2];
+    // LDS-DMA through buffer descriptors over this (image, head)'s key plane and V^T rows: the per-lane byte offsets are loop invariant
+    // (2 + 2 VGPRs), the tile position goes into the scalar offset - no per-lane 64-bit address arithmetic and no row clamp inside the key
+    // loop (it was ~14 VALU instructions per key tile in a loop that is bound by instruction issue).  Key rows past the end of the plane
+    // read the next plane / the descriptor's out-of-range zeros: finite, and masked to -inf below; V^T is zero padded to vt_kp keys.
+    typedef __attribute__((address_space(3))) unsigned char* lds_bptr;
+    const long long kplane_bytes = (long long)N * 256;
+    const long long kavail = ((((long long)p.B * 3 - ((long long)b * 3 + ty)) * p.H - h) * kplane_bytes);      // bytes from this plane to the end of qkvs
+    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)Ysp, 0, (int)(kavail < (1LL << 31) - 1 ? kavail : (1LL << 31) - 1), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)(FLASH ? VT : Ysp), 0, FLASH ? (int)(64LL * 2 * p.vt_kp * 2) : 0, 0x00020000);
+    int koffb[2], voffb[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        krow[j] = wave * 8 + j * 4 + (lane >> 4);
-        koff[j] = ((lane & 15) ^ (krow[j] & 15)) * 8;
-    }
-    long long voff[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
+        const int krow = wave * 8 + j * 4 + (lane >> 4);                 // row of the tile this lane loads a chunk of
+        koffb[j] = krow * 256 + (((lane & 15) ^ (krow & 15)) * 16);
         const int d = wave * 16 + j * 8 + (lane >> 3);
-        voff[j] = (long long)d * 2 * p.vt_kp + (((lane & 7) ^ ((d >> 1) & 7)) * 8);
+        voffb[j] = FLASH ? d * 2 * p.vt_kp * 2 + (((lane & 7) ^ ((d >> 1) & 7)) * 16) : 0;
     }
     // piece idx of this wave's PER_WAVE 1-KB loads of key tile kt: 0, 1 = K rows, 2, 3 = V^T rows (flash only)
     auto issue_piece = [&](int kt, int stage, int idx) {
-        u16* dstk = ring + stage * STAGE_EL;
+        unsigned dstk = __builtin_amdgcn_readfirstlane(ring_b + stage * (STAGE_EL * 2));     // wave-uniform (it goes into m0); also keeps
+        asm volatile("" : "+s"(dstk));                                                         // the per-piece destinations out of hoisted SGPRs
         if (idx < 2) {
-            const int j = idx;
-            const int key = min(kt * 32 + krow[j], N - 1);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ysp + (long long)key * 128 + koff[j]),
-                                             (__attribute__((address_space(3))) void*)(dstk + (wave * 8 + j * 4) * 128), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_bptr)(unsigned long long)(dstk + (wave * 8 + idx * 4) * 256), 16, koffb[idx], kt * (32 * 256), 0, 0);
         } else if (FLASH) {
             const int j = idx - 2;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(VT + voff[j] + kt * 64),
-                                             (__attribute__((address_space(3))) void*)(dstk + KT_EL + (wave * 16 + j * 8) * 64), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_bptr)(unsigned long long)(dstk + (KT_EL + (wave * 16 + j * 8) * 64) * 2), 16, voffb[j], kt * 128, 0, 0);
         }
     };
     auto issue = [&](int kt, int stage) {
