@@ -17,6 +17,7 @@
 // sub, mul, fma per guide channel + sub, v_exp_f32, fma - no separate multiplications by 1/3 and log2(e).
 #include <stdlib.h>
 #include <type_traits>
+#include <utility>
 #include "common.h"
 #include "excel_internal.h"
 
@@ -164,42 +165,55 @@ __global__ __launch_bounds__(256) void par_iterate_stream_kernel(const float* __
 // Jacobi step that RECOMPUTES the affinities from the guide image (par_affinity_kernel COMPACT statistics).
 // The 48 weights of a pixel are a function of 3 image values per tap and 5 per-pixel statistics; streaming them as 48 fp32
 // planes made the step HBM-bound at (48 + 2C) x 4 B/pixel - here a step reads (5 + 3 + 2C) x 4 B/pixel and pays
-// ~8 VALU operations per tap.  One workgroup = a 64 x 16 pixel tile (thread = 4 pixels); the planes it needs - the three guide
-// channels, then the image's mask channels - go through a DOUBLE-BUFFERED LDS tile (64 rows x 128 floats incl. the 24-pixel halo),
-// filled by LDS-DMA (16-byte pieces for interior tiles, 4-byte pieces with edge-clamped per-lane source addresses = replicate padding
-// at the left / right border): plane p+1 streams in while the taps of plane p are evaluated, one barrier per plane, no staging
-// registers.  Phase 1 (guide planes) accumulates the tap exponents in wall[ND][8] (float4 = this thread's 4 pixels), a finalisation
-// turns them into the weights, phase 2 (mask planes) applies them.
+// ~8 VALU operations per tap.  One workgroup = a 64 x 16 pixel tile, 512 threads, thread = 2 pixels; the planes it needs - the
+// three guide channels, then the image's mask channels - go through a DOUBLE-BUFFERED LDS tile (64 rows x 128 floats incl. the
+// 24-pixel halo), filled by LDS-DMA (16-byte pieces for interior tiles, 4-byte pieces with edge-clamped per-lane source addresses =
+// replicate padding at the left / right border): plane p+1 streams in while the taps of plane p are evaluated, one barrier per plane,
+// no staging registers.  Phase 1 (guide planes) accumulates the tap exponents in wall[6][8] (float2 = this thread's 2 pixels), a
+// finalisation turns them into the weights, phase 2 (mask planes) applies them.
 // Same operations in the same order as par_affinity_kernel + the streamed-plane kernel -> bit-identical results.
 // RAGGED: the tile comes from the tile map, rows are pitched (Wp = W rounded up to 4): any width works, the (up to 3) padding columns
 // of a row are computed and stored like pixels and never read as neighbours (border tiles clamp their source columns to W - 1).
-#define PG_TP 128            // LDS row pitch (floats): 512 B keeps every ds_read_b128 group on distinct banks
-template <int ND, int HALO, bool RAGGED>
-__global__ __launch_bounds__(256, 2) void par_iterate_guide_kernel(const float* __restrict__ guide, const float* __restrict__ stats,
-                                                                   const float* __restrict__ in, float* __restrict__ out,
-                                                                   const int* __restrict__ nchan, ParDil dl, int Cmax, TileGeo geo, int dbg) {
-    constexpr int TR = 16 + 2 * HALO, TP = PG_TP;
-    static_assert(64 + 2 * HALO <= TP, "tile row does not fit the LDS pitch");
+//
+// Thread = 2 pixels keeps the 96 weight registers + everything else under 128 VGPRs -> 4 waves per SIMD, two workgroups per CU (round
+// 2's float4 form held 192 weights in 256 VGPRs: 2 waves per SIMD, and every tap row waited out its own LDS round trip - the mask
+// phase issued 6 packed fma per ~130 cycles; measured 4.47 -> 3.39 ms per 32-image step, same bits).  The dilation set is a compile-time
+// constant (par_dil_ok admits nothing else), so every tap address is ONE per-thread base register + an immediate offset: no per-tap
+// address arithmetic, and tap row g+1 is in flight while row g is consumed (counted lgkmcnt).
+#define PG_TP 128            // LDS row pitch (floats): 512 B keeps every ds_read group on distinct banks
+template <int DI> struct ParD { static constexpr int v = DI == 0 ? 1 : DI == 1 ? 2 : DI == 2 ? 4 : DI == 3 ? 8 : DI == 4 ? 12 : 24; };
+template <class F, int... I> __device__ __forceinline__ void static_for_seq(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_seq(f, std::make_integer_sequence<int, N>{}); }
+template <int OFF> __device__ __forceinline__ f32x2 lds_read8_imm(unsigned base) {
+    static_assert(OFF >= 0 && OFF < 65536 && (OFF & 7) == 0, "ds_read_b64 immediate offset");
+    f32x2 v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(base), "n"(OFF) : "memory");
+    return v;
+}
+
+template <bool RAGGED>
+__global__ __launch_bounds__(512, 4) void par_iterate_guide_kernel(const float* __restrict__ guide, const float* __restrict__ stats,
+                                                                    const float* __restrict__ in, float* __restrict__ out,
+                                                                    const int* __restrict__ nchan, ParDil dl, int Cmax, TileGeo geo, int dbg) {
+    constexpr int ND = 6, HALO = 24, TR = 16 + 2 * HALO, TP = PG_TP, NG = 3 * ND;
     __shared__ __attribute__((aligned(1024))) float tile[2 * TR * TP];   // [2][TR][TP]
     const Tile tg = tile_of<RAGGED>(geo);
     const int b = tg.b, x0 = tg.x0, y0 = tg.y0, H = tg.H, W = tg.W, Wp = tg.Wp;
     const long long HW = tg.HW;
-    const int tid = threadIdx.x, lane = tid & 63, tx = tid & 15, ty = tid >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, tx = tid & 31, ty = tid >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int px = x0 + 4 * tx, py = y0 + ty;
+    const int px = x0 + 2 * tx, py = y0 + ty;
     const int nch = nchan ? min(nchan[b], Cmax) : Cmax;
-    const long long pix = (long long)min(py, H - 1) * Wp + min(px, Wp - 4);
+    const long long pix = (long long)min(py, H - 1) * Wp + min(px, Wp - 2);
     const float* st_b = stats + 5 * tg.base + pix;
 
-    // ---- plane staging by LDS-DMA: wave w fills rows [w*TR/4, (w+1)*TR/4) of the tile, two 64-float pieces per row
+    // ---- plane staging by LDS-DMA: wave w fills rows [w*TR/8, (w+1)*TR/8) of the tile
     typedef __attribute__((address_space(3))) unsigned char* lds_bptr;
     const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)(guide + 3 * tg.base), 0, (int)(3 * HW * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc((void*)(in + (long long)Cmax * tg.base), 0, (int)((long long)Cmax * HW * 4), 0x00020000);
     const int xoffA = min(max(x0 - HALO + lane, 0), W - 1) * 4, xoffB = min(max(x0 - HALO + 64 + lane, 0), W - 1) * 4;   // replicate padding in x
     const unsigned tile_b = lds_addr(tile);
-    constexpr int RPW = TR / 4;                                  // rows per wave
-    // tiles that do not touch the left / right image border need no replication in x: 16-byte DMA, one instruction = two tile rows
-    // (4x fewer instructions than the 4-byte form the border tiles need for per-element clamping)
+    constexpr int RPW = TR / 8;                                  // rows per wave
     const bool interior = x0 - HALO >= 0 && x0 + 64 + HALO <= W;
     const int x4off = min(x0 - HALO + 4 * (lane & 31), Wp - 4) * 4;         // (columns >= 64 + 2 HALO of the 128-float row are never read)
     auto stage = [&](int p, int buf) {                           // plane p of the sequence [guide 0..2, mask 0..nch-1] -> buffer buf
@@ -208,9 +222,11 @@ __global__ __launch_bounds__(256, 2) void par_iterate_guide_kernel(const float* 
         unsigned dst = tile_b + (buf * TR + wave * RPW) * (TP * 4);
         asm volatile("" : "+s"(dst));
         if (interior) {
-#pragma unroll 4
+            int half = lane >> 5;                                // opaque: the per-lane source offsets are recomputed per plane (hoisted out of
+            asm volatile("" : "+v"(half));                       // the plane loops they were live across the weight registers and spilled)
+#pragma unroll
             for (int j = 0; j < RPW / 2; ++j) {
-                const int gy = min(max(y0 - HALO + wave * RPW + 2 * j + (lane >> 5), 0), H - 1);   // replicate padding in y (per half-wave)
+                const int gy = min(max(y0 - HALO + wave * RPW + 2 * j + half, 0), H - 1);   // replicate padding in y (per half-wave)
                 const int voff = gy * Wp * 4 + x4off;
                 if (is_g) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_bptr)(unsigned long long)(dst + j * (2 * TP * 4)), 16, voff, plane_off, 0, 0);
                 else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_m, (lds_bptr)(unsigned long long)(dst + j * (2 * TP * 4)), 16, voff, plane_off, 0, 0);
@@ -231,123 +247,104 @@ __global__ __launch_bounds__(256, 2) void par_iterate_guide_kernel(const float* 
         }
     };
 
-    f32x4 wall[ND][8];
+    f32x2 wall[ND][8];
 #pragma unroll
     for (int di = 0; di < ND; ++di)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) wall[di][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < 8; ++k) wall[di][k] = f32x2{0.f, 0.f};
 
-    // taps of one staged plane: FN(di, k, float4 of the 4 neighbours); LDS reads as inline asm (a compiler-visible ds_read behind the
-    // pending LDS-DMA of the NEXT plane would be preceded by s_waitcnt vmcnt(0))
-    const int cb = HALO + 4 * tx;
-    auto taps = [&](int buf, auto&& fn) {
-        // opaque per plane: otherwise the ~50 per-lane LDS tap addresses (x 2 buffers) are hoisted out of the plane loop and compete
-        // with the pinned weight registers (spills)
-        int tq = threadIdx.x;                                    // (recomputed from the thread index: cb / ty carried from the top of
-        asm volatile("" : "+v"(tq));                              //  the kernel were live across the weight registers and spilled)
-        const int cbo = HALO + 4 * (tq & 15), tyo = tq >> 4;
-        const unsigned base = tile_b + buf * (TR * TP * 4);
-#pragma unroll
-        for (int di = 0; di < ND; ++di) {
-            const int d = dl.d[di];
-            const int rrow[3] = {tyo + HALO - d, tyo + HALO, tyo + HALO + d};
-            if ((d & 3) == 0) {
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {                    // one tap row at a time: at most 3 float4 in flight next to the 192 weight registers
-                    const unsigned rowa = base + (rrow[r] * TP + cbo) * 4;
-                    f32x4 L, M, R;
-                    asm volatile("ds_read_b128 %0, %1" : "=v"(L) : "v"(rowa - d * 4) : "memory");
-                    if (r != 1) asm volatile("ds_read_b128 %0, %1" : "=v"(M) : "v"(rowa) : "memory");
-                    asm volatile("ds_read_b128 %0, %1" : "=v"(R) : "v"(rowa + d * 4) : "memory");
-                    if (r != 1) {
-                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(L), "+v"(M), "+v"(R)::"memory");
-                        fn(di, r == 0 ? 0 : 5, L);
-                        fn(di, r == 0 ? 1 : 6, M);
-                        fn(di, r == 0 ? 2 : 7, R);
-                    } else {
-                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(L), "+v"(R)::"memory");
-                        fn(di, 3, L);
-                        fn(di, 4, R);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);           // consume this row before the next row's reads are issued
-                }
+    // taps of one staged plane: FN(di, k, float2 of the 2 neighbours) in tap order.  Tap row g = (dilation g/3, row -d / 0 / +d) is
+    // 3 (2 for the centre row) ds_read_b64 from `base` = the thread's tile origin in the plane's buffer; row g+1 is issued before
+    // row g is consumed.  d = 1 reads the aligned pairs around the pixel pair and shifts.
+    const unsigned org = tile_b + (ty * TP + 2 * tx) * 4;
+    auto taps = [&](int buf, auto&& fn, auto&& pin) {
+        unsigned base = org + buf * (TR * TP * 4);
+        asm volatile("" : "+v"(base));
+        f32x2 sl[2][3];
+        auto issue = [&](auto g) {
+            constexpr int G = decltype(g)::value, r = G % 3, d = ParD<G / 3>::v, s = G & 1;
+            constexpr int row = (HALO + (r - 1) * d) * TP * 4, cl = (d == 1) ? HALO - 2 : HALO - d, cr = (d == 1) ? HALO + 2 : HALO + d;
+            sl[s][0] = lds_read8_imm<row + cl * 4>(base);
+            if constexpr (r != 1 || d == 1) sl[s][1] = lds_read8_imm<row + HALO * 4>(base);
+            sl[s][2] = lds_read8_imm<row + cr * 4>(base);
+        };
+        issue(std::integral_constant<int, 0>{});
+        static_for<NG>([&](auto g) {
+            constexpr int G = decltype(g)::value, di = G / 3, r = G % 3, d = ParD<di>::v, s = G & 1;
+            constexpr bool mid = (r != 1 || d == 1);
+            if constexpr (G + 1 < NG) {
+                issue(std::integral_constant<int, G + 1>{});
+                constexpr int nxt = ((G + 1) % 3 != 1 || ParD<(G + 1) / 3>::v == 1) ? 3 : 2;      // reads of row g+1 may stay in flight
+                if constexpr (mid) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(sl[s][0]), "+v"(sl[s][1]), "+v"(sl[s][2]) : "n"(nxt) : "memory");
+                else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(sl[s][0]), "+v"(sl[s][2]) : "n"(nxt) : "memory");
             } else {
-                auto window = [&](auto shift_tag) {
-                    constexpr int SH = decltype(shift_tag)::value;
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        const unsigned rowa = base + (rrow[r] * TP + cbo) * 4;
-                        f32x4 L, M, R;
-                        asm volatile("ds_read_b128 %0, %1" : "=v"(L) : "v"(rowa - 16) : "memory");
-                        asm volatile("ds_read_b128 %0, %1" : "=v"(M) : "v"(rowa) : "memory");
-                        asm volatile("ds_read_b128 %0, %1" : "=v"(R) : "v"(rowa + 16) : "memory");
-                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(L), "+v"(M), "+v"(R)::"memory");
-                        const float win[12] = {L[0], L[1], L[2], L[3], M[0], M[1], M[2], M[3], R[0], R[1], R[2], R[3]};
-#pragma unroll
-                        for (int dx = -1; dx <= 1; ++dx) {
-                            if (r == 1 && dx == 0) continue;
-                            const int k = (r == 0) ? dx + 1 : (r == 1 ? (dx < 0 ? 3 : 4) : dx + 6);
-                            fn(di, k, f32x4{win[4 + SH * dx], win[5 + SH * dx], win[6 + SH * dx], win[7 + SH * dx]});
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                };
-                if (d == 1) window(std::integral_constant<int, 1>{});
-                else if (d == 2) window(std::integral_constant<int, 2>{});
-                else window(std::integral_constant<int, 3>{});
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sl[s][0]), "+v"(sl[s][1]), "+v"(sl[s][2])::"memory");
             }
-        }
+            constexpr int k0 = (r == 0) ? 0 : (r == 1 ? 3 : 5);
+            const f32x2 L = sl[s][0], R = sl[s][2];
+            if constexpr (d == 1) {
+                const f32x2 M = sl[s][1];
+                fn(di, k0, f32x2{L[1], M[0]});
+                if constexpr (r != 1) fn(di, k0 + 1, M);
+                fn(di, k0 + (r != 1 ? 2 : 1), f32x2{M[1], R[0]});
+            } else {
+                fn(di, k0, L);
+                if constexpr (r != 1) fn(di, k0 + 1, sl[s][1]);
+                fn(di, k0 + (r != 1 ? 2 : 1), R);
+            }
+            pin();                                               // row g is consumed HERE, between the reads of rows g+1 and g+2
+            __builtin_amdgcn_sched_barrier(0);
+        });
     };
 
     const int np = 3 + nch;
     stage(0, 0);
-    // phase 1 in its own loop (one body: with two different bodies in one rolled loop the 192 in-place accumulators were copied / spilled)
 #pragma unroll 1
     for (int p = 0; p < 3; ++p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's pieces of plane p have landed
         __builtin_amdgcn_s_barrier();                                // ... everyone's have, and everyone is done with plane p-1's buffer
         stage(p + 1, (p + 1) & 1);                                   // (np >= 4) streams in behind the taps below
         if (EXCEL_DBG(dbg) & 1) continue;
-        // guide channel p:  z_t += -(I_nb - I)^2 k2_p   as fma(dv dv, -k2, z), dv = nb + (-ctr): bit-identical to the affinity kernel,
-        // in forms that map onto packed VALU instructions without separate negations
-        const f32x4 nk2 = -*reinterpret_cast<const f32x4*>(st_b + (long long)p * HW);
-        f32x4 ctr;
-        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(ctr) : "v"(tile_b + (((p & 1) * TR + ty + HALO) * TP + cb) * 4) : "memory");
-        const f32x4 nctr = -ctr;
-        taps(p & 1, [&](int di, int k, const f32x4 nb) {
-            const f32x4 dv = nb + nctr;
+        // guide channel p:  z_t += -(I_nb - I)^2 k2_p   as fma(dv dv, -k2, z), dv = nb + (-ctr): bit-identical to the affinity kernel.
+        // (-ctr is opaque: the compiler otherwise folds the negation back and emits two unpacked v_sub_f32 instead of one v_pk_add_f32)
+        const f32x2 nk2 = -*reinterpret_cast<const f32x2*>(st_b + (long long)p * HW);
+        f32x2 ctr;
+        asm volatile("ds_read_b64 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(ctr) : "v"(org + (p & 1) * (TR * TP * 4)), "n"((HALO * TP + HALO) * 4) : "memory");
+        f32x2 nctr = -ctr;
+        asm volatile("" : "+v"(nctr));
+        taps(p & 1, [&](int di, int k, const f32x2 nb) {
+            const f32x2 dv = nb + nctr;
             wall[di][k] = __builtin_elementwise_fma(dv * dv, nk2, wall[di][k]);
-        });
+        }, [] {});
     }
     if (!(EXCEL_DBG(dbg) & 2)) {
-        // aff_t = 2^(z_t - m) / sum + pos_t : the affinity kernel's operations, one rounding each
-        const f32x4 m4 = *reinterpret_cast<const f32x4*>(st_b + 3 * HW), is4 = *reinterpret_cast<const f32x4*>(st_b + 4 * HW);
+        // aff_t = 2^(z_t - m) / sum + pos_t : the affinity kernel's operations, one rounding each (z + (-m) == z - m)
+        f32x2 nm2 = -*reinterpret_cast<const f32x2*>(st_b + 3 * HW);
+        asm volatile("" : "+v"(nm2));
+        const f32x2 is2 = *reinterpret_cast<const f32x2*>(st_b + 4 * HW);
 #pragma unroll
         for (int di = 0; di < ND; ++di)
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                f32x4 e;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_exp2f(__fsub_rn(wall[di][k][j], m4[j]));
+                const f32x2 z = wall[di][k] + nm2;
+                const f32x2 e = {__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])};
                 const float ps = dl.pos_sm[di * 8 + k];
-                wall[di][k] = __builtin_elementwise_fma(e, is4, f32x4{ps, ps, ps, ps});
+                wall[di][k] = __builtin_elementwise_fma(e, is2, f32x2{ps, ps});
             }
     }
-    // phase 2: the weights are loop invariant.  The output position is recomputed here from the thread index (opaque to the optimiser):
-    // carried from the top of the kernel it was live across the 192 pinned weight registers and went to scratch.
-    int tid2 = threadIdx.x;
-    asm volatile("" : "+v"(tid2));
-    const int px2 = x0 + 4 * (tid2 & 15), py2 = y0 + (tid2 >> 4);
-    const bool valid2 = px2 < W && py2 < H;
-    float* out_px = out + (long long)Cmax * tg.base + (long long)py2 * Wp + px2;
+    const bool valid = px < W && py < H;
+    float* out_px = out + (long long)Cmax * tg.base + (long long)py * Wp + px;
     for (int p = 3; p < np; ++p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (p + 1 < np) stage(p + 1, (p + 1) & 1);
         if (EXCEL_DBG(dbg) & 4) continue;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        taps(p & 1, [&](int di, int k, const f32x4 nb) { acc = __builtin_elementwise_fma(nb, wall[di][k], acc); });   // tap order, fused
-        if (valid2) *reinterpret_cast<f32x4*>(out_px + (long long)(p - 3) * HW) = acc;
+        f32x2 acc = {0.f, 0.f};
+        // (acc is pinned per tap row: it is only stored under `valid`, and the whole fma chain was otherwise sunk into that branch,
+        //  behind all 50 reads of the plane)
+        taps(p & 1, [&](int di, int k, const f32x2 nb) { acc = __builtin_elementwise_fma(nb, wall[di][k], acc); },   // tap order, fused
+             [&] { asm volatile("" : "+v"(acc)); });
+        if (valid) *reinterpret_cast<f32x2*>(out_px + (long long)(p - 3) * HW) = acc;
     }
 }
 
@@ -543,8 +540,8 @@ int excel_launch_par_iterate(const float* aff, const float* in, float* out, cons
 }
 
 // The recomputing step is built for the dilation set every caller of the reference uses, [1,2,4,8,12,24] (tools/infer_lam.py:168,
-// scripts/train_voc.py:112, scripts/train_coco.py:110): 6 x 8 float4 weights stay in registers (192 of 256 VGPRs), halo 24, taps
-// that are multiples of 4 or <= 3.  Any other set goes through the streamed kernel.
+// scripts/train_voc.py:112, scripts/train_coco.py:110): 6 x 8 float2 weights stay in registers (96 of 128 VGPRs), halo 24, tap
+// offsets as compile-time immediates.  Any other set goes through the streamed kernel.
 static bool par_dil_ok(const int* dil, int ndil) {
     static const int want[6] = {1, 2, 4, 8, 12, 24};
     if (ndil != 6) return false;
@@ -574,9 +571,9 @@ int excel_launch_par_iterate_guide(const float* guide, const float* stats, const
     dbg = env_dbg;
 #endif
     if (geo.tab)
-        hipLaunchKernelGGL((par_iterate_guide_kernel<6, 24, true>), dim3(total_tiles), dim3(256), 0, st, guide, stats, in, out, nchan, dl, Cmax, geo, dbg);
+        hipLaunchKernelGGL((par_iterate_guide_kernel<true>), dim3(total_tiles), dim3(512), 0, st, guide, stats, in, out, nchan, dl, Cmax, geo, dbg);
     else
-        hipLaunchKernelGGL((par_iterate_guide_kernel<6, 24, false>), dim3(cdiv(geo.W, 64), cdiv(geo.H, 16), geo.B), dim3(256), 0, st, guide, stats,
+        hipLaunchKernelGGL((par_iterate_guide_kernel<false>), dim3(cdiv(geo.W, 64), cdiv(geo.H, 16), geo.B), dim3(512), 0, st, guide, stats,
                            in, out, nchan, dl, Cmax, geo, dbg);
     EXCEL_CHECK_LAUNCH("par_iterate_guide");
     return EXCEL_OK;
