@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void par_affinity_kernel(const float* __restri
         const float mean = sum / (float)NT;
         float var = 0.f;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) { const float dv = nb[t] - mean; var += dv * dv; }
+        for (int t = 0; t < NT; ++t) { const float dv = nb[t] - mean; var = fmaf(dv, dv, var); }      // (explicit: par_stats_tile_kernel must round alike)
         const float den = sqrtf(var / (float)(NT - 1)) + 1e-8f;     // unbiased std (torch.std default)
         // (|nb - ctr| / den / w1)^2 / 3 * log2(e) as one fma per tap: 3 true divisions per pixel instead of 2 x 144 (the divisions
         // were ~80 % of this kernel's instructions); differs from the literal form by two roundings (~2e-7 relative)
@@ -348,6 +348,156 @@ __global__ __launch_bounds__(512, 4) void par_iterate_guide_kernel(const float* 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The COMPACT statistics (k2_r, k2_g, k2_b, m, 1/sum) of the 6-dilation set through the SAME tile machinery as the Jacobi step: a
+// guide plane is staged once per 64 x 16 tile (LDS-DMA, halo 24) and its 48 taps are read three times from LDS - tap sum (-> mean),
+// squared deviations (-> unbiased std -> k2), exponent accumulation - instead of 144 edge-clamped global loads per pixel and 48 live
+// tap registers (par_affinity_kernel: 320 us per 32 x 448^2 step).  Same operations per pixel in the same order as
+// par_affinity_kernel -> the same bits (tests: recompute == streamed, ragged == per-image).
+template <bool RAGGED>
+__global__ __launch_bounds__(512, 4) void par_stats_tile_kernel(const float* __restrict__ guide, float* __restrict__ stats, TileGeo geo, float w1) {
+    constexpr int ND = 6, HALO = 24, TR = 16 + 2 * HALO, TP = PG_TP, NG = 3 * ND, NT = 8 * ND;
+    __shared__ __attribute__((aligned(1024))) float tile[2 * TR * TP];   // [2][TR][TP]
+    const Tile tg = tile_of<RAGGED>(geo);
+    const int x0 = tg.x0, y0 = tg.y0, H = tg.H, W = tg.W, Wp = tg.Wp;
+    const long long HW = tg.HW;
+    const int tid = threadIdx.x, lane = tid & 63, tx = tid & 31, ty = tid >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = x0 + 2 * tx, py = y0 + ty;
+
+    // ---- plane staging by LDS-DMA, as in par_iterate_guide_kernel
+    typedef __attribute__((address_space(3))) unsigned char* lds_bptr;
+    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)(guide + 3 * tg.base), 0, (int)(3 * HW * 4), 0x00020000);
+    const int xoffA = min(max(x0 - HALO + lane, 0), W - 1) * 4, xoffB = min(max(x0 - HALO + 64 + lane, 0), W - 1) * 4;   // replicate padding in x
+    const unsigned tile_b = lds_addr(tile);
+    constexpr int RPW = TR / 8;
+    const bool interior = x0 - HALO >= 0 && x0 + 64 + HALO <= W;
+    const int x4off = min(x0 - HALO + 4 * (lane & 31), Wp - 4) * 4;
+    auto stage = [&](int p, int buf) {
+        const int plane_off = p * (int)(HW * 4);
+        unsigned dst = tile_b + (buf * TR + wave * RPW) * (TP * 4);
+        asm volatile("" : "+s"(dst));
+        if (interior) {
+            int half = lane >> 5;
+            asm volatile("" : "+v"(half));
+#pragma unroll
+            for (int j = 0; j < RPW / 2; ++j) {
+                const int gy = min(max(y0 - HALO + wave * RPW + 2 * j + half, 0), H - 1);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_bptr)(unsigned long long)(dst + j * (2 * TP * 4)), 16, gy * Wp * 4 + x4off, plane_off, 0, 0);
+            }
+            return;
+        }
+#pragma unroll 4
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int gy = min(max(y0 - HALO + wave * RPW + rr, 0), H - 1);
+            const int soff = plane_off + gy * Wp * 4;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_bptr)(unsigned long long)(dst + rr * (TP * 4)), 4, xoffA, soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_bptr)(unsigned long long)(dst + rr * (TP * 4) + 256), 4, xoffB, soff, 0, 0);
+        }
+    };
+
+    f32x2 acc[ND][8];
+#pragma unroll
+    for (int di = 0; di < ND; ++di)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[di][k] = f32x2{0.f, 0.f};
+
+    const unsigned org = tile_b + (ty * TP + 2 * tx) * 4;
+    auto taps = [&](int buf, auto&& fn, auto&& pin) {            // (par_iterate_guide_kernel: tap row g+1 in flight behind row g)
+        unsigned base = org + buf * (TR * TP * 4);
+        asm volatile("" : "+v"(base));
+        f32x2 sl[2][3];
+        auto issue = [&](auto g) {
+            constexpr int G = decltype(g)::value, r = G % 3, d = ParD<G / 3>::v, s = G & 1;
+            constexpr int row = (HALO + (r - 1) * d) * TP * 4, cl = (d == 1) ? HALO - 2 : HALO - d, cr = (d == 1) ? HALO + 2 : HALO + d;
+            sl[s][0] = lds_read8_imm<row + cl * 4>(base);
+            if constexpr (r != 1 || d == 1) sl[s][1] = lds_read8_imm<row + HALO * 4>(base);
+            sl[s][2] = lds_read8_imm<row + cr * 4>(base);
+        };
+        issue(std::integral_constant<int, 0>{});
+        static_for<NG>([&](auto g) {
+            constexpr int G = decltype(g)::value, di = G / 3, r = G % 3, d = ParD<di>::v, s = G & 1;
+            constexpr bool mid = (r != 1 || d == 1);
+            if constexpr (G + 1 < NG) {
+                issue(std::integral_constant<int, G + 1>{});
+                constexpr int nxt = ((G + 1) % 3 != 1 || ParD<(G + 1) / 3>::v == 1) ? 3 : 2;
+                if constexpr (mid) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(sl[s][0]), "+v"(sl[s][1]), "+v"(sl[s][2]) : "n"(nxt) : "memory");
+                else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(sl[s][0]), "+v"(sl[s][2]) : "n"(nxt) : "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sl[s][0]), "+v"(sl[s][1]), "+v"(sl[s][2])::"memory");
+            }
+            constexpr int k0 = (r == 0) ? 0 : (r == 1 ? 3 : 5);
+            const f32x2 L = sl[s][0], R = sl[s][2];
+            if constexpr (d == 1) {
+                const f32x2 M = sl[s][1];
+                fn(di, k0, f32x2{L[1], M[0]});
+                if constexpr (r != 1) fn(di, k0 + 1, M);
+                fn(di, k0 + (r != 1 ? 2 : 1), f32x2{M[1], R[0]});
+            } else {
+                fn(di, k0, L);
+                if constexpr (r != 1) fn(di, k0 + 1, sl[s][1]);
+                fn(di, k0 + (r != 1 ? 2 : 1), R);
+            }
+            pin();
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
+    const bool valid = px < W && py < H;
+    float* st_px = stats + 5 * tg.base + (long long)py * Wp + px;
+    stage(0, 0);
+#pragma unroll 1
+    for (int p = 0; p < 3; ++p) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (p + 1 < 3) stage(p + 1, (p + 1) & 1);
+        f32x2 ctr;
+        asm volatile("ds_read_b64 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(ctr) : "v"(org + (p & 1) * (TR * TP * 4)), "n"((HALO * TP + HALO) * 4) : "memory");
+        // unbiased std over the 48 taps (torch.std): tap sum in tap order, then the squared deviations from the mean in tap order
+        f32x2 sum = {0.f, 0.f};
+        taps(p & 1, [&](int, int, const f32x2 nb) { sum += nb; }, [&] { asm volatile("" : "+v"(sum)); });
+        const f32x2 mean = {sum[0] / (float)NT, sum[1] / (float)NT};
+        f32x2 nmean = -mean;
+        asm volatile("" : "+v"(nmean));
+        f32x2 var = {0.f, 0.f};
+        taps(p & 1, [&](int, int, const f32x2 nb) { const f32x2 dv = nb + nmean; var = __builtin_elementwise_fma(dv, dv, var); },
+             [&] { asm volatile("" : "+v"(var)); });
+        f32x2 k2;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float den = sqrtf(var[q] / (float)(NT - 1)) + 1e-8f;
+            const float k = 1.f / (den * w1);
+            k2[q] = __fmul_rn(k * k, PAR_LOG2E_3);
+        }
+        if (valid) *reinterpret_cast<f32x2*>(st_px + (long long)p * HW) = k2;
+        f32x2 nk2 = -k2, nctr = -ctr;
+        asm volatile("" : "+v"(nctr));
+        taps(p & 1, [&](int di, int k, const f32x2 nb) {
+            const f32x2 dv = nb + nctr;
+            acc[di][k] = __builtin_elementwise_fma(dv * dv, nk2, acc[di][k]);
+        }, [] {});
+    }
+    f32x2 m = {-INFINITY, -INFINITY};
+#pragma unroll
+    for (int di = 0; di < ND; ++di)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { m[0] = fmaxf(m[0], acc[di][k][0]); m[1] = fmaxf(m[1], acc[di][k][1]); }
+    f32x2 nm = -m;
+    asm volatile("" : "+v"(nm));
+    f32x2 ssum = {0.f, 0.f};
+#pragma unroll
+    for (int di = 0; di < ND; ++di)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const f32x2 z = acc[di][k] + nm;
+            ssum += f32x2{__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])};
+        }
+    if (valid) {
+        *reinterpret_cast<f32x2*>(st_px + 3 * HW) = m;
+        *reinterpret_cast<f32x2*>(st_px + 4 * HW) = f32x2{1.f / ssum[0], 1.f / ssum[1]};
+    }
+}
+
 // F.interpolate(mode='bilinear', align_corners=True) (PAR.py:67): planes of h x w -> H x W
 __device__ __forceinline__ float bilinear_ac_px(const float* __restrict__ p, int h, int w, int H, int W, int x, int y) {
     const float sy = (H > 1) ? (float)(h - 1) / (float)(H - 1) : 0.f;
@@ -509,6 +659,16 @@ static int make_dil(const int* dil, int ndil, float w1, float w2, ParDil* out) {
         default: CALL(8); break;            \
     }
 
+// The recomputing step is built for the dilation set every caller of the reference uses, [1,2,4,8,12,24] (tools/infer_lam.py:168,
+// scripts/train_voc.py:112, scripts/train_coco.py:110): 6 x 8 float2 weights stay in registers (96 of 128 VGPRs), halo 24, tap
+// offsets as compile-time immediates.  Any other set goes through the streamed kernel.
+static bool par_dil_ok(const int* dil, int ndil) {
+    static const int want[6] = {1, 2, 4, 8, 12, 24};
+    if (ndil != 6) return false;
+    for (int i = 0; i < 6; ++i)
+        if (dil[i] != want[i]) return false;
+    return true;
+}
 // geo.tab != nullptr: ragged batch of `total_tiles` 64x16 tiles (img / aff in the pitched layout); else uniform [B,.,H,W]
 int excel_launch_par_affinity(const float* img, float* aff, const TileGeo& geo, int total_tiles, const int* dil, int ndil, float w1, float w2,
                               hipStream_t st, int compact) {
@@ -516,9 +676,15 @@ int excel_launch_par_affinity(const float* img, float* aff, const TileGeo& geo, 
     ParDil dl;
     int rc = make_dil(dil, ndil, w1, w2, &dl);
     if (rc) return rc;
+    // compact statistics of the standard dilation set, 16-byte aligned pitched planes: the tile kernel
+    const bool tiled = compact && par_dil_ok(dil, ndil) && ((((uintptr_t)img | (uintptr_t)aff) & 15) == 0) &&
+                       (geo.tab ? true : (geo.W % 4 == 0 && geo.W >= 8 && 5LL * geo.H * geo.W * 4 < (1LL << 31)));
     if (geo.tab) {
         EXCEL_CHECK_ARG(compact && ndil == 6, "par_affinity: ragged batches use the compact statistics of the 6-dilation kernel");
-        hipLaunchKernelGGL((par_affinity_kernel<6, true>), dim3(total_tiles, 4), dim3(256), 0, st, img, aff, dl, geo, w1, 1);
+        if (tiled) hipLaunchKernelGGL((par_stats_tile_kernel<true>), dim3(total_tiles), dim3(512), 0, st, img, aff, geo, w1);
+        else hipLaunchKernelGGL((par_affinity_kernel<6, true>), dim3(total_tiles, 4), dim3(256), 0, st, img, aff, dl, geo, w1, 1);
+    } else if (tiled) {
+        hipLaunchKernelGGL((par_stats_tile_kernel<false>), dim3(cdiv(geo.W, 64), cdiv(geo.H, 16), geo.B), dim3(512), 0, st, img, aff, geo, w1);
     } else {
 #define CALL(N) hipLaunchKernelGGL((par_affinity_kernel<N, false>), dim3(cdiv(geo.W, 64), cdiv(geo.H, 4), geo.B), dim3(256), 0, st, img, aff, dl, geo, w1, compact ? 1 : 0)
         ND_SWITCH(ndil, CALL)
@@ -539,16 +705,6 @@ int excel_launch_par_iterate(const float* aff, const float* in, float* out, cons
     return EXCEL_OK;
 }
 
-// The recomputing step is built for the dilation set every caller of the reference uses, [1,2,4,8,12,24] (tools/infer_lam.py:168,
-// scripts/train_voc.py:112, scripts/train_coco.py:110): 6 x 8 float2 weights stay in registers (96 of 128 VGPRs), halo 24, tap
-// offsets as compile-time immediates.  Any other set goes through the streamed kernel.
-static bool par_dil_ok(const int* dil, int ndil) {
-    static const int want[6] = {1, 2, 4, 8, 12, 24};
-    if (ndil != 6) return false;
-    for (int i = 0; i < 6; ++i)
-        if (dil[i] != want[i]) return false;
-    return true;
-}
 // max_plane: the largest H * Wp of the launch; the LDS-DMA offsets inside one image are 32-bit (buffer descriptor per image)
 int excel_par_guide_supported(const void* guide, const void* stats, const void* in, const void* out, int Cmax, long long max_plane, int Wp,
                               const int* dil, int ndil) {
