@@ -45,6 +45,45 @@ __device__ __forceinline__ void ln_row(const float* __restrict__ src, const floa
     }
 }
 
+// The same row with D = 256 * NCH held in registers (one global read of the row instead of three passes through L1; same operations in
+// the same order -> same bits).  D = 768: NCH = 3.
+template <int NCH>
+__device__ __forceinline__ void ln_row_reg(const float* __restrict__ src, const float* __restrict__ w, const float* __restrict__ b,
+                                           float* __restrict__ dst, float eps, int lane, bool split) {
+    constexpr int D = 256 * NCH;
+    f32x4 v[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) v[i] = *reinterpret_cast<const f32x4*>(src + lane * 4 + 256 * i);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        v[i] -= mean;
+        q += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+    }
+    const float rstd = 1.f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane * 4 + 256 * i;
+        const f32x4 ww = *reinterpret_cast<const f32x4*>(w + c);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(b + c);
+        const f32x4 o4 = v[i] * rstd * ww + bb;
+        if (split) {
+            __bf16 hi[4], lo[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { hi[j] = (__bf16)o4[j]; lo[j] = (__bf16)(o4[j] - (float)hi[j]); }
+            __bf16* o = reinterpret_cast<__bf16*>(dst);
+            *reinterpret_cast<uint2*>(o + split_off(c, 0)) = *reinterpret_cast<const uint2*>(hi);
+            *reinterpret_cast<uint2*>(o + split_off(c, 1)) = *reinterpret_cast<const uint2*>(lo);
+        } else {
+            *reinterpret_cast<f32x4*>(dst + c) = o4;
+        }
+    }
+}
+
 // y[row] = LN(x[row]);  if cls_src != null, rows with (row % tokN == 0) read from cls_src instead
 // (the x[0] = x_ori[0] swap of clip_surgery_model.py:442, fused into ln_post).
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __restrict__ x, const float* __restrict__ cls_src,
@@ -55,7 +94,8 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __rest
     if (row >= rows) return;
     const float* src = x + (long long)row * in_stride;      // in_stride != D: gather every tokN-th row (cls tokens), compact output
     if (cls_src && (row % tokN) == 0) src = cls_src + (long long)row * in_stride;
-    ln_row(src, nullptr, w, b, y + (long long)row * D, D, eps, threadIdx.x & 63, split_out != 0);
+    if (D == 768) ln_row_reg<3>(src, w, b, y + (long long)row * D, eps, threadIdx.x & 63, split_out != 0);
+    else ln_row(src, nullptr, w, b, y + (long long)row * D, D, eps, threadIdx.x & 63, split_out != 0);
 }
 
 // x_pre[b,n,:] = (n == 0 ? class_embedding : patch[b,n-1,:]) + pos[n,:];  x = ln_pre(x_pre)
