@@ -473,9 +473,19 @@ __global__ __launch_bounds__(256, 2) void attn_rowpass_kernel(RowpassArgs p) {
     if (p.xcd_local) {
         // the q-blocks of one (image, head) share its K / V^T tiles: keep them on one XCD (consecutive logical ids) so the tiles are
         // fetched from the fabric once, not once per XCD (measured fabric traffic of this kernel: 2.6x its algorithmic bytes)
-        const int id = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
-        qb = id % gridDim.x;
-        bh = id / gridDim.x;
+        const int nq = gridDim.x, nbh = gridDim.y, lin = blockIdx.x + nq * blockIdx.y;
+        if ((nbh & 7) == 0 && nq > 1 && (p.N & 127) != 0) {
+            // ... and, inside an XCD's chunk, the full q-blocks first and the partial last q-block of every (image, head) at the end:
+            // 384 x 7 workgroups on 768 slots are 3.5 rounds; 384 x 6 full ones are exactly 3, and the tail round is then made of the
+            // short blocks (17 of 128 rows at N = 785: one active wave) instead of a half-empty round of full ones
+            const int x = lin & 7, loc = lin >> 3, per = nbh >> 3, nfull = per * (nq - 1);
+            if (loc < nfull) { bh = x * per + loc / (nq - 1); qb = loc % (nq - 1); }
+            else { bh = x * per + (loc - nfull); qb = nq - 1; }
+        } else {
+            const int id = xcd_remap(lin, nq * nbh);
+            qb = id % nq;
+            bh = id / nq;
+        }
     }
     const int b = bh / p.H, h = bh % p.H;
     const int type = blockIdx.z;
