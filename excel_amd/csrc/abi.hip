@@ -474,7 +474,7 @@ static int vit_forward_impl(excel_vit_t h, const float* img, int B, int S, void*
         // last block: its original-path output feeds only x[0] = x_ori[0] (:442) -> attention output, out-proj and MLP are
         // needed for the cls rows alone (the reference computes all rows; all_feats consumers still get them on request)
         const bool cls_only = surgery && l == L - 1 && !feats_out;
-        if (bf)   // V^T in split format: B operand of the bf16x3 P.V (all blocks) and of A_sum.V (surgery blocks)
+        if (bf && surgery)   // V^T in split format: B operand of A_sum.V (the row pass reads V through the LDS transpose read)
             TRY(excel_launch_vt_from_planes(qkvs, (unsigned short*)ws.vt, B, H, N, ws.KP, st));
         const bool in_aff = w_aff && l >= L - aff_layers;
         float* attn_l = (n_attn_out && l >= L - n_attn_out) ? attn_out + (size_t)(l - (L - n_attn_out)) * B * N * N : nullptr;

@@ -259,11 +259,15 @@ __device__ __forceinline__ void rowpass_body(const RowpassArgs& p, float* smem, 
 // vmcnt + raw s_barrier, exactly like gemm_bf16x3_kernel<4,3>: the register-staged version waited for each tile's global
 // loads inside the step that issued them.  LDS images are lane-linear, so both swizzles are applied to the SOURCE address:
 //   K tile   [32 keys][16 chunks of 16 B = hi 64 | lo 64]   chunk c at slot c ^ (key & 15)      (conflict-free b128)
-//   V^T tile [64 d   ][ 8 chunks of 16 B = hi 32 | lo 32]   chunk c at slot c ^ ((d >> 1) & 7)  (2-way on the b64 reads)
+//   V tile   8 sub-tiles (hi d 0-15, 16-31, 32-47, 48-63, then lo) of [32 keys][16 d] bf16, 1 KB each, 1152 B apart: the P.V operand
+//            (lane = d, 4 consecutive keys) is read with ds_read_b64_tr_b16 - the hardware transposes a [4 keys][16 d] block per 16
+//            lanes, each lane supplying the address of one 8-byte row segment - straight from the row-major q|k|v planes.  Rounds 1-3
+//            read it from a V^T copy that a separate transpose kernel wrote per block (0.39 ms per step, 2-way LDS conflicts).
 template <bool FLASH>
 __device__ __forceinline__ void rowpass_body_bf(const RowpassArgs& p, float* smem, int b, int h, int type, int qblk) {
     constexpr int KT_EL = 32 * 128;                      // u16 elements of a K tile (8 KB)
-    constexpr int VT_EL = 64 * 64;                       // u16 elements of a V^T tile (8 KB)
+    constexpr int VSUB = 1152;                           // bytes between V sub-tiles: 1 KB + 128 (the two sub-tiles a half-wave reads sit in complementary banks)
+    constexpr int VT_EL = 8 * VSUB / 2;                  // u16 elements of a V tile (9 KB)
     constexpr int STAGE_EL = KT_EL + (FLASH ? VT_EL : 0);
     constexpr int PER_WAVE = FLASH ? 4 : 2;              // 1-KB global_load_lds per wave per key tile
     const int tid = threadIdx.x, lane = tid & 63;
@@ -274,7 +278,7 @@ __device__ __forceinline__ void rowpass_body_bf(const RowpassArgs& p, float* sme
     const int ty = (type == 0) ? 1 : tx;
     const u16* Xsp = p.qkvs + (((long long)b * 3 + tx) * p.H + h) * (long long)N * 128;
     const u16* Ysp = p.qkvs + (((long long)b * 3 + ty) * p.H + h) * (long long)N * 128;
-    const u16* VT = FLASH ? p.vt + (((long long)b * p.H + h) * 64) * 2 * p.vt_kp : nullptr;
+    const u16* Vsp = p.qkvs + (((long long)b * 3 + 2) * p.H + h) * (long long)N * 128;
     u16* ring = reinterpret_cast<u16*>(smem);            // [3][K tile | V^T tile]
     const unsigned ring_b = __builtin_amdgcn_readfirstlane(lds_addr(ring));      // (provably wave-uniform: it goes into m0)
 
@@ -298,14 +302,15 @@ __device__ __forceinline__ void rowpass_body_bf(const RowpassArgs& p, float* sme
     const long long kplane_bytes = (long long)N * 256;
     const long long kavail = ((((long long)p.B * 3 - ((long long)b * 3 + ty)) * p.H - h) * kplane_bytes);      // bytes from this plane to the end of qkvs
     const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)Ysp, 0, (int)(kavail < (1LL << 31) - 1 ? kavail : (1LL << 31) - 1), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)(FLASH ? VT : Ysp), 0, FLASH ? (int)(64LL * 2 * p.vt_kp * 2) : 0, 0x00020000);
+    const long long vavail = ((((long long)p.B * 3 - ((long long)b * 3 + 2)) * p.H - h) * kplane_bytes);       // ... from the v plane to the end of qkvs
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)Vsp, 0, FLASH ? (int)(vavail < (1LL << 31) - 1 ? vavail : (1LL << 31) - 1) : 0, 0x00020000);
     int koffb[2], voffb[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int krow = wave * 8 + j * 4 + (lane >> 4);                 // row of the tile this lane loads a chunk of
         koffb[j] = krow * 256 + (((lane & 15) ^ (krow & 15)) * 16);
-        const int d = wave * 16 + j * 8 + (lane >> 3);
-        voffb[j] = FLASH ? d * 2 * p.vt_kp * 2 + (((lane & 7) ^ ((d >> 1) & 7)) * 16) : 0;
+        const int sub = wave * 2 + j;                                    // V sub-tile this lane loads 16 B of: key lane >> 1, d half lane & 1
+        voffb[j] = (lane >> 1) * 256 + (sub >> 2) * 128 + (((sub & 3) * 16 + (lane & 1) * 8) * 2);
     }
     // piece idx of this wave's PER_WAVE 1-KB loads of key tile kt: 0, 1 = K rows, 2, 3 = V^T rows (flash only)
     auto issue_piece = [&](int kt, int stage, int idx) {
@@ -315,7 +320,7 @@ __device__ __forceinline__ void rowpass_body_bf(const RowpassArgs& p, float* sme
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (lds_bptr)(unsigned long long)(dstk + (wave * 8 + idx * 4) * 256), 16, koffb[idx], kt * (32 * 256), 0, 0);
         } else if (FLASH) {
             const int j = idx - 2;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_bptr)(unsigned long long)(dstk + (KT_EL + (wave * 16 + j * 8) * 64) * 2), 16, voffb[j], kt * 128, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (lds_bptr)(unsigned long long)(dstk + KT_EL * 2 + (wave * 2 + j) * VSUB), 16, voffb[j], kt * (32 * 256), 0, 0);
         }
     };
     auto issue = [&](int kt, int stage) {
@@ -402,7 +407,7 @@ __device__ __forceinline__ void rowpass_body_bf(const RowpassArgs& p, float* sme
                 for (int e = 0; e < 16; ++e) { oT[0][e] *= alpha; oT[1][e] *= alpha; }
             }
             // P (this lane: keys (e&3)+8(e>>2)+4kh of query r) -> bf16 hi/lo; MFMA k-step ks takes e = 8ks..8ks+7, i.e. keys
-            // {16ks+4kh+0..3, 16ks+8+4kh+0..3}: the V^T operand reads exactly those two 8-byte groups of row d.
+            // {16ks+4kh+0..3, 16ks+8+4kh+0..3}: the V operand (lane = d) takes exactly those two groups of 4 consecutive keys.
             // hi = p truncated to bf16 (bit mask), lo = bf16(p - hi): p - hi is exact, so hi + lo keeps 16 mantissa bits.
             bf16x8 ph[2], pl[2];
 #pragma unroll
@@ -411,18 +416,18 @@ __device__ __forceinline__ void rowpass_body_bf(const RowpassArgs& p, float* sme
                 ph[e >> 3][e & 7] = (__bf16)hf;
                 pl[e >> 3][e & 7] = (__bf16)(s[e] - hf);
             }
-            const unsigned vt16 = ring_b + (stage * STAGE_EL + KT_EL) * 2;
+            // lane (d = 32 dt + r, kh): sub-tile 2 dt + (r >> 4), its column r & 15; the 16 lanes of a group address the 16 row segments
+            // (key = k0 + i / 4, d quarter i % 4) of the [4 keys][16 d] block whose column they receive
+            const unsigned vb = ring_b + (stage * STAGE_EL + KT_EL) * 2 + ((lane >> 4) & 1) * VSUB + (4 * kh + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-                const int d = dt * 32 + r, msk = (d >> 1) & 7;
-                const unsigned rowp = vt16 + (d * 64 + kh * 4) * 2;
                 bf16x4 vq[8];                                   // [ks][h0 h1 l0 l1]
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    vq[ks * 4 + 0] = lds_read8h(rowp + (((2 * ks) ^ msk) * 16));
-                    vq[ks * 4 + 1] = lds_read8h(rowp + (((2 * ks + 1) ^ msk) * 16));
-                    vq[ks * 4 + 2] = lds_read8h(rowp + (((4 + 2 * ks) ^ msk) * 16));
-                    vq[ks * 4 + 3] = lds_read8h(rowp + (((5 + 2 * ks) ^ msk) * 16));
+                    vq[ks * 4 + 0] = lds_read8h_tr(vb + dt * 2 * VSUB + ks * 512);
+                    vq[ks * 4 + 1] = lds_read8h_tr(vb + dt * 2 * VSUB + ks * 512 + 256);
+                    vq[ks * 4 + 2] = lds_read8h_tr(vb + (4 + dt * 2) * VSUB + ks * 512);
+                    vq[ks * 4 + 3] = lds_read8h_tr(vb + (4 + dt * 2) * VSUB + ks * 512 + 256);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vq[0]), "+v"(vq[1]), "+v"(vq[2]), "+v"(vq[3]), "+v"(vq[4]), "+v"(vq[5]), "+v"(vq[6]), "+v"(vq[7])::"memory");
 #pragma unroll
@@ -468,7 +473,7 @@ __device__ __forceinline__ void rowpass_body_bf(const RowpassArgs& p, float* sme
 }
 
 __global__ __launch_bounds__(256, 2) void attn_rowpass_kernel(RowpassArgs p) {
-    __shared__ __attribute__((aligned(1024))) float smem[3 * 4096];   // 48 KB: 3-stage ring of (K tile 8 KB + V^T tile 8 KB); >= the 33.8 KB of the fp32 path
+    __shared__ __attribute__((aligned(1024))) float smem[3 * (2048 + 2304)];   // 51 KB: 3-stage ring of (K tile 8 KB + V tile 9 KB); >= the 33.8 KB of the fp32 path
     int bh = blockIdx.y, qb = blockIdx.x;
     if (p.xcd_local) {
         // the q-blocks of one (image, head) share its K / V^T tiles: keep them on one XCD (consecutive logical ids) so the tiles are
@@ -490,7 +495,7 @@ __global__ __launch_bounds__(256, 2) void attn_rowpass_kernel(RowpassArgs p) {
     const int b = bh / p.H, h = bh % p.H;
     const int type = blockIdx.z;
     const bool flash = type == 0 && qb < p.flash_nq;
-    if (p.qkvs && p.vt) {
+    if (p.qkvs) {
         if (flash) rowpass_body_bf<true>(p, smem, b, h, 0, qb);
         else rowpass_body_bf<false>(p, smem, b, h, type, qb);
     } else {
