@@ -422,13 +422,15 @@ __device__ __forceinline__ void rowpass_body_bf(const RowpassArgs& p, float* sme
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
                 bf16x4 vq[8];                                   // [ks][h0 h1 l0 l1]
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    vq[ks * 4 + 0] = lds_read8h_tr(vb + dt * 2 * VSUB + ks * 512);
-                    vq[ks * 4 + 1] = lds_read8h_tr(vb + dt * 2 * VSUB + ks * 512 + 256);
-                    vq[ks * 4 + 2] = lds_read8h_tr(vb + (4 + dt * 2) * VSUB + ks * 512);
-                    vq[ks * 4 + 3] = lds_read8h_tr(vb + (4 + dt * 2) * VSUB + ks * 512 + 256);
-                }
+                const unsigned vbd = vb + dt * 2 * VSUB;        // (one address per d tile; everything else is the instruction's immediate)
+                vq[0] = lds_read8h_tr<0>(vbd);
+                vq[1] = lds_read8h_tr<256>(vbd);
+                vq[2] = lds_read8h_tr<4 * VSUB>(vbd);
+                vq[3] = lds_read8h_tr<4 * VSUB + 256>(vbd);
+                vq[4] = lds_read8h_tr<512>(vbd);
+                vq[5] = lds_read8h_tr<512 + 256>(vbd);
+                vq[6] = lds_read8h_tr<4 * VSUB + 512>(vbd);
+                vq[7] = lds_read8h_tr<4 * VSUB + 512 + 256>(vbd);
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vq[0]), "+v"(vq[1]), "+v"(vq[2]), "+v"(vq[3]), "+v"(vq[4]), "+v"(vq[5]), "+v"(vq[6]), "+v"(vq[7])::"memory");
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {

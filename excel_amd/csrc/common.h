@@ -170,9 +170,11 @@ __device__ __forceinline__ bf16x4 lds_read8h(unsigned addr) {
 }
 // hardware transpose read (gfx950): the 16 lanes of a group each address one 8-byte row segment of a [4 rows][16 columns] block of
 // 16-bit elements (segment i = row i / 4, columns 4 (i % 4) ..+3, any row stride); lane c of the group receives column c, rows 0..3
-__device__ __forceinline__ bf16x4 lds_read8h_tr(unsigned addr) {
+template <int OFF>
+__device__ __forceinline__ bf16x4 lds_read8h_tr(unsigned addr) {      // address + compile-time byte offset (the instruction's immediate)
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read_b64_tr_b16 immediate offset");
     f32x2 v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
     return __builtin_bit_cast(bf16x4, v);
 }
 __device__ __forceinline__ void lds_wait8(bf16x8 (&a)[4], bf16x8 (&b)[4]) {
