@@ -388,7 +388,11 @@ __device__ __forceinline__ void rowpass_body_bf(const RowpassArgs& p, float* sme
         float mx = s[0];
 #pragma unroll
         for (int e = 1; e < 16; ++e) mx = fmaxf(mx, s[e]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c2;
+        {
+            float mlo, mhi;
+            wave_halves(mx, mlo, mhi);
+            mx = fmaxf(mlo, mhi) * c2;
+        }
         const float m_new = fmaxf(m, mx);
         const bool grew = m_new > m;
         const float alpha = __builtin_amdgcn_exp2f(m - m_new);            // 1.0 exactly when the running max did not move
@@ -398,7 +402,11 @@ __device__ __forceinline__ void rowpass_body_bf(const RowpassArgs& p, float* sme
             s[e] = __builtin_amdgcn_exp2f(fmaf(s[e], c2, -m_new));
             ps += s[e];
         }
-        ps += __shfl_xor(ps, 32, 64);
+        {
+            float plo, phi;
+            wave_halves(ps, plo, phi);
+            ps = plo + phi;
+        }
         l = l * alpha + ps;
         m = m_new;
         if (FLASH) {

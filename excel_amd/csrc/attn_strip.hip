@@ -298,9 +298,11 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
             }
             // the two lane halves of a query row merge their (m, l); one entry per wave goes to the exchange
             {
-                const float m_o = __shfl_xor(m_run, 32, 64), l_o = __shfl_xor(l_run, 32, 64);
-                const float m_w = fmaxf(m_run, m_o);
-                l_run = l_run * __builtin_amdgcn_exp2f(m_run - m_w) + l_o * __builtin_amdgcn_exp2f(m_o - m_w);
+                float m_a, m_b, l_a, l_b;                     // (a: lanes 0..31, b: lanes 32..63 - in every lane, no LDS round trip)
+                wave_halves(m_run, m_a, m_b);
+                wave_halves(l_run, l_a, l_b);
+                const float m_w = fmaxf(m_a, m_b);
+                l_run = l_a * __builtin_amdgcn_exp2f(m_a - m_w) + l_b * __builtin_amdgcn_exp2f(m_b - m_w);
                 m_run = m_w;
             }
             const unsigned ls = lstat_addr + (t & 1) * (8 * 32 * 8);

@@ -45,19 +45,37 @@ static inline long long cdivl(long long a, long long b) { return (a + b - 1) / b
 #define EXCEL_DBG(x) 0
 #endif
 
+// The two halves of a wave exchange a register without an LDS round trip (v_permlane32_swap_b32, gfx950): lo = x of lane & 31, hi = x
+// of 32 + (lane & 31), in every lane - max(lo, hi) / lo + hi are the cross-half reductions (__shfl_xor(x, 32) is a ds_bpermute_b32).
+__device__ __forceinline__ void wave_halves(float x, float& lo, float& hi) {
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    lo = __uint_as_float(r[0]);
+    hi = __uint_as_float(r[1]);
+}
+// butterfly reductions; the first step (partner lane ^ 32) through the permlane swap: same pairing, same bits
 __device__ __forceinline__ float wave_sum(float v) {
+    float lo, hi;
+    wave_halves(v, lo, hi);
+    v = lo + hi;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
+    float lo, hi;
+    wave_halves(v, lo, hi);
+    v = fmaxf(lo, hi);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
 __device__ __forceinline__ float wave_min(float v) {
+    float lo, hi;
+    wave_halves(v, lo, hi);
+    v = fminf(lo, hi);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    for (int o = 16; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
     return v;
 }
 
