@@ -34,7 +34,7 @@ struct RowpassArgs {
     int out_split;       // 1: out is a split-bf16 tensor [B*N][2][H*64] (A operand of the bf16x3 out-proj GEMM)
     const unsigned short* qkvs;   // bf16x3 scores: q|k|v head-major in split format [B,3,H,N][2][64] (null = exact fp32 scores)
     int flash_nq;        // q-blocks >= flash_nq of type 0 only produce row stats (last block: only the cls row's output is consumed)
-    const unsigned short* vt;     // V^T in split format [B][H*64][2*vt_kp] (gemm_bf16x3.hip: vt_split_kernel): P.V as bf16x3 (null = fp32 P.V)
+    const unsigned short* vt;     // (rounds 1-2: V^T for the bf16x3 P.V; the bf16x3 row pass reads V from qkvs through the LDS transpose read)
     int vt_kp;
     int xcd_local;       // 1: workgroups of one (image, head) on one XCD
 };
@@ -919,7 +919,6 @@ int excel_launch_attn_rowpass(const float* qkvh, float* out, float* stats, int B
     ProfScope prof__(PROF_ATTN_ROWPASS, st);
     EXCEL_CHECK_ARG(hd == HD, "attention: head_dim must be 64 (got %d)", hd);
     EXCEL_CHECK_ARG(ntypes == 1 || ntypes == 4, "attention: ntypes must be 1 or 4");
-    EXCEL_CHECK_ARG(!qkvs || vt, "attention: the bf16x3 row pass needs V^T (vt) next to the split q|k|v");
     RowpassArgs a{qkvh, out, reinterpret_cast<float2*>(stats), B, H, N, scale, split_out, qkvs, flash_nq, vt, vt_kp, 1};
 #ifdef EXCEL_DEV
     { static const int x = getenv("EXCEL_ROWPASS_XCD") ? atoi(getenv("EXCEL_ROWPASS_XCD")) : 1; a.xcd_local = x; }

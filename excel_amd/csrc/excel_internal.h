@@ -46,7 +46,6 @@ struct GemmBfArgs {
 int excel_launch_gemm_bf16x3(const GemmBfArgs& p, hipStream_t stream);
 int excel_launch_split_bf16(const float* in, void* out, long long R, int K, hipStream_t st);
 int excel_launch_vt_from_planes(const unsigned short* qkvs, unsigned short* vt, int B, int H, int N, int KP, hipStream_t st);
-int excel_launch_vt_split(const float* v, unsigned short* vt, int B, int H, int N, int KP, long long v_batch_stride, hipStream_t st);
 
 int excel_launch_layernorm(const float* x, const float* cls_src, int tokN, const float* w, const float* b, float* y,
                            int rows, int D, float eps, hipStream_t st, int split_out = 0, long long in_stride = 0);

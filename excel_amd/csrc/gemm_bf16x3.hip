@@ -371,43 +371,9 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
     *reinterpret_cast<uint2*>(o + 32) = *reinterpret_cast<const uint2*>(lo);
 }
 
-// v [B][H][N][64] fp32 (head-major, image stride v_bstride) -> V^T in split format vt [B][H*64][2*KP] (row = one (head, d),
-// K axis = token m, zero-padded to KP): the K-major B operand of the bf16x3  A_sum . V  GEMM.  One workgroup per
-// (image, head, 64-token tile): coalesced 16-KB read, LDS transpose, 128-B contiguous hi|lo writes.
-__global__ __launch_bounds__(256) void vt_split_kernel(const float* __restrict__ v, u16* __restrict__ vt, int H, int N, int KP,
-                                                       long long v_bstride) {
-    __shared__ float t[64][65];
-    const int mt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const float* src = v + (long long)b * v_bstride + (long long)h * N * 64;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < 64 * 16; i += 256) {
-        const int m = i >> 4, c4 = i & 15;
-        const int gm = mt * 64 + m;
-        f32x4 x = {0.f, 0.f, 0.f, 0.f};
-        if (gm < N) x = *reinterpret_cast<const f32x4*>(src + (long long)gm * 64 + c4 * 4);
-        t[m][c4 * 4 + 0] = x[0]; t[m][c4 * 4 + 1] = x[1]; t[m][c4 * 4 + 2] = x[2]; t[m][c4 * 4 + 3] = x[3];
-    }
-    __syncthreads();
-    // thread -> (d, 4 consecutive m): 64 d x 16 groups
-    for (int i = tid; i < 64 * 16; i += 256) {
-        const int d = i >> 4, g4 = i & 15;
-        const int m0 = mt * 64 + g4 * 4;
-        if (m0 >= KP) continue;
-        __bf16 hi[4], lo[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float x = t[g4 * 4 + j][d];
-            hi[j] = (__bf16)x;
-            lo[j] = (__bf16)(x - (float)hi[j]);
-        }
-        __bf16* o = reinterpret_cast<__bf16*>(vt) + (((long long)b * H + h) * 64 + d) * 2 * KP + split_off(m0, 0);
-        *reinterpret_cast<uint2*>(o) = *reinterpret_cast<const uint2*>(hi);
-        *reinterpret_cast<uint2*>(o + 32) = *reinterpret_cast<const uint2*>(lo);
-    }
-}
-
-// Same V^T, cut from the split q|k|v the QKV epilogue already wrote (rows [hi 64 | lo 64] of v): the planes are produced by the
-// same rounding, so this is a pure 16-bit transpose -- bit-identical to vt_split_kernel on the fp32 v, which need not exist.
+// V^T in split format vt [B][H*64][2*KP] (row = one (head, d), K axis = token m, zero padded to KP): the K-major B operand of the bf16x3
+// A_sum . V GEMM, cut from the split q|k|v the QKV epilogue wrote (rows [hi 64 | lo 64] of v): a pure 16-bit transpose.  Since round 3 only the surgery blocks' A_sum.V GEMM needs it (the row pass reads V
+// row-major through the LDS transpose read).
 __global__ __launch_bounds__(256) void vt_from_planes_kernel(const u16* __restrict__ qkvs, u16* __restrict__ vt, int H, int N, int KP) {
     __shared__ u16 t[64][136];
     const int mt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
@@ -442,13 +408,6 @@ int excel_launch_vt_from_planes(const unsigned short* qkvs, unsigned short* vt, 
     return EXCEL_OK;
 }
 
-int excel_launch_vt_split(const float* v, unsigned short* vt, int B, int H, int N, int KP, long long v_batch_stride, hipStream_t st) {
-    ProfScope prof__(PROF_OTHER, st);
-    EXCEL_CHECK_ARG((KP % 32) == 0 && KP >= N, "vt_split: KP must be a multiple of 32 and >= N");
-    hipLaunchKernelGGL(vt_split_kernel, dim3(cdiv(KP, 64), H, B), dim3(256), 0, st, v, vt, H, N, KP, v_batch_stride);
-    EXCEL_CHECK_LAUNCH("vt_split");
-    return EXCEL_OK;
-}
 
 int excel_launch_gemm_bf16x3(const GemmBfArgs& p_in, hipStream_t stream) {
     GemmBfArgs p = p_in;
