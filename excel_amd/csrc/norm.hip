@@ -48,12 +48,15 @@ __device__ __forceinline__ void ln_row(const float* __restrict__ src, const floa
 // The same row with D = 256 * NCH held in registers (one global read of the row instead of three passes through L1; same operations in
 // the same order -> same bits).  D = 768: NCH = 3.
 template <int NCH>
-__device__ __forceinline__ void ln_row_reg(const float* __restrict__ src, const float* __restrict__ w, const float* __restrict__ b,
-                                           float* __restrict__ dst, float eps, int lane, bool split) {
+__device__ __forceinline__ void ln_row_reg(const float* __restrict__ src, const float* __restrict__ add, const float* __restrict__ w,
+                                           const float* __restrict__ b, float* __restrict__ dst, float eps, int lane, bool split) {
     constexpr int D = 256 * NCH;
     f32x4 v[NCH];
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) v[i] = *reinterpret_cast<const f32x4*>(src + lane * 4 + 256 * i);
+    for (int i = 0; i < NCH; ++i) {
+        v[i] = *reinterpret_cast<const f32x4*>(src + lane * 4 + 256 * i);
+        if (add) v[i] += *reinterpret_cast<const f32x4*>(add + lane * 4 + 256 * i);
+    }
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const float* __rest
     if (row >= rows) return;
     const float* src = x + (long long)row * in_stride;      // in_stride != D: gather every tokN-th row (cls tokens), compact output
     if (cls_src && (row % tokN) == 0) src = cls_src + (long long)row * in_stride;
-    if (D == 768) ln_row_reg<3>(src, w, b, y + (long long)row * D, eps, threadIdx.x & 63, split_out != 0);
+    if (D == 768) ln_row_reg<3>(src, nullptr, w, b, y + (long long)row * D, eps, threadIdx.x & 63, split_out != 0);
     else ln_row(src, nullptr, w, b, y + (long long)row * D, D, eps, threadIdx.x & 63, split_out != 0);
 }
 
@@ -107,7 +110,8 @@ __global__ __launch_bounds__(256) void assemble_ln_pre_kernel(const float* __res
     if (row >= B * tokN) return;
     const int bi = row / tokN, n = row % tokN;
     const float* src = (n == 0) ? cls_emb : patch + ((long long)bi * (tokN - 1) + (n - 1)) * D;
-    ln_row(src, pos + (long long)n * D, w, b, x + (long long)row * D, D, eps, threadIdx.x & 63);
+    if (D == 768) ln_row_reg<3>(src, pos + (long long)n * D, w, b, x + (long long)row * D, eps, threadIdx.x & 63, false);
+    else ln_row(src, pos + (long long)n * D, w, b, x + (long long)row * D, D, eps, threadIdx.x & 63);
 }
 
 // column sums of squares over the token axis: ss[b,c] = sum_n f[b,n,c]^2   (64 columns per block)
