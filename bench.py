@@ -126,7 +126,7 @@ def csrc_sha16():
     return h.hexdigest()[:16]
 
 
-def harness_ragged(model, device, n_images=256, batch=32, workers=8, seed=4321, passes=2):
+def harness_ragged(model, device, n_images=256, batch=32, workers=16, seed=4321, passes=2):
     """Side-line: the harness on the data the north star names - real VOC images have their OWN sizes (~375x500) and the path refines and
     scores at that size (tools/infer_lam.py:74,94).  The same pipeline over RAGGED batches of a VOC-like size distribution:
       resident       packed uint8 batches already in HBM (like the headline: decode and H2D excluded)

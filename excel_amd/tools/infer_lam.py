@@ -63,7 +63,7 @@ def get_parser():
     p.add_argument("--seed", default=1234, type=int)
     p.add_argument("--api_path", default=False, type=_bool, help="per-image reference call sequence instead of the batched pipeline")
     p.add_argument("--ragged", default=False, type=_bool, help="synthetic samples with VOC-like, per-image sizes (uint8 images), fed as ragged batches like real data")
-    p.add_argument("--num_workers", default=8, type=int, help="background decoders of the ragged path (the reference's DataLoader uses 2 worker processes, :167)")
+    p.add_argument("--num_workers", default=16, type=int, help="background decoders of the ragged path (the reference's DataLoader uses 2 worker processes, :167)")
     p.add_argument("--decode", default="threads", choices=["threads", "processes"],
                    help="threads: a decode thread pool in this process (Pillow releases the GIL; default); processes: forked DataLoader "
                         "workers like the reference - after such workers exit, host-side GPU event waits of this process were measured "
@@ -134,7 +134,7 @@ def build_validation(model=None, par=None, dataset=None, indices=None, device="c
         from ..utils import imutils
         pipe.hist = hist
         keep = bool(getattr(args, "crf_post", False))
-        nw = int(getattr(args, "num_workers", 8))
+        nw = int(getattr(args, "num_workers", 16))
         if getattr(args, "decode", "threads") == "processes" and nw > 0:    # the reference's mechanism (DataLoader worker processes, :167)
             batches = ragged_batches(dataset, indices, args.batch_size, num_workers=nw, pin_memory=False)
         else:                                                               # default: a thread pool (datasets/loader.threaded_batches)
