@@ -375,7 +375,10 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
 // A_sum . V GEMM, cut from the split q|k|v the QKV epilogue wrote (rows [hi 64 | lo 64] of v): a pure 16-bit transpose.  Since round 3 only the surgery blocks' A_sum.V GEMM needs it (the row pass reads V
 // row-major through the LDS transpose read).
 __global__ __launch_bounds__(256) void vt_from_planes_kernel(const u16* __restrict__ qkvs, u16* __restrict__ vt, int H, int N, int KP) {
-    __shared__ u16 t[64][136];
+    // 64 tokens x [hi 64 | lo 64] u16 as 64 dwords per row, pitch 65: the 4-byte writes of the load phase (row m, chunk c8: bank m + 4 c8 + k)
+    // and the 4-byte reads of the transpose phase (row 4 g4 + j, d pair: bank 4 g4 + j + dpair) are conflict-free (rounds 1-2 read single
+    // u16 down the rows of a 136-u16 pitch: LDS conflict rate 0.82)
+    __shared__ unsigned t32[64 * 65];
     const int mt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const u16* src = qkvs + ((((long long)b * 3 + 2) * H + h) * (long long)N) * 128;
     const int tid = threadIdx.x;
@@ -384,19 +387,22 @@ __global__ __launch_bounds__(256) void vt_from_planes_kernel(const u16* __restri
         const int gm = mt * 64 + m;
         uint4 x = {0u, 0u, 0u, 0u};
         if (gm < N) x = *reinterpret_cast<const uint4*>(src + (long long)gm * 128 + c8 * 8);
-        *reinterpret_cast<uint4*>(&t[m][c8 * 8]) = x;
+        unsigned* d = t32 + m * 65 + c8 * 4;
+        d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
     }
     __syncthreads();
-    for (int i = tid; i < 64 * 16; i += 256) {              // thread -> (d, 4 consecutive tokens)
-        const int d = i >> 4, g4 = i & 15;
+    for (int i = tid; i < 2 * 32 * 16; i += 256) {          // thread -> (hi | lo plane, pair of d, 4 consecutive tokens)
+        const int half = i >> 9, dpair = (i >> 4) & 31, g4 = i & 15;
         const int m0 = mt * 64 + g4 * 4;
         if (m0 >= KP) continue;
-        u16 hi[4], lo[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { hi[j] = t[g4 * 4 + j][d]; lo[j] = t[g4 * 4 + j][64 + d]; }
-        u16* o = vt + (((long long)b * H + h) * 64 + d) * 2 * KP + split_off(m0, 0);
-        *reinterpret_cast<uint2*>(o) = *reinterpret_cast<const uint2*>(hi);
-        *reinterpret_cast<uint2*>(o + 32) = *reinterpret_cast<const uint2*>(lo);
+        const unsigned* rp = t32 + (g4 * 4) * 65 + half * 32 + dpair;
+        const unsigned w0 = rp[0], w1 = rp[65], w2 = rp[130], w3 = rp[195];
+        uint2 even, odd;                                      // d = 2 dpair: the low halves of the four dwords; d + 1: the high halves
+        even.x = __builtin_amdgcn_perm(w1, w0, 0x05040100u); even.y = __builtin_amdgcn_perm(w3, w2, 0x05040100u);
+        odd.x = __builtin_amdgcn_perm(w1, w0, 0x07060302u);  odd.y = __builtin_amdgcn_perm(w3, w2, 0x07060302u);
+        u16* o = vt + (((long long)b * H + h) * 64 + 2 * dpair) * 2 * KP + split_off(m0, 0) + half * 32;
+        *reinterpret_cast<uint2*>(o) = even;
+        *reinterpret_cast<uint2*>(o + 2 * KP) = odd;
     }
 }
 
