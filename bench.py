@@ -52,10 +52,11 @@ def par_bytes_per_image(C, H=448, W=448):
     return 20 * (48 + 2 * C) * H * W * 4 + (3 + 48) * H * W * 4
 
 
-def cpu_baseline(max_images, seed, budget_s=25.0):
+def cpu_baseline(max_images, seed, budget_s=60.0):
     """The reference's algorithm (oracle/: numpy + torch-CPU restatement, batch 1 like tools/infer_lam.py:167, fp32, all host threads)
     timed on this box's cores over a bounded sample of the same synthetic workload: images 0, 1, ... of the benchmark's data set
-    until `budget_s` seconds of CPU work (at least 4, at most `max_images`).  Returns (json block, labels) - the labels double as
+    until `budget_s` seconds of CPU work (at least 4, at most `max_images`; BASELINE configs[0] is 64 images: ~0.7 s each on the GPU
+    box's host, so the default budget lets all 64 complete).  Returns (json block, labels) - the labels double as
     the checker of the GPU run (see `verify`)."""
     import torch
     import oracle
@@ -115,15 +116,10 @@ def cpu_baseline(max_images, seed, budget_s=25.0):
 
 
 def csrc_sha16():
-    """sha256 (first 16 hex digits) of the kernel sources: stamps profiles so the line can say whether `traffic` was measured on this code."""
-    import hashlib
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, "excel_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
-    return h.hexdigest()[:16]
+    """Id of the kernel sources in the tree (excel_amd/build.py:source_id): stamps profiles so the line can say whether `traffic` was
+    measured on this code, and is compared with the id compiled into the loaded library (`excel_build_id`)."""
+    from excel_amd import build as _build
+    return _build.source_id(dev=False)
 
 
 def harness_ragged(model, device, n_images=256, batch=32, workers=16, seed=4321, passes=2):
@@ -194,69 +190,107 @@ def harness_ragged(model, device, n_images=256, batch=32, workers=16, seed=4321,
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def main():
+def self_launch_argv(argv, n_gpus, port=None):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: the command line this process replaces itself with - the same
+    script and arguments, one rank per GPU under torch.distributed.run on this node (what the driver's own multi-GPU command looks like)."""
+    if port is None:
+        import socket
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_gpus)}",
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.abspath(__file__)] + list(argv)
+
+
+def make_workload(args, rank, world, device):
+    """The benchmark's model, pipeline and resident batches of this rank: rank r takes images r, r+R, ... (tools/infer_lam.py:166);
+    two distinct resident batches, alternated.  -> (pipe, batches, ks, model)"""
+    import torch
+    from excel_amd.model import ExCEL_model
+    from excel_amd.pipeline import TrainingFreePipeline
+    from excel_amd.tools import synthetic
+    from excel_amd.tools.infer_lam import shard_indices
+    B, S, NC = args.batch, 448, 21
+    model = ExCEL_model(clip_model="ExCEL_ViT-B/16", num_classes=NC, img_size=S, mode="train", device=device,
+                        state_dict=synthetic.make_vit_state_dict(seed=0), text_features=synthetic.make_text_features(45))
+    n_batches = 2
+    ds = synthetic.SyntheticSegDataset(world * B * n_batches, (S, S), num_classes=NC, seed=1234)
+    mine = shard_indices(len(ds), rank, world)
+    batches, ks = [], []
+    for i in range(n_batches):
+        _, imgs, gts, cls = ds.batch(mine[i * B:(i + 1) * B])
+        ks.append(cls.sum(1))
+        batches.append((torch.from_numpy(imgs).to(device), torch.from_numpy(cls).to(device), torch.from_numpy(gts).to(device)))
+    pipe = TrainingFreePipeline(model, num_classes=NC, smax=ds.max_k())
+    return pipe, batches, ks, model
+
+
+def main(argv=None, hooks=None):
+    """`hooks` (tests only): {"backend": "gloo", "device": "cpu", "make_workload": fn} runs this same control flow - shard, timed loop,
+    the ONE all-gather, max-over-ranks time, rank 0 prints - on CPU ranks with a stand-in pipeline (tests/test_host_cpu.py)."""
+    hooks = hooks or {}
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step (BASELINE configs[2]: 32)")
-    ap.add_argument("--cpu-images", type=int, default=64, help="upper bound of the CPU-baseline sample (stops after ~25 s of CPU work; 0 = skip)")
+    ap.add_argument("--cpu-images", type=int, default=64, help="upper bound of the CPU-baseline sample (stops after ~60 s of CPU work; 0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--ragged-images", type=int, default=256, help="images of the harness_ragged side-line (0 = skip)")
     ap.add_argument("--overlap", type=int, default=int(os.environ.get("EXCEL_BENCH_OVERLAP", "0")),
                     help="1: two-stream software pipeline (PAR of batch i overlaps the ViT of batch i+1)")
     ap.add_argument("--split", type=int, default=int(os.environ.get("EXCEL_BENCH_SPLIT", "1")),
                     help="run each batch as this many concurrent sub-batches on separate streams (1 = single stream)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     import torch
     import torch.distributed as dist
+    on_gpu = "device" not in hooks
+    if on_gpu:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the HIP library is the only compute path (no CPU fallback)")
+        if torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus} needs {args.gpus} GPUs, found {torch.cuda.device_count()}")
+        if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+            # launched bare: become the torch.distributed.run launcher of N ranks of this same command
+            cmd = self_launch_argv(sys.argv[1:] if argv is None else argv, args.gpus)
+            print("bench.py: self-launching", " ".join(cmd), file=sys.stderr, flush=True)
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            os.execv(cmd[0], cmd)
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP library is the only compute path (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
     if world != args.gpus:
-        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+    else:
+        device = torch.device(hooks["device"])
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")      # RCCL on ROCm
+        dist.init_process_group(backend=hooks.get("backend", "nccl"))      # "nccl" is RCCL on ROCm
         assert dist.get_world_size() == args.gpus
 
-    from excel_amd import ops
-    from excel_amd.model import ExCEL_model
-    from excel_amd.pipeline import TrainingFreePipeline
-    from excel_amd.tools import synthetic
-    from excel_amd.tools.infer_lam import gather_hists, shard_indices
+    from excel_amd.tools.infer_lam import gather_hists
     from excel_amd.utils import evaluate
-
     B, S, NC = args.batch, 448, 21
-    model = ExCEL_model(clip_model="ExCEL_ViT-B/16", num_classes=NC, img_size=S, mode="train", device=device,
-                        state_dict=synthetic.make_vit_state_dict(seed=0), text_features=synthetic.make_text_features(45))
-    # rank r takes images r, r+R, ... (tools/infer_lam.py:166); two distinct resident batches, alternated
     n_batches = 2
-    ds = synthetic.SyntheticSegDataset(world * B * n_batches, (S, S), num_classes=NC, seed=1234)
-    mine = shard_indices(len(ds), rank, world)
-    batches = []
-    ks = []
-    for i in range(n_batches):
-        _, imgs, gts, cls = ds.batch(mine[i * B:(i + 1) * B])
-        ks.append(cls.sum(1))
-        batches.append((torch.from_numpy(imgs).to(device), torch.from_numpy(cls).to(device), torch.from_numpy(gts).to(device)))
-    pipe = TrainingFreePipeline(model, num_classes=NC, smax=ds.max_k())
+    pipe, batches, ks, model = hooks.get("make_workload", make_workload)(args, rank, world, device)
+    if on_gpu:
+        from excel_amd import _lib, ops
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
     for i in range(args.warmup):
         pipe.run_batch(*batches[i % n_batches])
     pipe.reset()
-    timing = not args.no_kernel_timing
-    gmode = model.encoder.visual.handle().gemm_mode()
+    timing = on_gpu and not args.no_kernel_timing
+    gmode = model.encoder.visual.handle().gemm_mode() if on_gpu else "stub"
     dom_cat = "gemm_bf16x3" if gmode == "bf16x3" else "gemm_nt"
     if timing:
         # inside the timed region the two roofline kernels are bracketed with HIP events on their launch stream, every 4th
@@ -303,7 +337,7 @@ def main():
             "metric": "images/sec (CAM+PAR refine, 448x448)", "value": round(value, 3), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if model.encoder.visual.handle().gemm_mode() == "f32" else "bf16x3 (fp32 as bf16 hi+lo, fp32 accumulate)",
+            "dtype": "f32" if gmode == "f32" else "bf16x3 (fp32 as bf16 hi+lo, fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: VOC-shaped 448x448, batch=32/GPU, ViT-B/16 surgery + patch-text CAM "
                                    "(T=45,F=20) + affinity random walk + PAR(20 it, 6 dilations) + argmax + confusion, "
@@ -314,6 +348,9 @@ def main():
             "miou_synthetic": round(float(miou), 6),
             # self-check of the sharded run: the ranks the collective really spanned and every rank's scored-pixel count (a rank that
             # did not run, or ran another shard twice, shows here)
+            # the library that ran: the id of the sources it was compiled from (excel_build_id) next to the id of the sources in the tree
+            "lib_build_id": _lib.build_id() if on_gpu else None, "csrc_sha16": csrc_sha16(),
+            "lib_built_from_these_sources": on_gpu and _lib.build_id().replace("-dev", "") == csrc_sha16(),
             "rccl_ranks": int(dist.get_world_size()) if world > 1 else 1,
             "per_rank_hist_mass": [int(x) for x in per_rank.reshape(per_rank.shape[0], -1).sum(1).tolist()],
         }
@@ -403,7 +440,7 @@ def main():
                     "note": "bound: 97 % of these flops are the projection GEMM (198 tiles on 256 CUs: 77 % of one round); the similarity part is HBM / "
                             "latency-bound (arithmetic intensity ~45 flop/B, SURVEY 8d; x_raw is read twice: norm pass + similarity pass); ln_post is timed under 'layernorm'"}
             out["kernel_ms_per_step"] = {k: round(v, 4) for k, v in sorted(ms.items(), key=lambda kv: -kv[1])}
-        if world == 1 and args.cpu_images > 0:
+        if on_gpu and world == 1 and args.cpu_images > 0:
             ncpu = min(args.cpu_images, n_batches * B)
             out["cpu_baseline"], cpu_labels = cpu_baseline(ncpu, seed=1234)
             # the labels of the timed kernels (same resident batches, one more untimed pass) against the CPU port's labels of the same
@@ -419,7 +456,7 @@ def main():
             out["verify"] = {"images": len(agree), "pixels": px, "label_agreement_mean": round(float(np.mean(agree)), 6),
                              "label_agreement_min": round(float(np.min(agree)), 6),
                              "checker": "oracle (CPU port) labels of the same images; bf16x3 vs exact fp32 differ only where a CAM lies on a uint8 / box threshold"}
-        if world == 1 and args.ragged_images > 0:
+        if on_gpu and world == 1 and args.ragged_images > 0:
             out["harness_ragged"] = harness_ragged(model, device, n_images=args.ragged_images, batch=B)
         print(json.dumps(out), flush=True)
         v = out.get("verify")

@@ -68,6 +68,7 @@ class RaggedInfo(C.Structure):
 SIGNATURES = {
     "excel_last_error": (C.c_char_p, []),
     "excel_abi_version": (c_i, []),
+    "excel_build_id": (C.c_char_p, []),
     "excel_gemm_f32": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
                              c_ll, c_ll, c_ll, c_ll, c_f]),
     "excel_split_bf16": (c_i, [c_f, c_f, c_ll, c_i, c_f]),
@@ -166,6 +167,11 @@ def lib():
         fn.argtypes = args
     _lib = handle
     return _lib
+
+
+def build_id():
+    """Source id compiled into the loaded library (include/excel_hip.h: excel_build_id)."""
+    return lib().excel_build_id().decode()
 
 
 def check(rc, what):

@@ -22,6 +22,24 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
+def source_id(dev=None):
+    """sha256 (first 16 hex digits) of every kernel source and header the library is compiled from (file names + bytes, sorted;
+    `-dev` appended for an EXCEL_DEV build).  build() embeds it in the library (`excel_build_id()`), bench.py prints both: a stale
+    `.so` whose time stamps happen to look fresh cannot be benchmarked unnoticed."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    for f in files:
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    pub = os.path.join(CSRC, "..", "..", "include", "excel_hip.h")
+    h.update(b"include/excel_hip.h")
+    h.update(open(pub, "rb").read())
+    if dev is None:
+        dev = os.environ.get("EXCEL_DEV") == "1"
+    return h.hexdigest()[:16] + ("-dev" if dev else "")
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -33,7 +51,9 @@ def build(force=False, verbose=True):
     """EXCEL_DEV=1 in the environment adds -DEXCEL_DEV: ablation / experiment switches read from environment variables are compiled
     in (development only; the shipped library has none)."""
     hipcc = _hipcc()
+    force = force or os.environ.get("EXCEL_BUILD_FORCE") == "1"      # the driver-side "does it build from source" check
     flags = FLAGS + (["-DEXCEL_DEV"] if os.environ.get("EXCEL_DEV") == "1" else [])
+    sid = source_id()
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     # objects built with other flags (a dev build, another compiler) are stale whatever their time stamps say
     stamp = os.path.join(CSRC, ".build_flags")
@@ -45,8 +65,15 @@ def build(force=False, verbose=True):
         src = os.path.join(CSRC, s)
         obj = os.path.join(CSRC, s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _stale(obj, [src] + hdrs):
-            jobs.append([hipcc] + flags + ["-c", src, "-o", obj])
+        extra = []
+        stale = force or _stale(obj, [src] + hdrs)
+        if s == "abi.hip":
+            # abi.hip carries the id of ALL sources (excel_build_id): it is rebuilt whenever any of them changed
+            extra = ['-DEXCEL_BUILD_ID="%s"' % sid]
+            idstamp = os.path.join(CSRC, ".build_id")
+            stale = stale or not os.path.exists(idstamp) or open(idstamp).read() != sid
+        if stale:
+            jobs.append([hipcc] + flags + extra + ["-c", src, "-o", obj])
     if jobs:
         with cf.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             for cmd, res in zip(jobs, ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs)):
@@ -63,6 +90,8 @@ def build(force=False, verbose=True):
             print("[excel_amd.build] linked", LIB)
     with open(stamp, "w") as f:
         f.write(sig)
+    with open(os.path.join(CSRC, ".build_id"), "w") as f:
+        f.write(sid)
     return LIB
 
 

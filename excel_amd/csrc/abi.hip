@@ -17,7 +17,11 @@ void excel_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* excel_last_error(void) { return g_err; }
-extern "C" int excel_abi_version(void) { return 2; }
+extern "C" int excel_abi_version(void) { return 3; }
+#ifndef EXCEL_BUILD_ID
+#define EXCEL_BUILD_ID "unstamped"
+#endif
+extern "C" const char* excel_build_id(void) { return EXCEL_BUILD_ID; }
 
 // ------------------------------------------------------------------------------------ profiling hooks
 bool g_excel_prof_on = false;
@@ -799,8 +803,10 @@ extern "C" int excel_par_forward_ragged(const float* imgs, int h, int w, const f
     float* guide = (float*)((char*)pp + align_up((size_t)Cmax * tp * sizeof(float), 256));
     hipStream_t st = ST(stream);
     const TileGeo geo = ragged_geo(table, info->B);
-    EXCEL_CHECK_ARG(excel_par_guide_supported(guide, stats, masks, out, Cmax, info->max_plane_pix, 8, dilations, ndil) && (((uintptr_t)pp & 15) == 0),
-                    "par_forward_ragged: needs dilations [1,2,4,8,12,24], 16-byte aligned buffers and Cmax * H * W * 4 < 2^31 per image");
+    // (every pitch of the ragged layout is a multiple of 4 floats by construction - excel_ragged_plan - so 4 stands for all of them)
+    EXCEL_CHECK_ARG(excel_par_guide_supported(guide, stats, masks, out, Cmax, info->max_plane_pix, 4, dilations, ndil) && (((uintptr_t)pp & 15) == 0),
+                    "par_forward_ragged: needs dilations [1,2,4,8,12,24], 16-byte aligned buffers and max(Cmax,5) * H * Wp * 4 < 2^31 per image "
+                    "(Wp = W rounded up to 4)");
     // the guide always goes through the align_corners=True resize (PAR.py:67): it is the identity where (H_b, W_b) == (h, w), and it
     // brings the uniform [B,3,h,w] network input into the pitched per-image layout
     TRY(excel_launch_bilinear_ac_ragged(imgs, guide, h, w, geo, info->total_tiles, st));

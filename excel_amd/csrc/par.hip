@@ -708,7 +708,9 @@ int excel_launch_par_iterate(const float* aff, const float* in, float* out, cons
 // max_plane: the largest H * Wp of the launch; the LDS-DMA offsets inside one image are 32-bit (buffer descriptor per image)
 int excel_par_guide_supported(const void* guide, const void* stats, const void* in, const void* out, int Cmax, long long max_plane, int Wp,
                               const int* dil, int ndil) {
-    const bool vec = (Wp % 4) == 0 && Wp >= 8 && ((((uintptr_t)guide | (uintptr_t)stats | (uintptr_t)in | (uintptr_t)out) & 15) == 0);
+    // (any pitch that is a multiple of 4 floats works, down to Wp = 4: border tiles clamp their source columns per lane -
+    // tests/test_gpu_ops.py::test_ragged_tiny_images, test_par_uniform_narrow_images)
+    const bool vec = (Wp % 4) == 0 && Wp >= 4 && ((((uintptr_t)guide | (uintptr_t)stats | (uintptr_t)in | (uintptr_t)out) & 15) == 0);
     const long long planes = Cmax > 5 ? Cmax : 5;
     return (vec && par_dil_ok(dil, ndil) && planes * max_plane * 4 < (1LL << 31)) ? 1 : 0;
 }

@@ -12,6 +12,7 @@ torch.utils.data is used as process / shared-memory plumbing only.
 """
 import numpy as np
 import torch
+from threading import current_thread as threading_current
 from torch.utils.data import DataLoader, Dataset
 
 
@@ -124,8 +125,40 @@ class DeviceFeeder:
             self._free.put(i)
         self._copy_stream = torch.cuda.Stream(device=self.device)
         self._error = None
+        self._stop = threading.Event()
+        self._last_done = None          # event after the last kernels that read a ring buffer (see close)
         self._thread = threading.Thread(target=self._run, daemon=True)
         self._thread.start()
+
+    def close(self):
+        """Stop the staging thread and make the ring safe to free: waits (on the host) for the kernels of the batch handed out last,
+        so the buffers - allocated on the copy stream, read on the consumer's - do not return to the caching allocator while a kernel
+        still reads them; drains the queues so a staging thread blocked on a full / empty queue exits.  Called when iteration ends
+        (normally, by `break`, or by an exception in the consumer) and from __del__."""
+        import queue
+        self._stop.set()
+        try:
+            while True:                  # unblock a producer waiting on `_ready.put`
+                self._ready.get_nowait()
+        except queue.Empty:
+            pass
+        self._free.put(-1)               # unblock a producer waiting on `_free.get`
+        if self._last_done is not None:
+            self._last_done.synchronize()
+            self._last_done = None
+        if self._thread.is_alive() and self._thread is not threading_current():
+            self._thread.join(timeout=5.0)
+        try:
+            while True:
+                self._ready.get_nowait()
+        except queue.Empty:
+            pass
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     @staticmethod
     def _grow(store, name, numel, dtype, make):
@@ -148,6 +181,8 @@ class DeviceFeeder:
             torch.cuda.set_device(self.device)
             for rb in self._batches:
                 i = self._free.get()
+                if self._stop.is_set() or i < 0:
+                    break
                 slot = self._slots[i]                          # (the consumer frees a slot only after its kernels finished)
                 plan = self._ops.RaggedPlan(rb.hw, None)
                 with torch.cuda.stream(self._copy_stream):
@@ -161,29 +196,41 @@ class DeviceFeeder:
         except BaseException as e:      # surfaced in the consumer
             self._error = e
         finally:
-            self._ready.put(None)
+            if not self._stop.is_set():
+                self._ready.put(None)
 
     def __iter__(self):
         from collections import deque
         inflight = deque()              # (slot, event after the last kernel that reads it), oldest first
         cur_slot = None
-        while True:
-            cur = torch.cuda.current_stream(self.device)
-            if cur_slot is not None:    # everything enqueued for the batch handed out last is in `cur`
+        cur = torch.cuda.current_stream(self.device)
+        try:
+            while True:
+                cur = torch.cuda.current_stream(self.device)
+                if cur_slot is not None:    # everything enqueued for the batch handed out last is in `cur`
+                    done = torch.cuda.Event()
+                    done.record(cur)
+                    inflight.append((cur_slot, done))
+                    self._last_done = done
+                    cur_slot = None
+                while inflight and (len(inflight) > self._nslots - 2 or inflight[0][1].query()):
+                    i, done = inflight.popleft()
+                    done.synchronize()
+                    self._free.put(i)
+                item = self._ready.get()
+                if item is None:
+                    if self._error is not None:
+                        raise self._error
+                    return
+                i, ev, names, plan, images, cls, labels = item
+                cur.wait_event(ev)
+                cur_slot = i
+                yield names, plan, images, cls, labels
+        finally:
+            # the consumer is done with the iterator (exhausted, `break`, exception): whatever it enqueued for the last batch is in
+            # `cur` - record it, then close() waits for it before the ring can be freed
+            if cur_slot is not None:
                 done = torch.cuda.Event()
                 done.record(cur)
-                inflight.append((cur_slot, done))
-                cur_slot = None
-            while inflight and (len(inflight) > self._nslots - 2 or inflight[0][1].query()):
-                i, done = inflight.popleft()
-                done.synchronize()
-                self._free.put(i)
-            item = self._ready.get()
-            if item is None:
-                if self._error is not None:
-                    raise self._error
-                return
-            i, ev, names, plan, images, cls, labels = item
-            cur.wait_event(ev)
-            cur_slot = i
-            yield names, plan, images, cls, labels
+                self._last_done = done
+            self.close()

@@ -29,7 +29,11 @@ class TrainingFreePipeline:
 
     def _buf(self, name, numel, dtype=torch.float32, device=None):
         """Step-persistent scratch (cams, PAR output, PAR workspace): one grow-only flat buffer per (name, launch stream), so a step
-        allocates nothing and launches no fill kernels.  Only buffers nobody outside the step keeps are taken from here."""
+        allocates nothing and launches no fill kernels.  Only buffers nobody outside the step keeps are taken from here.
+        The buffers are NOT initialised and the producers skip what nobody reads: pad columns (W_b <= x < Wp_b) and the planes of
+        unused channels (c >= nchan[b]) of the step's cams / PAR output hold garbage.  The step's own consumers clamp to W_b - 1 and
+        nchan[b]; a new consumer (saving cams, a CRF stage) must do the same or ask for `return_intermediates=True`, which switches to
+        fresh zero-filled tensors."""
         key = (name, torch.cuda.current_stream().cuda_stream)
         b = self._bufs.get(key)
         if b is None or b.numel() < numel or b.dtype != dtype:
@@ -76,7 +80,9 @@ class TrainingFreePipeline:
     def run_batch_ragged(self, hwc_packed, plan, cls_labels, gts_packed=None, S=448, return_intermediates=False):
         """hwc_packed: the decoded uint8 [H_b,W_b,3] images back to back (device); plan = ops.RaggedPlan of their sizes;
         cls_labels [B,F] f32 one-hot; gts_packed: the uint8 [H_b,W_b] ground-truth maps back to back (255 = ignore) or None.
-        Returns the labels as one flat uint8 tensor (image b = plan.label(labels, b))."""
+        Returns the labels as one flat uint8 tensor (image b = plan.label(labels, b)).
+        Without `return_intermediates` the cams / PAR output live in uninitialised step buffers (see _buf: pad columns and unused
+        channels are undefined); with it they are fresh tensors whose unused parts are zero."""
         dev = hwc_packed.device
         B = plan.B
         g = S // 16

@@ -71,6 +71,8 @@ def get_parser():
     p.add_argument("--clip_root", default=None, type=str, help="directory holding the published CLIP archive (ViT-B-16.pt); default $EXCEL_CLIP_ROOT, ~/.cache/clip")
     p.add_argument("--bpe_path", default=None, type=str, help="CLIP's bpe_simple_vocab_16e6.txt.gz (default $EXCEL_BPE_VOCAB)")
     p.add_argument("--gemm_mode", default=None, type=str, help="bf16x3 (default) | f32")
+    p.add_argument("--cpu_affinity", default="auto", choices=["auto", "off"],
+                   help="auto: with several ranks on the node every rank pins itself (decode pool included) to its own share of the host cores")
     p.add_argument("--json_out", default=None, type=str, help="rank 0 writes a one-line JSON record of the run here (rate, ranks, per-rank mass)")
     return p
 
@@ -79,6 +81,21 @@ def get_parser():
 def shard_indices(n, rank, world):
     """Subset(np.arange(i, len, n_gpus)) (tools/infer_lam.py:166)."""
     return np.arange(rank, n, world)
+
+
+def pin_rank_to_cores(local_rank, local_world):
+    """Give local rank r of R its own contiguous share of the CPUs this process may run on (os.sched_setaffinity): the decode pool and
+    the launch thread of a rank then stay off the other ranks' cores (8 ranks x 16 decode threads + 8 launch threads on one host,
+    BASELINE configs[3]).  -> the core set, or None when there are fewer cores than ranks / the platform has no affinity call."""
+    if not hasattr(os, "sched_setaffinity") or local_world <= 1:
+        return None
+    cores = sorted(os.sched_getaffinity(0))
+    if len(cores) < local_world:
+        return None
+    per = len(cores) // local_world
+    mine = set(cores[local_rank * per:(local_rank + 1) * per])
+    os.sched_setaffinity(0, mine)
+    return mine
 
 
 def gather_hists(hist, group=None):
@@ -112,6 +129,18 @@ def format_scores_table(score, cat_list, metric_names=("confusion", "precision",
 
 
 # ------------------------------------------------------------------ the loop
+def _check_present_classes(batches, smax):
+    """The compacted class list of an image has `smax` slots (the kernels clamp to it): an image with MORE present classes than the data
+    set's max_k() promised would silently lose the extra ones - refuse it instead, on the host, from the batch's own one-hot rows."""
+    for rb in batches:
+        k = rb.cls.sum(1)
+        if int(k.max()) > smax:
+            b = int(k.argmax())
+            raise RuntimeError(f"{rb.names[b]}: {int(k[b])} present classes, the pipeline was built for at most {smax} (dataset.max_k()): "
+                               "build TrainingFreePipeline with a larger smax")
+        yield rb
+
+
 def build_validation(model=None, par=None, dataset=None, indices=None, device="cuda", args=None, pipe=None):
     """-> (hist [nc,nc] int64 on device, images processed, seconds).  Mirrors :63-128."""
     from ..pipeline import TrainingFreePipeline
@@ -140,6 +169,7 @@ def build_validation(model=None, par=None, dataset=None, indices=None, device="c
         else:                                                               # default: a thread pool (datasets/loader.threaded_batches)
             from ..datasets.loader import threaded_batches
             batches = threaded_batches(dataset, indices, args.batch_size, num_threads=max(nw, 1))
+        batches = _check_present_classes(batches, pipe.smax)
         if on_gpu:
             from ..datasets.loader import DeviceFeeder
             feed = DeviceFeeder(batches, device)              # H2D on a copy stream, a few batches ahead
@@ -151,8 +181,9 @@ def build_validation(model=None, par=None, dataset=None, indices=None, device="c
                 inter = out[1]
                 cls_idx, ncls = inter["cls_idx"].cpu().numpy(), inter["ncls"].cpu().numpy()
                 for b, name in enumerate(names):
-                    k = int(ncls[b])
-                    imutils.save_logits(args.logits_dir, name, plan.planes(inter["cams"], b, pipe.smax + 1)[:k + 1], cls_idx[b, :k].astype(np.int64))
+                    k = min(int(ncls[b]), pipe.smax)            # (ncls <= smax is enforced below; the record stays consistent anyway)
+                    imutils.save_logits(args.logits_dir, name, plan.planes(inter["cams"], b, pipe.smax + 1)[:k + 1], cls_idx[b, :k].astype(np.int64),
+                                        run_token=getattr(args, "run_token", None))
             nimg += len(names)
         if on_gpu:
             torch.cuda.synchronize()
@@ -184,7 +215,7 @@ def build_validation(model=None, par=None, dataset=None, indices=None, device="c
                 labels, normed = refine_cams_with_bkg_weclip(refined, inputs[i], cls_lst, par, gts.shape[-2:])   # :94
                 if getattr(args, "crf_post", False):                                         # :116-119 record for the CRF stage
                     from ..utils import imutils
-                    imutils.save_logits(args.logits_dir, str(names[i]), normed, cls_lst)
+                    imutils.save_logits(args.logits_dir, str(names[i]), normed, cls_lst, run_token=getattr(args, "run_token", None))
                 hist = evaluate.hist_from_labels([gt_dev[i]], [labels[0]], args.num_classes, device, hist)
         else:
             pipe.hist = hist
@@ -262,7 +293,10 @@ def crf_proc(args, rank=0, world=1, device="cuda"):
     for i in shard_indices(len(name_list), rank, world):
         name = name_list[i]
         rec = os.path.join(args.logits_dir, name + ".npy")
-        if not os.path.isfile(rec) or os.path.getmtime(rec) < getattr(args, "run_started", 0.0) - 1.0:
+        # records carry the token of the run that wrote them (validate() draws one and shares it with every rank): no dependence on
+        # file-system time stamps or clocks.  A caller that runs build_validation + crf_proc without a token accepts any record.
+        token = getattr(args, "run_token", None)
+        if not os.path.isfile(rec) or (token is not None and imutils.logits_run_token(rec) != token):
             raise RuntimeError(f"crf_proc: {rec} was not written by this run (missing or stale): the CRF stage scores the records of the "
                                "main loop (tools/infer_lam.py:116-119), never those of an earlier one")
         lams, keys = imutils.load_logits(rec)                                               # :203-206
@@ -298,7 +332,17 @@ def validate(args=None, dataset=None, pipe=None):
         device = torch.device(pipe.device)
     if world > 1 and not dist.is_initialized():
         dist.init_process_group(backend=args.backend)                                       # :133
-    args.run_started = time.time()
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    if pipe is None and getattr(args, "cpu_affinity", "auto") == "auto" and local_world > 1:
+        cores = pin_rank_to_cores(int(os.environ.get("LOCAL_RANK", args.local_rank)), local_world)
+        if cores and rank == 0:
+            logging.info(f"rank 0 pinned to {len(cores)} of the host's cores (every rank takes its own share; --cpu_affinity off disables)")
+    # one token per evaluation, the same on every rank (rank 0 draws it): stamps the CRF records this run writes
+    import uuid
+    tok = [uuid.uuid4().hex]
+    if world > 1:
+        dist.broadcast_object_list(tok, src=0)
+    args.run_token = tok[0]
     if dataset is not None:
         args.ragged_batches = True
     elif getattr(args, "data_folder", None):

@@ -44,14 +44,24 @@ def denormalize_img2(imgs=None):
     return ops.denormalize_img(imgs, as_float=True)
 
 
-def save_logits(logits_dir, name, valid_lam, keys_gt):
-    """tools/infer_lam.py:116-119."""
+def save_logits(logits_dir, name, valid_lam, keys_gt, run_token=None):
+    """tools/infer_lam.py:116-119.  `run_token` (optional, an extra key next to the reference's two: its reader looks keys up by name)
+    marks the run that wrote the record, so the CRF stage can refuse records of an earlier run whatever the file system's time
+    stamps say."""
     os.makedirs(logits_dir, exist_ok=True)
     valid_lam = valid_lam.detach().cpu().numpy() if hasattr(valid_lam, "detach") else np.asarray(valid_lam)
     keys_gt = keys_gt.detach().cpu().numpy() if hasattr(keys_gt, "detach") else np.asarray(keys_gt)
     path = os.path.join(logits_dir, name + ".npy")
-    np.save(path, {"valid_lam": valid_lam, "keys_gt": keys_gt})
+    rec = {"valid_lam": valid_lam, "keys_gt": keys_gt}
+    if run_token is not None:
+        rec["run_token"] = str(run_token)
+    np.save(path, rec)
     return path
+
+
+def logits_run_token(path):
+    """The run token of a record written by save_logits (None: written without one, e.g. by the reference)."""
+    return np.load(path, allow_pickle=True).item().get("run_token")
 
 
 def load_logits(path):

@@ -26,6 +26,10 @@ extern "C" {
 
 const char* excel_last_error(void);
 int excel_abi_version(void);
+/* (host) id of the sources this library was compiled from: first 16 hex digits of the sha256 over csrc/*.hip, csrc/*.h and this header
+ * (excel_amd/build.py:source_id; "-dev" appended for an EXCEL_DEV build, "unstamped" when compiled outside build.py).  The harness
+ * compares it with the sources next to it so that a stale library is never measured. */
+const char* excel_build_id(void);
 
 /* ------------------------------------------------------------------ building blocks (exported for tests / reuse) */
 
@@ -353,7 +357,14 @@ int excel_cam_upsample_bkg_ragged(const float* refined, const int32_t* ncls, con
                                   int Smax, float* cams, void* workspace, int flags, void* stream);
 
 /* PAR.forward for a ragged batch: imgs [B,3,h,w] (the uniform network input; resized per image with align_corners=True like
- * PAR.py:67), masks / out = Cmax pitched planes per image.  Dilations must be [1,2,4,8,12,24] (the recomputing kernel). */
+ * PAR.py:67), masks / out = Cmax pitched planes per image.
+ * Narrower contract than excel_par_forward (only the recomputing tile kernel exists for ragged batches; there is no streamed-affinity
+ * fallback): returns EXCEL_ERR_ARG (-1) unless
+ *   - n_iter >= 1            (excel_par_forward copies masks to out for n_iter == 0; here that is an error),
+ *   - dilations == [1,2,4,8,12,24] (what the reference always uses, PAR.py callers),
+ *   - every buffer is 16-byte aligned and max(Cmax,5) * H_b * Wp_b * 4 < 2^31 for every image (Wp_b = W_b rounded up to 4).
+ * The pad columns (W_b <= x < Wp_b) of `out` and its planes c >= nchan[b] are UNDEFINED on return (masks' pad columns are never read
+ * as neighbours); consumers clamp to W_b - 1 and nchan[b] (excel_argmax_label_ragged does). */
 size_t excel_par_ragged_workspace_bytes(long long total_pix, int Cmax);
 int excel_par_forward_ragged(const float* imgs, int h, int w, const float* masks, const int32_t* nchan, const int32_t* table,
                              const excel_ragged_info* info, int Cmax, const int32_t* dilations /*host*/, int ndil, int n_iter, float w1,

@@ -36,8 +36,14 @@ class VitConfig:
         return self.width // self.heads
 
 
-def make_vit_weights(cfg: VitConfig, seed: int = 0, attn_gain: float = 4.0):
+def make_vit_weights(cfg: VitConfig, seed: int = 0, attn_gain: float = 4.0, outliers: bool = False):
     """Seeded synthetic weights with the reference module's shapes.
+
+    `outliers=True` turns the benign random net into a CLIP-LIKE STRESS NET (applied on top of the same seeded weights, from a second
+    random stream, so `outliers=False` stays bit-identical): a handful of "massive activation" channels (their residual-stream values
+    are ~50-100x the rest, written by a few MLP output rows and the class / positional embeddings, as trained CLIP ViTs have),
+    heavy-tailed (log-normal) LayerNorm gains, and q/k/v gains high enough that many attention rows are close to one-hot.  Real CLIP
+    ViT-B/16 weights are not available offline; this is the closest the parity tests can get to their numerical regime.
 
     RandomState (legacy, stream-stable across numpy versions) so the GPU box
     regenerates bit-identical weights.  q/k/v projections get a gain so that
@@ -73,6 +79,29 @@ def make_vit_weights(cfg: VitConfig, seed: int = 0, attn_gain: float = 4.0):
         w[p + "mlp.c_proj.weight"] = rn(D, 4 * D, std=0.5 * (4 * D) ** -0.5)
         w[p + "mlp.c_proj.bias"] = rn(D, std=0.02)
     w["proj"] = rn(D, cfg.out_dim, std=D ** -0.5)
+    if outliers:
+        ro = np.random.RandomState(seed + 7919)
+        n_out = 3 + int(ro.randint(0, 4))                                  # 3..6 massive channels
+        chans = ro.choice(D, n_out, replace=False)
+        gains = ro.uniform(50.0, 100.0, n_out).astype(f32)
+        # the embeddings put a large constant into those channels for every token, and a few blocks' MLP output rows keep feeding them
+        w["class_embedding"][chans] += gains * (ro.choice([-1.0, 1.0], n_out)).astype(f32) * f32(0.5)
+        w["positional_embedding"][:, chans] += (gains * ro.choice([-1.0, 1.0], n_out)).astype(f32)[None, :] * f32(0.5)
+        for i in ro.choice(L, max(2, L // 3), replace=False):
+            p = f"transformer.resblocks.{int(i)}."
+            w[p + "mlp.c_proj.weight"][chans, :] *= gains[:, None]
+            w[p + "mlp.c_proj.bias"][chans] *= gains
+        # heavy-tailed LayerNorm gains (log-normal, sigma 0.5: a few of 768 gains reach 4-5x) - but the massive channels are read with a
+        # small gain, as trained nets do (otherwise every LayerNorm output is those channels alone)
+        names = ["ln_pre", "ln_post"] + [f"transformer.resblocks.{i}.{nm}" for i in range(L) for nm in ("ln_1", "ln_2")]
+        for nm in names:
+            gsc = np.exp(0.5 * ro.standard_normal(D)).astype(f32)
+            gsc[chans] = f32(0.05)
+            w[nm + ".weight"] = (w[nm + ".weight"] * gsc).astype(f32)
+        # sharper attention: near-one-hot rows in the later blocks
+        for i in range(L):
+            p = f"transformer.resblocks.{i}."
+            w[p + "attn.in_proj_weight"][:2 * D] *= f32(2.0)
     return w
 
 

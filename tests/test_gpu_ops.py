@@ -741,6 +741,96 @@ def test_gemm_bf16x3(ops, M, N, K):
     assert np.array_equal(hi, _bf16_round(out))
 
 
+@pytest.mark.parametrize("M,N,K", [(25120, 768, 768), (25120, 2304, 768), (25120, 3072, 768), (25120, 768, 3072), (12560, 3072, 768),
+                                   (12560, 768, 768), (25120, 512, 768)])
+def test_gemm_bf16x3_bench_shapes(ops, M, N, K):
+    """The GEMM instances the benchmark actually runs (B = 32 / 16 at 448^2: M = B * 785): the 320x256 tile `gemm_bf16x3_kernel<2,4,5,2>`
+    (49.9 % of the step) and the 256x256 tile `<2,4,4,2>` that the smaller shapes of test_gemm_bf16x3 never select - proj, QKV, fc1, fc2,
+    the final projection - against a float64 product, plain and with bias + QuickGELU + residual, and with the split-bf16 output."""
+    rs = np.random.RandomState(M % 1000 + N + K)
+    A = rs.standard_normal((M, K)).astype(np.float32)
+    W = (rs.standard_normal((N, K)) * 0.05).astype(np.float32)
+    bias = rs.standard_normal(N).astype(np.float32)
+    res = rs.standard_normal((M, N)).astype(np.float32)
+    ref = A.astype(np.float64) @ W.T.astype(np.float64)
+    As, Ws = ops.split_bf16(dev(A)), ops.split_bf16(dev(W))
+    out = host(ops.gemm_bf16x3(As, Ws))
+    scale = np.sqrt(K) * 0.05
+    assert maxabs(out, ref) < 3e-5 * scale
+    y = ref + bias
+    y = y * (1.0 / (1.0 + np.exp(-1.702 * y))) + res
+    out2 = host(ops.gemm_bf16x3(As, Ws, bias=dev(bias), residual=dev(res), act=1))
+    assert maxabs(out2, y) < 3e-5 * scale + 2e-6
+    hi, lo = _unsplit(host(ops.gemm_bf16x3(As, Ws, split_out=True)))
+    assert np.array_equal(hi, _bf16_round(out)) and np.array_equal(lo, _bf16_round(out - hi))
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_vit_b16_448_clip_like_outlier_net(ops, mode):
+    """Full-size ViT-B/16 @448 on a CLIP-LIKE STRESS NET (oracle.vit.make_vit_weights(outliers=True): 3-6 massive-activation channels at
+    50-100x the rest of the residual stream, log-normal LayerNorm gains, sharp attention rows) instead of the benign random net of the
+    other tests: bf16x3's error is relative, so the north-star gates must hold here too - CAM <= 1e-3 after the min-max
+    normalisation, w_aff within 5e-4 relative - in both matrix-core modes."""
+    cfg = VitConfig(width=768, layers=12, heads=12, patch=16, out_dim=512, input_resolution=224, n_surgery=5)
+    w = make_vit_weights(cfg, seed=1, attn_gain=2.0, outliers=True)
+    imgs = np.random.RandomState(4).standard_normal((1, 3, 448, 448)).astype(np.float32)
+    h = make_handle(ops, cfg, w, mode=mode)
+    r = h.forward(dev(imgs), want_w_aff=True, n_attn_out=6, want_raw=True)
+    x, attn, feats = oracle.vit.vit_forward(imgs, w, cfg)
+    resid = np.abs(feats[-1]).max(axis=(0, 1))
+    assert np.sort(resid)[-3] > 20 * np.median(resid)               # the stress regime is really there
+    f_ref, _, _ = oracle.cam.generate_clip_fts(imgs, w, cfg)
+    e_feat = relmax(host(r["image_features"]), f_ref)
+    e_aff = relmax(host(r["w_aff"]), attn[-6:, :, 1:, 1:].mean(0, dtype=np.float32))
+    text = np.random.RandomState(8).standard_normal((45, 512)).astype(np.float32)
+    text /= np.linalg.norm(text, axis=1, keepdims=True)
+    full, _ = ops.clip_feature_surgery(r["image_features"], dev(text), num_fg=20)
+    e_cam = maxabs(host(full), oracle.cam.clip_feature_surgery(f_ref, text))
+    print(f"outlier net, {mode}: feature rel err {e_feat:.2e}, w_aff rel err {e_aff:.2e}, CAM max-abs err {e_cam:.2e}")
+    assert e_cam < 1e-3 and e_aff < 5e-4 and e_feat < 5e-4
+
+
+def test_baseline_batch16_vit_cam(ops):
+    """BASELINE configs[1] on its own terms: 448x448, batch 16, ViT-B/16 surgery forward + patch-text CAM only (the GEMM tile the
+    launcher picks for M = 16 * 785 differs from B = 32's).  Batch invariance bit for bit against B = 1 for three of the 16 images,
+    the oracle on two of them (CAM gate 1e-3)."""
+    from excel_amd.model import ExCEL_model
+    from excel_amd.tools import synthetic
+    sd = synthetic.make_vit_state_dict(seed=0)
+    text = synthetic.make_text_features(45)
+    model = ExCEL_model(clip_model="ExCEL_ViT-B/16", num_classes=21, img_size=448, mode="train", state_dict=sd, text_features=text)
+    ds = synthetic.SyntheticSegDataset(16, (448, 448), seed=555)
+    _, imgs, _, _ = ds.batch(range(16))
+    x = dev(imgs)
+    _, _, attr, attn_w, _ = model(x)
+    assert attr.shape == (16, 784, 20)
+    for b in (0, 7, 15):
+        _, _, a1, w1, _ = model(x[b:b + 1])
+        assert torch.equal(a1[0], attr[b]) and torch.equal(w1.w_aff[0], attn_w.w_aff[b])
+    cfg = VitConfig(width=768, layers=12, heads=12, patch=16, out_dim=512, input_resolution=224, n_surgery=5)
+    wo = oracle.vit.reload_self_attn({k: np.asarray(v) for k, v in sd.items()}, cfg, 28, "train")
+    text_attr = host(model.text_attr)
+    for b in (3, 12):
+        f_ref, _, _ = oracle.cam.generate_clip_fts(imgs[b:b + 1], wo, cfg)
+        cam = oracle.cam.clip_feature_surgery(f_ref, text_attr.T.copy())[:, 1:, :20]
+        assert maxabs(host(attr[b]), cam[0]) < 1e-3
+
+
+def test_par_uniform_narrow_images(ops):
+    """The recomputing PAR tile kernel on UNIFORM batches narrower than 8 pixels (W = 4: the pitch the ragged path already runs it at):
+    same results as the oracle and as the streamed-affinity kernel (EXCEL_PAR_STREAM_AFFINITIES)."""
+    rs = np.random.RandomState(23)
+    for (H, W) in ((9, 4), (33, 4), (5, 8)):
+        img = rs.standard_normal((2, 3, H, W)).astype(np.float32)
+        masks = rs.rand(2, 3, H, W).astype(np.float32)
+        out = ops.par_forward(dev(img), dev(masks), num_iter=3)
+        ref = oracle.par.PAR([1, 2, 4, 8, 12, 24], 3)
+        for b in range(2):
+            assert maxabs(host(out)[b], ref(img[b:b + 1], masks[b:b + 1])[0]) < 5e-5, (H, W)
+        streamed = ops.par_forward(dev(img), dev(masks), num_iter=3, stream_affinities=True)
+        assert torch.equal(out, streamed), (H, W)
+
+
 def test_vit_b16_448_bf16x3_mode(ops):
     """Same BASELINE-shape check as the fp32 test, with the linear layers on the bf16x3 path: the CAM gate (1e-3)
     must hold with a wide margin (measured ~1e-5)."""

@@ -990,13 +990,44 @@ def test_infer_lam_data_folder_runs_ragged_batches_of_32(gpu, tmp_path):
     infer_lam.validate(infer_lam.get_parser().parse_args(crf + ["--api_path", "true", "--logits_dir", str(tmp_path / "logits_api")]))
     lam1, keys1 = imutils.load_logits(str(tmp_path / "logits_api" / (ids[5] + ".npy")))
     assert np.array_equal(lam, lam1) and list(keys) == list(keys1)
-    # a stale record (older than the run) is refused instead of being scored
-    import os
-    import time
+    # records carry the token of the run that wrote them: a record of ANOTHER run is refused instead of being scored (no dependence
+    # on file time stamps), a caller without a token accepts what is there
+    assert imutils.logits_run_token(str(logits / (ids[5] + ".npy"))) is not None
     args = infer_lam.get_parser().parse_args(crf)
-    args.run_started = time.time() + 3600
+    args.run_token = "some-other-run"
     with pytest.raises(RuntimeError, match="stale"):
         infer_lam.crf_proc(args, 0, 1, "cuda")
+    args.run_token = None
+    _, t_any = infer_lam.crf_proc(args, 0, 1, "cuda")
+    assert np.array_equal(host(t_any), host(crf_total))
+
+
+def test_device_feeder_hands_out_batches_and_closes(gpu):
+    """datasets/loader.DeviceFeeder: the device tensors it hands out equal the host batches; leaving the loop early (break) or dropping
+    the feeder right after the last batch stops the staging thread and waits for the consumer's kernels before the ring is freed
+    (the ring was freed while kernels could still read it; the thread stayed blocked on its queues)."""
+    import threading
+    from excel_amd.datasets.loader import DeviceFeeder, pack_samples, threaded_batches
+    from excel_amd.tools import synthetic
+    ds = synthetic.SyntheticSegDataset(23, num_classes=21, seed=5, ragged=True)
+    ref = [pack_samples([ds[j] for j in range(s0, min(s0 + 4, 23))]) for s0 in range(0, 23, 4)]
+    sums = []
+    feed = DeviceFeeder(threaded_batches(ds, range(23), 4, num_threads=3), "cuda")
+    for k, (names, plan, images, cls_t, labels_t) in enumerate(feed):
+        assert names == ref[k].names and torch.equal(images.cpu(), ref[k].images) and torch.equal(labels_t.cpu(), ref[k].labels)
+        assert torch.equal(cls_t.cpu(), ref[k].cls) and plan.B == len(names)
+        sums.append(images.to(torch.int64).sum())              # a kernel of the consumer's stream reads the ring buffer
+    assert len(sums) == len(ref) and [int(x) for x in sums] == [int(r.images.to(torch.int64).sum()) for r in ref]
+    assert not feed._thread.is_alive()
+    # early exit: the staging thread must not stay blocked on its queues
+    before = threading.active_count()
+    feed = DeviceFeeder(threaded_batches(ds, list(range(23)) * 4, 4, num_threads=3), "cuda", slots=3)
+    for k, item in enumerate(feed):
+        if k == 1:
+            break
+    feed.close()
+    feed._thread.join(10)
+    assert not feed._thread.is_alive() and threading.active_count() <= before + 3
 
 
 @pytest.mark.parametrize("gemm_mode", ["f32", "bf16x3"])

@@ -286,6 +286,148 @@ def test_validate_control_flow_world4_uneven_tail():
         assert abs(miou - oracle.evaluate.scores_from_hist(ref)["miou"]) < 1e-12
 
 
+class _BenchStubPipe:
+    """Stands in for TrainingFreePipeline under bench.main: the 'labels' of a batch are a function of its images, scored into `hist`."""
+
+    def __init__(self):
+        self.hist = torch.zeros(21, 21, dtype=torch.int64)
+        self.calls = 0
+
+    def reset(self):
+        self.hist.zero_()
+
+    def drain(self):
+        pass
+
+    def run_batch(self, imgs, cls, gts):
+        pred = (imgs.view(imgs.shape[0], -1)[:, :gts[0].numel()].to(torch.int64) % 21).reshape(gts.shape)
+        self.hist += torch.from_numpy(oracle.evaluate.fast_hist(gts.numpy().ravel(), pred.numpy().ravel(), 21))
+        self.calls += 1
+        return pred
+
+
+def _bench_stub_batches(rank, world, B, n_batches=2):
+    """Rank r's resident batches: images r, r+R, ... of a world*B*n_batches data set (bench.make_workload's sharding)."""
+    from excel_amd.tools.infer_lam import shard_indices
+    mine = shard_indices(world * B * n_batches, rank, world)
+    out = []
+    for i in range(n_batches):
+        idx = mine[i * B:(i + 1) * B]
+        imgs = torch.stack([torch.from_numpy(np.random.RandomState(900 + int(j)).randint(0, 256, (6, 7)).astype(np.int64)) for j in idx])
+        gts = torch.stack([torch.from_numpy(np.random.RandomState(1900 + int(j)).randint(0, 21, (6, 7)).astype(np.uint8)) for j in idx])
+        out.append((imgs, torch.zeros(B, 20), gts))
+    return out, mine
+
+
+def _bench_worker(rank, world, port, B, steps, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import contextlib
+    import io
+    import torch.distributed as dist  # noqa: F401
+    import bench
+    pipe = _BenchStubPipe()
+
+    def make_workload(args, r, w, device):
+        assert (r, w) == (rank, world) and args.batch == B
+        batches, _ = _bench_stub_batches(r, w, B)
+        return pipe, batches, [np.ones(B), np.ones(B)], None
+
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main(["--gpus", str(world), "--steps", str(steps), "--warmup", "1", "--batch", str(B), "--no-kernel-timing",
+                    "--cpu-images", "0", "--ragged-images", "0"],
+                   hooks={"backend": "gloo", "device": "cpu", "make_workload": make_workload})
+    q.put((rank, buf.getvalue(), pipe.calls, pipe.hist.numpy()))
+
+
+def test_bench_main_world8_gloo_stub_pipeline():
+    """bench.py's OWN multi-rank path (the command the driver's 8-GPU run executes) on 8 gloo ranks with a stand-in pipeline: sharding by
+    rank, warm-up + reset, the timed loop, the ONE all-gather of the confusion matrices, the max-over-ranks time, exactly one JSON line from
+    rank 0 whose `value` is the whole job's images over that time and whose per-rank masses show all 8 ranks."""
+    import json
+    import torch.multiprocessing as mp
+    world, B, steps = 8, 3, 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, B, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r for r in [q.get(timeout=300) for _ in range(world)]}
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    lines = [l for l in res[0][1].splitlines() if l.strip()]
+    assert len(lines) == 1 and all(not res[r][1].strip() for r in range(1, world))      # ONE line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["rccl_ranks"] == 8 and out["scaling"] == "weak" and out["steps"] == steps
+    assert abs(out["value"] - world * B * steps / (out["ms_per_step"] * 1e-3 * steps)) < 1e-3 * out["value"] + 1e-3
+    # every rank ran warm-up + steps batches of ITS shard; the gathered masses are the ranks' own scored pixels
+    expect_total = np.zeros((21, 21), np.int64)
+    for r in range(world):
+        assert res[r][2] == 1 + steps
+        batches, mine = _bench_stub_batches(r, world, B)
+        assert list(mine) == list(range(r, world * B * 2, world))
+        h = np.zeros((21, 21), np.int64)
+        for i in range(steps):
+            imgs, _, gts = batches[i % 2]
+            pred = (imgs.view(B, -1).numpy() % 21).ravel()
+            h += oracle.evaluate.fast_hist(gts.numpy().ravel(), pred, 21)
+        assert np.array_equal(res[r][3], h)
+        assert out["per_rank_hist_mass"][r] == int(h.sum())
+        expect_total += h
+    assert abs(out["miou_synthetic"] - round(float(oracle.evaluate.scores_from_hist(expect_total)["miou"]), 6)) < 1e-9
+
+
+def test_bench_self_launch_argv():
+    """`python bench.py --gpus N` launched bare re-executes itself as N ranks under torch.distributed.run on 127.0.0.1, with its own
+    arguments passed through (the driver's multi-GPU command has exactly this shape)."""
+    import sys
+    import bench
+    argv = bench.self_launch_argv(["--gpus", "8", "--steps", "20", "--warmup", "5"], 8, port=29417)
+    assert argv[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in argv and "--nproc-per-node=8" in argv
+    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1" and argv[argv.index("--master-port") + 1] == "29417"
+    i = argv.index(os.path.join(ROOT, "bench.py"))
+    assert argv[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    port = int(bench.self_launch_argv([], 2)[bench.self_launch_argv([], 2).index("--master-port") + 1])
+    assert 1024 < port < 65536
+    # without a GPU the bare command refuses before it launches anything
+    with pytest.raises(SystemExit):
+        bench.main(["--gpus", "2"])
+
+
+def test_pin_rank_to_cores_disjoint_shares():
+    """infer_lam.pin_rank_to_cores: local rank r of R takes the r-th contiguous share of the cores the process may run on; the shares are
+    disjoint (8 ranks x (16 decode threads + launch thread) on one host, BASELINE configs[3])."""
+    from excel_amd.tools.infer_lam import pin_rank_to_cores
+    if not hasattr(os, "sched_getaffinity") or len(os.sched_getaffinity(0)) < 2:
+        pytest.skip("needs >= 2 cores and sched_setaffinity")
+    saved = os.sched_getaffinity(0)
+    try:
+        cores = sorted(saved)
+        R = min(4, len(cores))
+        shares = []
+        for r in range(R):
+            os.sched_setaffinity(0, saved)
+            shares.append(pin_rank_to_cores(r, R))
+            assert os.sched_getaffinity(0) == shares[-1]
+        per = len(cores) // R
+        assert all(len(sh) == per for sh in shares) and len(set().union(*shares)) == R * per
+        assert shares[0] == set(cores[:per])
+        os.sched_setaffinity(0, saved)
+        assert pin_rank_to_cores(0, 1) is None and os.sched_getaffinity(0) == saved
+    finally:
+        os.sched_setaffinity(0, saved)
+
+
+def test_loaded_library_is_built_from_these_sources():
+    """excel_build_id(): the id compiled into libexcel_hip.so equals the id of the sources in the tree (excel_amd/build.py:source_id)."""
+    from excel_amd import _lib, build
+    build.build(verbose=False)
+    assert _lib.build_id() == build.source_id() and len(build.source_id(dev=False)) == 16
+
+
 def test_ragged_loaders_pack_in_order():
     """datasets/loader: threaded_batches (decode thread pool, the harness default) and ragged_batches (DataLoader worker processes, the
     reference's mechanism) hand out the same RaggedBatches, in index order, last batch partial, images / labels packed back to back."""
