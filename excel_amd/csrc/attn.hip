@@ -37,6 +37,7 @@ struct RowpassArgs {
     const unsigned short* vt;     // (rounds 1-2: V^T for the bf16x3 P.V; the bf16x3 row pass reads V from qkvs through the LDS transpose read)
     int vt_kp;
     int xcd_local;       // 1: workgroups of one (image, head) on one XCD
+    int tail_grp;        // (image, head) groups per chunk of the XCD-local order: their full q-blocks, then their partial last q-blocks
 };
 
 typedef unsigned short u16;
@@ -493,9 +494,15 @@ __global__ __launch_bounds__(256, 2) void attn_rowpass_kernel(RowpassArgs p) {
             // ... and, inside an XCD's chunk, the full q-blocks first and the partial last q-block of every (image, head) at the end:
             // 384 x 7 workgroups on 768 slots are 3.5 rounds; 384 x 6 full ones are exactly 3, and the tail round is then made of the
             // short blocks (17 of 128 rows at N = 785: one active wave) instead of a half-empty round of full ones
-            const int x = lin & 7, loc = lin >> 3, per = nbh >> 3, nfull = per * (nq - 1);
-            if (loc < nfull) { bh = x * per + loc / (nq - 1); qb = loc % (nq - 1); }
-            else { bh = x * per + (loc - nfull); qb = nq - 1; }
+            // Round 4: not ONE tail per XCD but one per chunk of `tail_grp` groups: the partial block of a group then runs while the
+            // group's K / V tiles (400 KB per (image, head)) are still in the XCD's 4-MB L2 - at the very end every partial block
+            // re-fetched them from the fabric (PMC: 463 MB per launch against 312 MB before the tail order, ~308 MB algorithmic).
+            const int x = lin & 7, loc = lin >> 3, per = nbh >> 3;
+            const int grp = min(max(p.tail_grp, 1), per), cs = grp * nq;
+            const int c = loc / cs, within = loc - c * cs;
+            const int g0 = c * grp, gcount = min(grp, per - g0), nfull = gcount * (nq - 1);
+            if (within < nfull) { bh = x * per + g0 + within / (nq - 1); qb = within % (nq - 1); }
+            else { bh = x * per + g0 + (within - nfull); qb = nq - 1; }
         } else {
             const int id = xcd_remap(lin, nq * nbh);
             qb = id % nq;
@@ -919,9 +926,10 @@ int excel_launch_attn_rowpass(const float* qkvh, float* out, float* stats, int B
     ProfScope prof__(PROF_ATTN_ROWPASS, st);
     EXCEL_CHECK_ARG(hd == HD, "attention: head_dim must be 64 (got %d)", hd);
     EXCEL_CHECK_ARG(ntypes == 1 || ntypes == 4, "attention: ntypes must be 1 or 4");
-    RowpassArgs a{qkvh, out, reinterpret_cast<float2*>(stats), B, H, N, scale, split_out, qkvs, flash_nq, vt, vt_kp, 1};
+    RowpassArgs a{qkvh, out, reinterpret_cast<float2*>(stats), B, H, N, scale, split_out, qkvs, flash_nq, vt, vt_kp, 1, 1 << 20};
 #ifdef EXCEL_DEV
     { static const int x = getenv("EXCEL_ROWPASS_XCD") ? atoi(getenv("EXCEL_ROWPASS_XCD")) : 1; a.xcd_local = x; }
+    { static const int g = getenv("EXCEL_ROWPASS_GRP") ? atoi(getenv("EXCEL_ROWPASS_GRP")) : 0; if (g > 0) a.tail_grp = g; }
 #endif
     hipLaunchKernelGGL(attn_rowpass_kernel, dim3(cdiv(N, 128), B * H, ntypes), dim3(256), 0, st, a);
     EXCEL_CHECK_LAUNCH("attn_rowpass");

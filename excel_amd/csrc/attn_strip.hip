@@ -16,11 +16,17 @@
 // Two sweeps over the heads reuse one accumulator set: sweep A (q.q, k.k, v.v -> A_sum), then sweep W (q.k -> W).
 // Workgroups of one image are placed on one XCD (xcd_remap) so its q|k|v planes are fetched from HBM once per XCD L2.
 #include <stdlib.h>
+#include <type_traits>
+#include <utility>
 #include "common.h"
 #include "excel_internal.h"
 
 typedef unsigned short u16;
 
+template <class F, int... I> __device__ __forceinline__ void static_for_seq(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_seq(f, std::make_integer_sequence<int, N>{}); }
+
+#define STRIP_VAR 0          // the variant the shipped library runs (see the kernel header)
 #define GLDS(src, dst) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
 struct StripArgs {
@@ -40,7 +46,13 @@ struct StripArgs {
     int split_c;          // > 0: the two sweeps of a strip are separate workgroups, split_c strips per XCD (see the launcher)
 };
 
-template <int NTW, int DBG>
+// VAR (round 4; bit set = on):
+//   bit0  the 12 MFMAs of a score tile alternate between TWO accumulators per k-step (the first MFMA of each takes C = 0), summed at
+//         the end: the DMA instalments / address updates between k-steps then sit between MFMAs on DIFFERENT accumulators (an extra
+//         issue slot between two MFMAs on the same accumulator costs ~43 cycles on this core, MI355X_MICROARCH.md); all folds early
+//   bit1  the key fragments of tile j+1 are read into the registers tile j's MFMAs have just released, one k-step at a time, behind
+//         those MFMAs: the LDS round trip (and the wait for the tile's DMA) leaves the wave's critical path
+template <int NTW, int DBG, int VAR>
 __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
     constexpr int TILE_EL = 32 * 128;                                    // u16 elements of a 32-row operand tile (8 KB)
     // one LDS object: [wave][slot] key tiles (128 KB) | [parity] query strip of a phase (16 KB)
@@ -173,7 +185,17 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
         f32x16 s[NTW];
         float mref[NTW];                                           // running maximum (log2 units) tile j was exponentiated against
         bool pending = false;
-        const bool late_f = (wave & 4) != 0;
+        const bool late_f = (VAR & 7) ? false : (wave & 4) != 0;
+        bf16x8 yh[4], yl[4];                                       // key fragments (VAR bit 1: carried from tile to tile)
+        if constexpr ((VAR & 6) != 0) {
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // tile 0 of the stream landed (tile 1 may be in flight)
+            const unsigned k0 = ring_addr + (r * 128) * 2;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                yh[s4] = lds_read16(k0 + (((s4 * 2 + kh) ^ (r & 15)) * 16));
+                yl[s4] = lds_read16(k0 + (((8 + s4 * 2 + kh) ^ (r & 15)) * 16));
+            }
+        }
         auto apply_phase = [&](int tp) {
             const unsigned ls = lstat_addr + (tp & 1) * (8 * 32 * 8);
             float M, L = 0.f;
@@ -239,50 +261,205 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
                 m_run = m_new;
                 mref[j] = m_new;
             };
+            if constexpr ((VAR & 4) != 0) {
+                // ---- VAR bit 2: the softmax of tile j-1 runs INSIDE tile j's MFMA block, a few single-issue VALU per MFMA gap (an MFMA
+                // occupies the matrix pipe for 32 cycles = ~8 issue slots of this wave), and consecutive MFMAs alternate between the two
+                // accumulators (k-steps {0,1} and {2,3} interleaved), so no filler sits between two MFMAs on the SAME accumulator.
+                // Scalar fma / add instead of the packed forms (packed fp32 beside MFMAs is slower than two scalar ops on this core);
+                // even / odd partial sums like the packed version -> the same bits.
+                float sm_tm = 0.f, sm_mnew = 0.f, sm_pe = 0.f, sm_po = 0.f;
+                auto sm_chunk = [&](int jp, auto cc) {
+                    constexpr int c = decltype(cc)::value;
+                    if constexpr (c == 0) {
+                        sm_tm = fmaxf(s[jp][0], s[jp][1]);
 #pragma unroll
-            for (int j = 0; j < NTW; ++j) {
-                if (j < NTW - 1 || full) {
-                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                        // tile gc landed (gc+1 may be in flight)
-                    const unsigned kr = ring_addr + ((gc & 1) * TILE_EL + r * 128) * 2;
-                    bf16x8 yh[4], yl[4];
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) {
-                        yh[s4] = lds_read16(kr + (((s4 * 2 + kh) ^ (r & 15)) * 16));
-                        yl[s4] = lds_read16(kr + (((8 + s4 * 2 + kh) ^ (r & 15)) * 16));
+                        for (int e = 2; e < 8; e += 2) sm_tm = fmaxf(fmaxf(sm_tm, s[jp][e]), s[jp][e + 1]);
+                        asm volatile("" : "+v"(sm_tm));            // (pins: the optimiser otherwise sinks the whole chain to its last use)
                     }
-                    lds_wait8(yh, yl);                                                      // fragments in registers: the slot is free
-                    if ((DBG & 1) && !(DBG & 2)) issue_next();                              // tile gc+2 -> this slot
-                    ++gc;
-                    f32x16 sj;
+                    if constexpr (c == 1) {
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) sj[e] = 0.f;
-                    if (!(DBG & 1)) {
+                        for (int e = 8; e < 16; e += 2) sm_tm = fmaxf(fmaxf(sm_tm, s[jp][e]), s[jp][e + 1]);
+                        sm_mnew = fmaxf(m_run, sm_tm * c2);
+                        asm volatile("" : "+v"(sm_mnew));
+                    }
+                    if constexpr (c == 2) {
+                        l_run *= __builtin_amdgcn_exp2f(m_run - sm_mnew);
+                        sm_pe = 0.f; sm_po = 0.f;
+                        asm volatile("" : "+v"(l_run));
+                    }
+                    if constexpr (c >= 2 && c <= 9) {
+                        constexpr int e0 = 2 * (c - 2);
+                        const float a0 = fmaf(s[jp][e0], c2, -sm_mnew), a1 = fmaf(s[jp][e0 + 1], c2, -sm_mnew);
+                        const float p0 = __builtin_amdgcn_exp2f(a0), p1 = __builtin_amdgcn_exp2f(a1);
+                        s[jp][e0] = p0; s[jp][e0 + 1] = p1;
+                        sm_pe += p0; sm_po += p1;
+                        asm volatile("" : "+v"(s[jp][e0]), "+v"(s[jp][e0 + 1]), "+v"(sm_pe), "+v"(sm_po));
+                    }
+                    if constexpr (c == 9) {
+                        l_run += sm_pe + sm_po;
+                        m_run = sm_mnew;
+                        mref[jp] = sm_mnew;
+                    }
+                };
+#define STRIP_GAP() __builtin_amdgcn_sched_barrier(0)
+#define STRIP_CH(c) do { if (j > 0) sm_chunk(j - 1, std::integral_constant<int, c>{}); } while (0)
+#define STRIP_RD(s4) do { yh[s4] = lds_read16(kn + ((((s4) * 2 + kh) ^ (r & 15)) * 16)); yl[s4] = lds_read16(kn + (((8 + (s4) * 2 + kh) ^ (r & 15)) * 16)); } while (0)
+#define STRIP_MF(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    if (j < NTW - 1 || full) {
+                        lds_wait8(yh, yl);                                                      // this tile's fragments (read behind the previous tile's MFMAs)
+                        ++gc;
+                        const unsigned kn = ring_addr + ((gc & 1) * TILE_EL + r * 128) * 2;      // the next tile of the stream
+                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        f32x16 sa, sb;
+                        STRIP_GAP(); issue_next_part(0); STRIP_GAP();
+                        sa = STRIP_MF(yl[0], xh[0], zero); STRIP_GAP(); STRIP_CH(0); STRIP_GAP();
+                        sb = STRIP_MF(yl[1], xh[1], zero); STRIP_GAP(); STRIP_CH(1); STRIP_GAP();
+                        sa = STRIP_MF(yh[0], xl[0], sa); STRIP_GAP(); STRIP_CH(2); STRIP_GAP();
+                        sb = STRIP_MF(yh[1], xl[1], sb); STRIP_GAP(); STRIP_CH(3); STRIP_GAP();
+                        sa = STRIP_MF(yh[0], xh[0], sa); STRIP_GAP();
+                        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                        // all but the two pieces just issued: the next tile landed
+                        STRIP_RD(0); STRIP_CH(4); STRIP_GAP();
+                        sb = STRIP_MF(yh[1], xh[1], sb); STRIP_GAP(); STRIP_RD(1); issue_next_part(1); STRIP_GAP();
+                        sa = STRIP_MF(yl[2], xh[2], sa); STRIP_GAP(); STRIP_CH(5); STRIP_GAP();
+                        sb = STRIP_MF(yl[3], xh[3], sb); STRIP_GAP(); STRIP_CH(6); STRIP_GAP();
+                        sa = STRIP_MF(yh[2], xl[2], sa); STRIP_GAP(); STRIP_CH(7); issue_next_part(2); STRIP_GAP();
+                        sb = STRIP_MF(yh[3], xl[3], sb); STRIP_GAP(); STRIP_CH(8); STRIP_GAP();
+                        sa = STRIP_MF(yh[2], xh[2], sa); STRIP_GAP(); STRIP_RD(2); STRIP_CH(9); STRIP_GAP();
+                        sb = STRIP_MF(yh[3], xh[3], sb); STRIP_GAP(); STRIP_RD(3); issue_next_part(3); STRIP_GAP();
+                        f32x16 sj = sa + sb;
+                        if (ragged && first + j == last_tile) {                                 // wave-uniform: keys >= N only here
+                            int lim = nvalid_last;
+                            asm volatile("" : "+v"(lim));
+#pragma unroll
+                            for (int e = 0; e < 16; ++e)
+                                if ((e & 3) + 8 * (e >> 2) >= lim) sj[e] = -INFINITY;
+                        }
+                        s[j] = sj;
+                    }
+                }
+                {   // the last tile's softmax has no MFMA block to hide in
+                    const int jl = full ? NTW - 1 : (NTW > 1 ? NTW - 2 : 0);
+                    static_for<10>([&](auto cc) { sm_chunk(jl, cc); });
+                }
+#undef STRIP_GAP
+#undef STRIP_CH
+#undef STRIP_RD
+#undef STRIP_MF
+            } else
+            if constexpr ((VAR & 3) == 0) {
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    if (j < NTW - 1 || full) {
+                        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                        // tile gc landed (gc+1 may be in flight)
+                        const unsigned kr = ring_addr + ((gc & 1) * TILE_EL + r * 128) * 2;
+                        bf16x8 yh[4], yl[4];
+    #pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) {
+                            yh[s4] = lds_read16(kr + (((s4 * 2 + kh) ^ (r & 15)) * 16));
+                            yl[s4] = lds_read16(kr + (((8 + s4 * 2 + kh) ^ (r & 15)) * 16));
+                        }
+                        lds_wait8(yh, yl);                                                      // fragments in registers: the slot is free
+                        if ((DBG & 1) && !(DBG & 2)) issue_next();                              // tile gc+2 -> this slot
+                        ++gc;
+                        f32x16 sj;
+    #pragma unroll
+                        for (int e = 0; e < 16; ++e) sj[e] = 0.f;
+                        if (!(DBG & 1)) {
+    #pragma unroll
+                            for (int s4 = 0; s4 < 4; ++s4) {
+                                if (!(DBG & 2)) issue_next_part(s4);                            // tile gc+2 -> this slot, two pieces per k-step
+                                sj = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl[s4], xh[s4], sj, 0, 0, 0);
+                                sj = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[s4], xl[s4], sj, 0, 0, 0);
+                                sj = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[s4], xh[s4], sj, 0, 0, 0);
+                                __builtin_amdgcn_sched_barrier(0);                              // keep the instalments where they are
+                            }
+                        } else {
+                            sj[0] = (float)yl[0][0] + (float)yh[3][1] + (float)xh[0][0] + (float)xl[3][1];
+                        }
+                        if (NTW < 5) {                                                          // (at 5 tiles per wave the register file has no room for the overlap)
+                            if (j > 0 && !(DBG & 4)) softmax_tile(j - 1);                       // in the shadow of these MFMAs
+                        }
+                        if (ragged && first + j == last_tile) {                                 // wave-uniform: keys >= N only here
+                            int lim = nvalid_last;                    // opaque: the 16 lane masks must not be hoisted into (spilled) SGPR pairs
+                            asm volatile("" : "+v"(lim));
+    #pragma unroll
+                            for (int e = 0; e < 16; ++e)
+                                if ((e & 3) + 8 * (e >> 2) >= lim) sj[e] = -INFINITY;
+                        }
+                        if (j == 0 && pending && late_f) apply_phase(t - 1);                    // late F: behind tile 0's MFMAs, before s[0] is replaced
+                        s[j] = sj;
+                    }
+                }
+} else {
+                // ---- round-4 tile loop (VAR bits 0 / 1, see the kernel header)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    if (j < NTW - 1 || full) {
+                        if constexpr (VAR & 2) {
+                            lds_wait8(yh, yl);                                                  // this tile's fragments (read behind the previous tile's MFMAs)
+                        } else {
+                            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                    // tile gc landed (gc+1 may be in flight)
+                            const unsigned kr = ring_addr + ((gc & 1) * TILE_EL + r * 128) * 2;
+#pragma unroll
+                            for (int s4 = 0; s4 < 4; ++s4) {
+                                yh[s4] = lds_read16(kr + (((s4 * 2 + kh) ^ (r & 15)) * 16));
+                                yl[s4] = lds_read16(kr + (((8 + s4 * 2 + kh) ^ (r & 15)) * 16));
+                            }
+                            lds_wait8(yh, yl);                                                  // fragments in registers: the slot is free
+                        }
+                        ++gc;
+                        const unsigned kn = ring_addr + ((gc & 1) * TILE_EL + r * 128) * 2;      // the NEXT tile of the stream (VAR bit 1)
+                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        f32x16 sa, sb;
 #pragma unroll
                         for (int s4 = 0; s4 < 4; ++s4) {
-                            if (!(DBG & 2)) issue_next_part(s4);                            // tile gc+2 -> this slot, two pieces per k-step
-                            sj = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl[s4], xh[s4], sj, 0, 0, 0);
-                            sj = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[s4], xl[s4], sj, 0, 0, 0);
-                            sj = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[s4], xh[s4], sj, 0, 0, 0);
-                            __builtin_amdgcn_sched_barrier(0);                              // keep the instalments where they are
+                            issue_next_part(s4);                                                // tile gc+1 -> this tile's slot, two pieces per k-step
+                            __builtin_amdgcn_sched_barrier(0);                                  // ... BETWEEN the MFMA groups (different accumulators)
+                            if (s4 == 0) {
+                                sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl[0], xh[0], zero, 0, 0, 0);
+                                sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[0], xl[0], sa, 0, 0, 0);
+                                sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[0], xh[0], sa, 0, 0, 0);
+                            } else if (s4 == 1) {
+                                sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl[1], xh[1], zero, 0, 0, 0);
+                                sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[1], xl[1], sb, 0, 0, 0);
+                                sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[1], xh[1], sb, 0, 0, 0);
+                            } else if (s4 == 2) {
+                                sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl[2], xh[2], sa, 0, 0, 0);
+                                sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[2], xl[2], sa, 0, 0, 0);
+                                sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[2], xh[2], sa, 0, 0, 0);
+                            } else {
+                                sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl[3], xh[3], sb, 0, 0, 0);
+                                sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[3], xl[3], sb, 0, 0, 0);
+                                sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[3], xh[3], sb, 0, 0, 0);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            if constexpr (VAR & 2) {
+                                // everything older than the 2 (s4 + 1) pieces just issued has landed: the next tile is in its slot
+                                if (s4 == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                                yh[s4] = lds_read16(kn + (((s4 * 2 + kh) ^ (r & 15)) * 16));
+                                yl[s4] = lds_read16(kn + (((8 + s4 * 2 + kh) ^ (r & 15)) * 16));
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
                         }
-                    } else {
-                        sj[0] = (float)yl[0][0] + (float)yh[3][1] + (float)xh[0][0] + (float)xl[3][1];
-                    }
-                    if (NTW < 5) {                                                          // (at 5 tiles per wave the register file has no room for the overlap)
-                        if (j > 0 && !(DBG & 4)) softmax_tile(j - 1);                       // in the shadow of these MFMAs
-                    }
-                    if (ragged && first + j == last_tile) {                                 // wave-uniform: keys >= N only here
-                        int lim = nvalid_last;                    // opaque: the 16 lane masks must not be hoisted into (spilled) SGPR pairs
-                        asm volatile("" : "+v"(lim));
+                        if (NTW < 5) {
+                            if (j > 0 && !(DBG & 4)) softmax_tile(j - 1);                       // in the shadow of these MFMAs
+                        }
+                        f32x16 sj = sa + sb;
+                        if (ragged && first + j == last_tile) {                                 // wave-uniform: keys >= N only here
+                            int lim = nvalid_last;
+                            asm volatile("" : "+v"(lim));
 #pragma unroll
-                        for (int e = 0; e < 16; ++e)
-                            if ((e & 3) + 8 * (e >> 2) >= lim) sj[e] = -INFINITY;
+                            for (int e = 0; e < 16; ++e)
+                                if ((e & 3) + 8 * (e >> 2) >= lim) sj[e] = -INFINITY;
+                        }
+                        s[j] = sj;
                     }
-                    if (j == 0 && pending && late_f) apply_phase(t - 1);                    // late F: behind tile 0's MFMAs, before s[0] is replaced
-                    s[j] = sj;
                 }
             }
-            if (!(DBG & 4)) {
+            if constexpr ((VAR & 4) != 0) {
+            } else if (!(DBG & 4)) {
                 if (NTW < 5) {
                     if (full) softmax_tile(NTW - 1);
                     else if (NTW > 1) softmax_tile(NTW > 1 ? NTW - 2 : 0);
@@ -422,25 +599,39 @@ int excel_launch_attn_strip(const unsigned short* qkvs, unsigned short* a_sum, f
     static const int dbg = getenv("EXCEL_STRIP_DBG") ? atoi(getenv("EXCEL_STRIP_DBG")) : 0;
     if (dbg && ntw == 4) {
         switch (dbg) {
-            case 1: hipLaunchKernelGGL((attn_strip_kernel<4, 1>), grid, block, 0, st, a); break;
-            case 2: hipLaunchKernelGGL((attn_strip_kernel<4, 2>), grid, block, 0, st, a); break;
-            case 3: hipLaunchKernelGGL((attn_strip_kernel<4, 3>), grid, block, 0, st, a); break;
-            case 4: hipLaunchKernelGGL((attn_strip_kernel<4, 4>), grid, block, 0, st, a); break;
-            case 5: hipLaunchKernelGGL((attn_strip_kernel<4, 5>), grid, block, 0, st, a); break;
-            case 6: hipLaunchKernelGGL((attn_strip_kernel<4, 6>), grid, block, 0, st, a); break;
-            case 7: hipLaunchKernelGGL((attn_strip_kernel<4, 7>), grid, block, 0, st, a); break;
-            default: hipLaunchKernelGGL((attn_strip_kernel<4, 8>), grid, block, 0, st, a); break;
+            case 1: hipLaunchKernelGGL((attn_strip_kernel<4, 1, 0>), grid, block, 0, st, a); break;
+            case 2: hipLaunchKernelGGL((attn_strip_kernel<4, 2, 0>), grid, block, 0, st, a); break;
+            case 3: hipLaunchKernelGGL((attn_strip_kernel<4, 3, 0>), grid, block, 0, st, a); break;
+            case 4: hipLaunchKernelGGL((attn_strip_kernel<4, 4, 0>), grid, block, 0, st, a); break;
+            case 5: hipLaunchKernelGGL((attn_strip_kernel<4, 5, 0>), grid, block, 0, st, a); break;
+            case 6: hipLaunchKernelGGL((attn_strip_kernel<4, 6, 0>), grid, block, 0, st, a); break;
+            case 7: hipLaunchKernelGGL((attn_strip_kernel<4, 7, 0>), grid, block, 0, st, a); break;
+            default: hipLaunchKernelGGL((attn_strip_kernel<4, 8, 0>), grid, block, 0, st, a); break;
+        }
+        EXCEL_CHECK_LAUNCH("attn_strip");
+        return EXCEL_OK;
+    }
+#endif
+#ifdef EXCEL_DEV
+    static const int var = getenv("EXCEL_STRIP_VAR") ? atoi(getenv("EXCEL_STRIP_VAR")) : STRIP_VAR;
+    if (ntw == 4 && var != STRIP_VAR) {
+        switch (var) {
+            case 0: hipLaunchKernelGGL((attn_strip_kernel<4, 0, 0>), grid, block, 0, st, a); break;
+            case 1: hipLaunchKernelGGL((attn_strip_kernel<4, 0, 1>), grid, block, 0, st, a); break;
+            case 2: hipLaunchKernelGGL((attn_strip_kernel<4, 0, 2>), grid, block, 0, st, a); break;
+            case 3: hipLaunchKernelGGL((attn_strip_kernel<4, 0, 3>), grid, block, 0, st, a); break;
+            default: hipLaunchKernelGGL((attn_strip_kernel<4, 0, 7>), grid, block, 0, st, a); break;
         }
         EXCEL_CHECK_LAUNCH("attn_strip");
         return EXCEL_OK;
     }
 #endif
     switch (ntw) {
-        case 1: hipLaunchKernelGGL((attn_strip_kernel<1, 0>), grid, block, 0, st, a); break;
-        case 2: hipLaunchKernelGGL((attn_strip_kernel<2, 0>), grid, block, 0, st, a); break;
-        case 3: hipLaunchKernelGGL((attn_strip_kernel<3, 0>), grid, block, 0, st, a); break;
-        case 4: hipLaunchKernelGGL((attn_strip_kernel<4, 0>), grid, block, 0, st, a); break;
-        default: hipLaunchKernelGGL((attn_strip_kernel<5, 0>), grid, block, 0, st, a); break;
+        case 1: hipLaunchKernelGGL((attn_strip_kernel<1, 0, STRIP_VAR>), grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((attn_strip_kernel<2, 0, STRIP_VAR>), grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL((attn_strip_kernel<3, 0, STRIP_VAR>), grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL((attn_strip_kernel<4, 0, STRIP_VAR>), grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL((attn_strip_kernel<5, 0, STRIP_VAR>), grid, block, 0, st, a); break;
     }
     EXCEL_CHECK_LAUNCH("attn_strip");
     return EXCEL_OK;

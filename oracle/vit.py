@@ -105,24 +105,43 @@ def make_vit_weights(cfg: VitConfig, seed: int = 0, attn_gain: float = 4.0, outl
     return w
 
 
+# Arithmetic type of the restatement: fp32 like the reference.  `precision(np.float64)` re-runs the SAME code in float64 - used only to
+# put a number on the fp32 path's own round-off in ill-conditioned regimes (the CLIP-like stress net), never as the parity target.
+F32 = np.float32
+
+
+class precision:
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global F32
+        self.saved, F32 = F32, self.dtype
+        return self
+
+    def __exit__(self, *exc):
+        global F32
+        F32 = self.saved
+
+
 def layer_norm(x, w, b, eps=1e-5):
     # LayerNorm subclass computing in fp32, eps = torch default (:271-277)
-    x = x.astype(np.float32)
-    mu = x.mean(-1, keepdims=True, dtype=np.float32)
+    x = x.astype(F32)
+    mu = x.mean(-1, keepdims=True, dtype=F32)
     xc = x - mu
-    var = (xc * xc).mean(-1, keepdims=True, dtype=np.float32)
-    return (xc / np.sqrt(var + np.float32(eps))) * w + b
+    var = (xc * xc).mean(-1, keepdims=True, dtype=F32)
+    return (xc / np.sqrt(var + F32(eps))) * w + b
 
 
 def quick_gelu(x):
     # QuickGELU :280-282
-    return x * (np.float32(1) / (np.float32(1) + np.exp(np.float32(-1.702) * x)))
+    return x * (F32(1) / (F32(1) + np.exp(F32(-1.702) * x)))
 
 
 def softmax(x, axis=-1):
     m = x.max(axis=axis, keepdims=True)
     e = np.exp(x - m)
-    return e / e.sum(axis=axis, keepdims=True, dtype=np.float32)
+    return e / e.sum(axis=axis, keepdims=True, dtype=F32)
 
 
 def resize_pos_embed(pos, new_side):
@@ -134,7 +153,7 @@ def resize_pos_embed(pos, new_side):
     grid = pos[1:].reshape(side, side, D).transpose(2, 0, 1)          # [D, side, side]
     grid = bilinear_resize(grid, new_side, new_side, align_corners=False)
     grid = grid.reshape(D, new_side * new_side).T
-    return np.concatenate([pos[:1], grid], 0).astype(np.float32)
+    return np.concatenate([pos[:1], grid], 0).astype(F32)
 
 
 def _split_heads(t, h):
@@ -157,28 +176,28 @@ def mha_block_attention(y, p, w, cfg):
     """nn.MultiheadAttention(need_weights=True): returns (out [N,D], head-MEAN weights [N,N])."""
     h = cfg.heads
     q, k, v = _qkv(y, p, w, h)
-    scale = np.float32(cfg.head_dim ** -0.5)
+    scale = F32(cfg.head_dim ** -0.5)
     a = softmax((q * scale) @ k.transpose(0, 2, 1))
     o = _merge_heads(a @ v) @ w[p + "attn.out_proj.weight"].T + w[p + "attn.out_proj.bias"]
-    return o.astype(np.float32), a.mean(0, dtype=np.float32)
+    return o.astype(F32), a.mean(0, dtype=F32)
 
 
 def feature_similarity(feats, beta=1.0, gamma=3.0):
     """Shared front of the LVC branch (:130-133) and of attn_pred (model/model_excel.py:71-75): channel-normalised
     token similarity, shifted by beta x the mean over the WHOLE batch tensor and scaled by gamma.
     feats [B,C,g,g] (or [B,C,P]) -> [B,P,P] f32."""
-    f = np.asarray(feats, np.float32)
+    f = np.asarray(feats, F32)
     f = f.reshape(f.shape[0], f.shape[1], -1)
-    nrm = np.sqrt((f * f).sum(1, keepdims=True, dtype=np.float32))
-    f = f / np.maximum(nrm, np.float32(1e-12))                        # F.normalize(dim=1), eps 1e-12
-    sim = np.einsum("bcm,bcn->bmn", f, f).astype(np.float32)          # :131
-    return ((sim - sim.mean(dtype=np.float32) * np.float32(beta)) * np.float32(gamma)).astype(np.float32)   # :132
+    nrm = np.sqrt((f * f).sum(1, keepdims=True, dtype=F32))
+    f = f / np.maximum(nrm, F32(1e-12))                        # F.normalize(dim=1), eps 1e-12
+    sim = np.einsum("bcm,bcn->bmn", f, f).astype(F32)          # :131
+    return ((sim - sim.mean(dtype=F32) * F32(beta)) * F32(gamma)).astype(F32)   # :132
 
 
 def ex_attention(ex_feats):
     """Attention.forward :128-137: negatives of the similarity -> -inf, row softmax.  [B,C,g,g] -> ex_attn [B,P,P]."""
     sim = feature_similarity(ex_feats, 1.0, 3.0)
-    sim = np.where(sim < 0, -np.inf, sim).astype(np.float32)          # :133
+    sim = np.where(sim < 0, -np.inf, sim).astype(F32)          # :133
     return softmax(sim)                                               # :137 (identical for every head)
 
 
@@ -187,21 +206,21 @@ def surgery_attention(y, p, w, cfg, ex_attn=None):
     ex_attn [P,P] (LVC branch :127-141) is added to every head's attn[1:,1:]."""
     h = cfg.heads
     q, k, v = _qkv(y, p, w, h)
-    scale = np.float32(cfg.head_dim ** -0.5)
+    scale = F32(cfg.head_dim ** -0.5)
     attn_ori = softmax((q @ k.transpose(0, 2, 1)) * scale)            # :102-103
     a1 = softmax((q @ q.transpose(0, 2, 1)) * scale)                  # :119
     a2 = softmax((k @ k.transpose(0, 2, 1)) * scale)                  # :120
     a3 = softmax((v @ v.transpose(0, 2, 1)) * scale)                  # :121
-    attn = (a1 + a2 + a3) / np.float32(3)                             # :125 / :139
+    attn = (a1 + a2 + a3) / F32(3)                             # :125 / :139
     if ex_attn is not None:
-        attn[:, 1:, 1:] = attn[:, 1:, 1:] + np.asarray(ex_attn, np.float32)[None]    # :140-141
-    attn = attn.sum(0, keepdims=True, dtype=np.float32)               # :146  head-summed, broadcast on V
+        attn[:, 1:, 1:] = attn[:, 1:, 1:] + np.asarray(ex_attn, F32)[None]    # :140-141
+    attn = attn.sum(0, keepdims=True, dtype=F32)               # :146  head-summed, broadcast on V
     x_ori = _merge_heads(attn_ori @ v)                                # :148
     x = _merge_heads(attn @ v)                                        # :149
     Wo, bo = w[p + "attn.out_proj.weight"], w[p + "attn.out_proj.bias"]
     x = x @ Wo.T + bo                                                 # :151
     x_ori = x_ori @ Wo.T + bo                                         # :152
-    return x.astype(np.float32), x_ori.astype(np.float32), attn_ori.sum(0, dtype=np.float32)  # :154
+    return x.astype(F32), x_ori.astype(F32), attn_ori.sum(0, dtype=F32)  # :154
 
 
 def mlp(x, p, w):
@@ -215,7 +234,7 @@ def patch_embed(img, w, cfg):
     C, S, _ = img.shape
     g = S // ps
     patches = img.reshape(C, g, ps, g, ps).transpose(1, 3, 0, 2, 4).reshape(g * g, C * ps * ps)
-    return (patches @ w["conv1.weight"].reshape(cfg.width, -1).T).astype(np.float32)
+    return (patches @ w["conv1.weight"].reshape(cfg.width, -1).T).astype(F32)
 
 
 def vit_forward_single(img, w, cfg: VitConfig, pos=None, ex_attn=None, aliased_feats=False):
@@ -240,7 +259,7 @@ def vit_forward_single(img, w, cfg: VitConfig, pos=None, ex_attn=None, aliased_f
         pos = resize_pos_embed(w["positional_embedding"], g)         # :426-435
     x = x + pos
     x = layer_norm(x, w["ln_pre.weight"], w["ln_pre.bias"])          # :438
-    x = x.astype(np.float32)
+    x = x.astype(F32)
     x_ori = None
     attn_weights, all_feats = [], []
     for i in range(L):
@@ -249,7 +268,7 @@ def vit_forward_single(img, w, cfg: VitConfig, pos=None, ex_attn=None, aliased_f
             o, a = mha_block_attention(layer_norm(x, w[p + "ln_1.weight"], w[p + "ln_1.bias"]), p, w, cfg)
             x = x + o
             x = x + mlp(layer_norm(x, w[p + "ln_2.weight"], w[p + "ln_2.bias"]), p, w)
-            x = x.astype(np.float32)
+            x = x.astype(F32)
             feat = x
         else:
             src = x if x_ori is None else x_ori                      # :323 vs :315
@@ -257,10 +276,10 @@ def vit_forward_single(img, w, cfg: VitConfig, pos=None, ex_attn=None, aliased_f
                 layer_norm(src, w[p + "ln_1.weight"], w[p + "ln_1.bias"]), p, w, cfg, ex_attn)
             x_ori = src + x_ori_res                                  # :317 / :326
             if aliased_feats and i > first_surgery:
-                all_feats[i - 1] = x_ori.astype(np.float32).copy()   # Q4: the previous entry saw this in-place add
+                all_feats[i - 1] = x_ori.astype(F32).copy()   # Q4: the previous entry saw this in-place add
             x_ori = x_ori + mlp(layer_norm(x_ori, w[p + "ln_2.weight"], w[p + "ln_2.bias"]), p, w)
-            x_ori = x_ori.astype(np.float32)
-            x = (x + x_res).astype(np.float32)                       # :319 / :329  (no FFN on the new path)
+            x_ori = x_ori.astype(F32)
+            x = (x + x_res).astype(F32)                       # :319 / :329  (no FFN on the new path)
             feat = x_ori
         attn_weights.append(a)
         all_feats.append(feat.copy())
@@ -268,9 +287,9 @@ def vit_forward_single(img, w, cfg: VitConfig, pos=None, ex_attn=None, aliased_f
     if x_ori is not None:
         x[0] = x_ori[0]                                              # :442
         if aliased_feats and first_surgery >= 1:
-            all_feats[first_surgery - 1] = x.astype(np.float32).copy()   # Q4: aliases the new-path x, incl. the cls swap
+            all_feats[first_surgery - 1] = x.astype(F32).copy()   # Q4: aliases the new-path x, incl. the cls swap
     x = layer_norm(x, w["ln_post.weight"], w["ln_post.bias"])        # :445
-    x = (x @ w["proj"]).astype(np.float32)                           # :446
+    x = (x @ w["proj"]).astype(F32)                           # :446
     return x, attn_weights, all_feats
 
 
@@ -282,7 +301,7 @@ def vit_forward(imgs, w, cfg: VitConfig, ex_feats=None, aliased_feats=False):
     ex = ex_attention(ex_feats) if ex_feats is not None else None
     xs, attns, feats = [], [], []
     for b in range(imgs.shape[0]):
-        x, a, f = vit_forward_single(np.asarray(imgs[b], np.float32), w, cfg, pos, None if ex is None else ex[b], aliased_feats)
+        x, a, f = vit_forward_single(np.asarray(imgs[b], F32), w, cfg, pos, None if ex is None else ex[b], aliased_feats)
         xs.append(x)
         attns.append(np.stack(a, 0))
         feats.append(np.stack(f, 0))
