@@ -456,6 +456,10 @@ def main(argv=None, hooks=None):
             out["verify"] = {"images": len(agree), "pixels": px, "label_agreement_mean": round(float(np.mean(agree)), 6),
                              "label_agreement_min": round(float(np.min(agree)), 6),
                              "checker": "oracle (CPU port) labels of the same images; bf16x3 vs exact fp32 differ only where a CAM lies on a uint8 / box threshold"}
+        if on_gpu and world == 1:
+            # the guard a user runs on his own weights (ExCEL_model.check_numerics): the default bf16x3 mode against exact fp32 on four of the
+            # benchmark's images - CAM max-abs difference (gate 1e-3; infer_lam falls back to exact fp32 above 5e-4)
+            out["numerics_check"] = model.check_numerics(batches[0][0][:4], fallback=False)
         if on_gpu and world == 1 and args.ragged_images > 0:
             out["harness_ragged"] = harness_ragged(model, device, n_images=args.ragged_images, batch=B)
         print(json.dumps(out), flush=True)

@@ -42,6 +42,7 @@ struct GemmBfArgs {
     int dbg;                     // dev only: bit0 = skip MFMA/LDS-read work, bit1 = skip the staging loads after the first tile
     int batch;                   // >= 1: blockIdx.y; operands advance by sA / sB bf16 elements, C by sC floats, Cs by sCs bf16 elements
     long long sA, sB, sC, sCs;
+    int mix_tall, mix_short;     // set by the launcher (mixed-height 320x256 / 256x256 row tiles, gemm_bf16x3.hip); 0 = uniform tiles
 };
 int excel_launch_gemm_bf16x3(const GemmBfArgs& p, hipStream_t stream);
 int excel_launch_split_bf16(const float* in, void* out, long long R, int K, hipStream_t st);

@@ -94,7 +94,7 @@ __device__ __forceinline__ void bf_epilogue(const GemmBfArgs& p, const f32x16 (&
 // float4 loads, fp32 rows are written as full 256-B segments, split-bf16 rows as 8-byte hi/lo groups.
 template <int OUT_MODE, int TI>
 __device__ __forceinline__ void bf_epilogue_lds(const GemmBfArgs& p, const f32x16 (&acc)[TI][2], int m0, int n0, int wm, int wn,
-                                                int lane, float* scratch) {
+                                                int lane, float* scratch, int nti = TI) {
     const int r = lane & 31;
     const int c4 = (lane & 15) * 4;
     const int col = n0 + wn * 64 + c4;
@@ -111,6 +111,7 @@ __device__ __forceinline__ void bf_epilogue_lds(const GemmBfArgs& p, const f32x1
     }
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
+        if (i >= nti) break;                                  // (mixed-height tiles: a short tile has nti = TI - 1 row tiles per wave)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -119,7 +120,7 @@ __device__ __forceinline__ void bf_epilogue_lds(const GemmBfArgs& p, const f32x1
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int row_l = it * 4 + (lane >> 4);
-            const int row = m0 + wm * (TI * 32) + i * 32 + row_l;
+            const int row = m0 + wm * (nti * 32) + i * 32 + row_l;
             f32x4 v = *reinterpret_cast<const f32x4*>(&scratch[row_l * 68 + c4]);
             if (row >= p.M || !col_ok) continue;
             v += bias4;
@@ -161,7 +162,12 @@ __device__ __forceinline__ void bf_epilogue_lds(const GemmBfArgs& p, const f32x1
 //   <2,2,2,2>: 128x128, 64 KB LDS, 2 workgroups/CU                      (small / batched problems)
 //   <4,2,2,3>: 256x128, 144 KB, 8 waves, counted vmcnt ring             (N = 768 GEMMs: keeps 594 tiles for 256 CUs)
 //   <2,4,4,2>: 256x256, 128 KB, 8 waves x (128x64), half the bytes/flop of 128x128   (QKV, fc1)
-template <int WM, int WN, int TI, int NSTAGE>
+// MIX (320 x 256 instance only): MIXED-HEIGHT row tiles.  M = 25 120 rows are 785 blocks of 32; uniform 320-row tiles give every CU
+// 3 (QKV: 9 column tiles) or 4 (fc1: 12) tiles of 10 blocks = 30 / 40 where 27.6 / 36.8 would do (92 % of the rounds filled).  With
+// `mix_tall` row tiles of 320 rows followed by `mix_short` row tiles of 256 rows (the same workgroup shape; a short tile's waves run 4
+// of their 5 row tiles) the same number of tiles covers M with less padding: a CU gets 2 tall + 1 short = 28 (3 + 1 = 38).  Tall tiles
+// are dispatched first inside every XCD's chunk (longest first), the short ones level the last round.
+template <int WM, int WN, int TI, int NSTAGE, bool MIX = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16x3_kernel(GemmBfArgs p) {
     constexpr int BM = WM * TI * 32, BN = WN * 64;
     constexpr int STAGE = (BM + BN) * TROW;                  // u16 elements per stage: A rows then B rows
@@ -178,9 +184,32 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16x3_kernel(GemmBfArgs
     const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, kh = lane >> 5;
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int tm = id / tiles_n, tn = id % tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
+    int m0, n0, nti = TI;
+    if (MIX) {
+        // XCD x (hardware id & 7) owns a contiguous run of the tall tiles and a contiguous run of the short tiles, tall ones first
+        const int T = p.mix_tall * tiles_n, A = (p.mix_tall + p.mix_short) * tiles_n;
+        const int x = blockIdx.x & 7, loc = blockIdx.x >> 3;
+        const int tq = T >> 3, tr = T & 7, aq = A >> 3, ar = A & 7;
+        const int tbase = x * tq + min(x, tr), tcount = tq + (x < tr ? 1 : 0);
+        const int abase = x * aq + min(x, ar);
+        int rt, tn;
+        if (loc < tcount) {
+            const int k = tbase + loc;
+            rt = k / tiles_n; tn = k - rt * tiles_n;
+            m0 = rt * BM;
+        } else {
+            const int k = (abase - tbase) + (loc - tcount);          // index among the short tiles
+            rt = k / tiles_n; tn = k - rt * tiles_n;
+            m0 = p.mix_tall * BM + rt * (BM - 64);
+            nti = TI - 1;
+        }
+        n0 = tn * BN;
+    } else {
+        const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+        const int tm = id / tiles_n, tn = id % tiles_n;
+        m0 = tm * BM; n0 = tn * BN;
+    }
+    const int wm_rows = nti * 32;                            // rows per wave row of this tile
     if (p.batch > 1) {      // batched problems (blockIdx.y): advance the operand / output bases (block-uniform)
         const long long z = blockIdx.y;
         p.A += z * p.sA; p.B += z * p.sB; p.C += z * p.sC; p.Cs += z * p.sCs;
@@ -262,15 +291,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16x3_kernel(GemmBfArgs
                 // are streamed one row tile ahead instead of all at once, and the scheduler may not hoist them
                 bf16x8 ah[2], al[2];
                 {
-                    const u16* rowp = as + (wm * (TI * 32) + r) * TROW;
+                    const u16* rowp = as + (wm * wm_rows + r) * TROW;
                     ah[0] = *reinterpret_cast<const bf16x8*>(rowp + ch);
                     al[0] = *reinterpret_cast<const bf16x8*>(rowp + cl);
                 }
 #pragma unroll
                 for (int i = 0; i < TI; ++i) {
                     if (kt_next >= 0 && s2 * TI + i < PER_WAVE) issue_piece(kt_next, stage ^ 1, s2 * TI + i);
-                    if (i + 1 < TI) {
-                        const u16* rowp = as + (wm * (TI * 32) + (i + 1) * 32 + r) * TROW;
+                    if (MIX && i >= nti) continue;                  // short tile: this wave has TI - 1 row tiles (the DMA piece above still goes out)
+                    if (i + 1 < TI && (!MIX || i + 1 < nti)) {
+                        const u16* rowp = as + (wm * wm_rows + (i + 1) * 32 + r) * TROW;
                         ah[(i + 1) & 1] = *reinterpret_cast<const bf16x8*>(rowp + ch);
                         al[(i + 1) & 1] = *reinterpret_cast<const bf16x8*>(rowp + cl);
                     }
@@ -343,9 +373,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16x3_kernel(GemmBfArgs
     if (vec) {
         // every wave is past the last barrier of the k-loop: the staging ring is free -> per-wave transpose scratch
         float* scratch = reinterpret_cast<float*>(smem) + wave * (32 * 68);
-        if (p.out_mode == GEMM_OUT_SPLIT_BF16) bf_epilogue_lds<GEMM_OUT_SPLIT_BF16, TI>(p, acc, m0, n0, wm, wn, lane, scratch);
-        else if (p.out_mode == GEMM_OUT_QKV_HEADMAJOR) bf_epilogue_lds<GEMM_OUT_QKV_HEADMAJOR, TI>(p, acc, m0, n0, wm, wn, lane, scratch);
-        else bf_epilogue_lds<GEMM_OUT_PLAIN, TI>(p, acc, m0, n0, wm, wn, lane, scratch);
+        if (p.out_mode == GEMM_OUT_SPLIT_BF16) bf_epilogue_lds<GEMM_OUT_SPLIT_BF16, TI>(p, acc, m0, n0, wm, wn, lane, scratch, nti);
+        else if (p.out_mode == GEMM_OUT_QKV_HEADMAJOR) bf_epilogue_lds<GEMM_OUT_QKV_HEADMAJOR, TI>(p, acc, m0, n0, wm, wn, lane, scratch, nti);
+        else bf_epilogue_lds<GEMM_OUT_PLAIN, TI>(p, acc, m0, n0, wm, wn, lane, scratch, nti);
     } else {
         if (p.out_mode == GEMM_OUT_SPLIT_BF16) bf_epilogue<GEMM_OUT_SPLIT_BF16, TI>(p, acc, m0, n0, wm, wn, lane);
         else if (p.out_mode == GEMM_OUT_QKV_HEADMAJOR) bf_epilogue<GEMM_OUT_QKV_HEADMAJOR, TI>(p, acc, m0, n0, wm, wn, lane);
@@ -427,8 +457,10 @@ int excel_launch_gemm_bf16x3(const GemmBfArgs& p_in, hipStream_t stream) {
     EXCEL_CHECK_ARG((((uintptr_t)p.A | (uintptr_t)p.B) & 15) == 0, "gemm_bf16x3: operands must be 16-byte aligned");
 #ifdef EXCEL_DEV
     static const char* force = getenv("EXCEL_BF_TILE");      // dev knob: "128" | "256x128" | "256" | "320"
+    static const bool force_uniform = getenv("EXCEL_BF_UNIFORM") != nullptr;   // dev knob: no mixed-height tiles
 #else
     const char* const force = nullptr;
+    const bool force_uniform = false;
 #endif
     int kind;   // 0: 128x128, 1: 256x128, 2: 256x256, 3: 320x256
     if (force) kind = !strcmp(force, "320") ? 3 : !strcmp(force, "256") ? 2 : (!strcmp(force, "256x128") ? 1 : 0);
@@ -455,6 +487,29 @@ int excel_launch_gemm_bf16x3(const GemmBfArgs& p_in, hipStream_t stream) {
         }
     }
     const int nb = p.batch > 1 ? p.batch : 1;
+    if (kind == 3 && nb == 1 && !force_uniform) {
+        // mixed-height row tiles (kernel header): R = rounds of the uniform 320-row tiling; nt = the row tiles that fit into R rounds;
+        // `tall` of them must be 320 rows high to cover M, the rest can be 256.  Worth it when the tall tiles leave room in the last round
+        // for short ones (tall * tiles_n <= (R - 1) * CUs): then no CU gets R tall tiles.
+        static int n_cu2 = 0;
+        if (!n_cu2) {
+            int dev = 0; hipDeviceProp_t prop;
+            n_cu2 = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+        }
+        const int tiles_n = cdiv(p.N, 256), units = cdiv(p.M, 32);
+        const int R = cdiv(cdiv(p.M, 320) * tiles_n, n_cu2);
+        const int nt = (R * n_cu2) / tiles_n;
+        int tall = (units - 8 * nt + 1) / 2;
+        if (tall < 0) tall = 0;
+        int shrt = nt - tall;
+        while (shrt > 0 && 10 * tall + 8 * (shrt - 1) >= units) --shrt;      // no more row tiles than M needs
+        if (R >= 2 && shrt > 0 && tall <= nt && 10 * tall + 8 * shrt >= units && tall * tiles_n <= (R - 1) * n_cu2) {
+            p.mix_tall = tall; p.mix_short = shrt;
+            hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 4, 5, 2, true>), dim3((tall + shrt) * tiles_n, 1), dim3(512), 0, stream, p);
+            EXCEL_CHECK_LAUNCH("gemm_bf16x3");
+            return EXCEL_OK;
+        }
+    }
     if (kind == 3) {
         hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 4, 5, 2>), dim3(cdiv(p.M, 320) * cdiv(p.N, 256), nb), dim3(512), 0, stream, p);
     } else if (kind == 2) {

@@ -116,3 +116,28 @@ class ExCEL_model:
         return seg, attn_fts, attr_maps_raw, attn_weights, attn_pred
 
     __call__ = forward
+
+    def check_numerics(self, img, tol=5e-4, fallback=True):
+        """Guard of the default "bf16x3" matrix-core mode on the caller's OWN weights and images.  bf16x3 carries 16 mantissa bits per
+        operand; measured against a float64 run of the oracle its CAM error is ~14x that of fp32 arithmetic.  On benign networks
+        that is 1e-5 (gate 1e-3); on an ill-conditioned network (massive-activation channels + near-one-hot attention rows:
+        tests/test_gpu_ops.py::test_vit_b16_448_clip_like_outlier_net) fp32 itself sits at 2e-4 and bf16x3 exceeds the gate.  This
+        runs ViT + CAM of `img` [b,3,S,S] in the current mode and in exact fp32 ("f32") and compares the attr maps - the quantity the
+        gate is stated on.  -> {"max_abs_diff", "tol", "mode_before", "mode_after"}; with `fallback`, a difference above `tol` (half
+        the gate by default) switches this model to exact fp32 for everything that follows."""
+        h = self.encoder.visual.handle()
+        before = h.gemm_mode()
+        if before == "f32":
+            return {"max_abs_diff": 0.0, "tol": tol, "mode_before": before, "mode_after": before}
+        fast = self.forward(img)[2].clone()
+        h.set_gemm_mode("f32")
+        try:
+            exact = self.forward(img)[2]
+            diff = float((fast - exact).abs().max())
+        finally:
+            h.set_gemm_mode(before)
+        after = before
+        if not (diff <= tol) and fallback:              # (NaN compares false: falls back too)
+            h.set_gemm_mode("f32")
+            after = "f32"
+        return {"max_abs_diff": diff, "tol": tol, "mode_before": before, "mode_after": after}

@@ -71,6 +71,10 @@ def get_parser():
     p.add_argument("--clip_root", default=None, type=str, help="directory holding the published CLIP archive (ViT-B-16.pt); default $EXCEL_CLIP_ROOT, ~/.cache/clip")
     p.add_argument("--bpe_path", default=None, type=str, help="CLIP's bpe_simple_vocab_16e6.txt.gz (default $EXCEL_BPE_VOCAB)")
     p.add_argument("--gemm_mode", default=None, type=str, help="bf16x3 (default) | f32")
+    p.add_argument("--gemm_check", default=True, type=_bool,
+                   help="before the loop, run the first few images in the default bf16x3 mode AND in exact fp32 and compare the CAMs; above "
+                        "--gemm_check_tol the run falls back to exact fp32 (ill-conditioned weights; ExCEL_model.check_numerics)")
+    p.add_argument("--gemm_check_tol", default=5e-4, type=float)
     p.add_argument("--cpu_affinity", default="auto", choices=["auto", "off"],
                    help="auto: with several ranks on the node every rank pins itself (decode pool included) to its own share of the host cores")
     p.add_argument("--json_out", default=None, type=str, help="rank 0 writes a one-line JSON record of the run here (rate, ranks, per-rank mass)")
@@ -317,6 +321,38 @@ def crf_proc(args, rank=0, world=1, device="cuda"):
     return evaluate.scores_from_hist(total), total                                          # :233
 
 
+def _gemm_self_check(model, dataset, idx, args, device, world):
+    """ExCEL_model.check_numerics on the first (up to 4) samples of this rank's shard, resized like the loop resizes them (:74).  With
+    several ranks the verdict is shared (max over ranks of the difference): every rank runs the same mode."""
+    from .. import ops
+    S = args.resize_size
+    take = [int(i) for i in idx[:4]]
+    first = dataset[take[0]][1]
+    if first.dtype == np.uint8:                                                             # decoded images of their own sizes
+        from ..datasets.loader import pack_samples
+        rb = pack_samples([dataset[i] for i in take])
+        inputs = ops.normalize_resize_u8_ragged(rb.images.to(device), ops.RaggedPlan(rb.hw, device), S)
+    else:
+        _, imgs, _, _ = dataset.batch(take)
+        inputs = torch.from_numpy(imgs).to(device)
+        if inputs.shape[-2:] != (S, S):
+            inputs = ops.bilinear_resize(inputs, S, S, align_corners=False)
+    h = model.encoder.visual.handle()
+    res = model.check_numerics(inputs, tol=float(getattr(args, "gemm_check_tol", 5e-4)), fallback=False)
+    diff = res["max_abs_diff"]
+    if world > 1 and dist.is_initialized():
+        t = torch.tensor([diff if diff == diff else float("inf")], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        diff = float(t.item())
+    if res["mode_before"] != "f32" and not (diff <= res["tol"]):
+        h.set_gemm_mode("f32")
+        logging.warning(f"gemm self-check: CAMs of the bf16x3 mode differ from exact fp32 by {diff:.2e} (> {res['tol']:.1e}) on these "
+                        "weights: the run continues in exact fp32 (gemm_mode f32)")
+    else:
+        logging.info(f"gemm self-check: bf16x3 vs exact fp32 CAM max-abs difference {diff:.2e} (tolerance {res['tol']:.1e})")
+    return {"max_abs_diff": diff, "tol": res["tol"], "mode_before": res["mode_before"], "mode_after": h.gemm_mode()}
+
+
 def validate(args=None, dataset=None, pipe=None):
     """tools/infer_lam.py:130-176.  `dataset` / `pipe` are injection points for the multi-rank control-flow tests (a stub pipeline on
     CPU tensors over gloo): with `pipe` given no model is built and the device is pipe.device; the product path passes neither."""
@@ -368,6 +404,8 @@ def validate(args=None, dataset=None, pipe=None):
                             gemm_mode=getattr(args, "gemm_mode", None), **resolve_model_inputs(args))
     par = PAR(num_iter=20, dilations=[1, 2, 4, 8, 12, 24])                                  # :168
     idx = shard_indices(len(dataset), rank, world)                                          # :166
+    if model is not None and getattr(args, "gemm_check", True) and len(idx) > 0:
+        validate.last_gemm_check = _gemm_self_check(model, dataset, idx, args, device, world)
     hist, nimg, secs = build_validation(model, par, dataset, idx, device, args, pipe=pipe)
     validate.last_model = model                                                             # handle for callers / tests
     per_rank, total = gather_hists(hist)
