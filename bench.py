@@ -291,7 +291,7 @@ def main(argv=None, hooks=None):
     pipe.reset()
     timing = on_gpu and not args.no_kernel_timing
     gmode = model.encoder.visual.handle().gemm_mode() if on_gpu else "stub"
-    dom_cat = "gemm_bf16x3" if gmode == "bf16x3" else "gemm_nt"
+    dom_cat = "gemm_bf16x3" if gmode in ("bf16x3", "f16x3") else "gemm_nt"
     if timing:
         # inside the timed region the two roofline kernels are bracketed with HIP events on their launch stream, every 4th
         # launch of each (an event pair costs ~10 us of GPU idle: all ~290 launches/step would take 5 % off `value`)
@@ -337,7 +337,7 @@ def main(argv=None, hooks=None):
             "metric": "images/sec (CAM+PAR refine, 448x448)", "value": round(value, 3), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if gmode == "f32" else "bf16x3 (fp32 as bf16 hi+lo, fp32 accumulate)",
+            "dtype": {"f32": "f32", "f16x3": "f16x3 (fp32 as IEEE-half hi+lo, fp32 accumulate)"}.get(gmode, "bf16x3 (fp32 as bf16 hi+lo, fp32 accumulate)"),
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: VOC-shaped 448x448, batch=32/GPU, ViT-B/16 surgery + patch-text CAM "
                                    "(T=45,F=20) + affinity random walk + PAR(20 it, 6 dilations) + argmax + confusion, "
@@ -376,10 +376,11 @@ def main(argv=None, hooks=None):
                     traffic_source = src
                 except Exception:
                     traffic = par_traffic = traffic_source = None
-            if mode == "bf16x3":
+            if mode in ("bf16x3", "f16x3"):
                 peak = BF16_MFMA_PEAK_TF
                 kname = ("gemm_bf16x3_kernel (fp32 operands as bf16 hi+lo planes, 3 x v_mfma_f32_32x32x16_bf16 per product; "
-                         "all nn.Linear / patch-embed / proj GEMMs)")
+                         "all nn.Linear / patch-embed / proj GEMMs)") if mode == "bf16x3" else (
+                         "gemm_bf16x3_kernel, IEEE-half instance (fp32 operands as f16 hi+lo planes, 3 x v_mfma_f32_32x32x16_f16 per product)")
             else:
                 peak = F32_MATRIX_PEAK_TF
                 kname = "gemm_f32_kernel<NT> (fp32 MFMA 32x32x2; all nn.Linear / patch-embed / proj / sim GEMMs)"
@@ -390,9 +391,9 @@ def main(argv=None, hooks=None):
                 "launches_per_step": prof_all[cat]["launches"] // steps,
                 "algorithmic_gflop_per_image": round(prof_all[cat]["work"] / steps / B / 1e9, 3),
                 "survey_gflop_per_image": round(GEMM_GFLOP_PER_IMG, 3),
-                "algorithmic_bytes_per_launch": int(gemm_bytes_per_step(B)[0] / gemm_bytes_per_step(B)[1]) if mode == "bf16x3" else None,
+                "algorithmic_bytes_per_launch": int(gemm_bytes_per_step(B)[0] / gemm_bytes_per_step(B)[1]) if mode != "f32" else None,
             }
-            if mode == "bf16x3":
+            if mode != "f32":
                 # the kernel issues 3 bf16 MFMAs per algorithmic product: matrix-pipe utilisation is 3x the algorithmic fraction
                 out["roofline"]["mfma_issue_frac"] = round(3 * achieved / peak, 4)
                 out["roofline"]["fp32_equivalent_peak"] = round(peak / 3, 1)
@@ -419,7 +420,7 @@ def main(argv=None, hooks=None):
                                                   "token_norm", "cam_epilogue", "cam_proj", "cam_fused") if k in prof_all)
             if vit_ms > 0:
                 tf = VIT_CAM_GFLOP_PER_IMG * 1e9 * B * steps / (vit_ms * 1e-3) / 1e12
-                vpeak = BF16_MFMA_PEAK_TF if mode == "bf16x3" else F32_MATRIX_PEAK_TF
+                vpeak = BF16_MFMA_PEAK_TF if mode != "f32" else F32_MATRIX_PEAK_TF
                 out["roofline_vit_cam"] = {"bound": "mfma", "achieved": round(tf, 3), "peak": vpeak, "unit": "TFLOP/s",
                                            "frac": round(tf / vpeak, 4),
                                            "note": "181.2 GFLOP/img (reference algorithm) over all ViT+CAM kernel time"}
@@ -429,12 +430,12 @@ def main(argv=None, hooks=None):
             if cam_ms > 0:
                 cam_flops = sum(prof_all[k]["work"] for k in ("cam_proj", "cam_fused") if k in prof_all)
                 tf = cam_flops / (cam_ms * 1e-3) / 1e12
-                vpeak = BF16_MFMA_PEAK_TF if mode == "bf16x3" else F32_MATRIX_PEAK_TF
+                vpeak = BF16_MFMA_PEAK_TF if mode != "f32" else F32_MATRIX_PEAK_TF
                 out["roofline_sim_gemm"] = {
                     "kernel": "final projection GEMM [B*N,768]x[768,512] + the patch-text CAM kernels (token-axis norm pass, patch x text similarity "
                               "tiles on the matrix core with class-prior / redundancy epilogue, min-max finish: three whole-chip launches)",
                     "bound": "mfma", "achieved": round(tf, 3), "peak": vpeak, "unit": "TFLOP/s", "frac": round(tf / vpeak, 4),
-                    "mfma_issue_frac": round((3 if mode == "bf16x3" else 1) * tf / vpeak, 4),
+                    "mfma_issue_frac": round((3 if mode != "f32" else 1) * tf / vpeak, 4),
                     "algorithmic_gflop_per_image": round(cam_flops / steps / B / 1e9, 4), "survey_gflop_per_image": 0.653,
                     "ms_per_step": round(cam_ms / steps, 4),
                     "note": "bound: 97 % of these flops are the projection GEMM (198 tiles on 256 CUs: 77 % of one round); the similarity part is HBM / "

@@ -73,6 +73,8 @@ SIGNATURES = {
                              c_ll, c_ll, c_ll, c_ll, c_f]),
     "excel_split_bf16": (c_i, [c_f, c_f, c_ll, c_i, c_f]),
     "excel_gemm_bf16x3": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
+    "excel_split_f16": (c_i, [c_f, c_f, c_ll, c_i, c_f]),
+    "excel_gemm_f16x3": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
     "excel_layernorm": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, C.c_float, c_f]),
     "excel_vit_create": (c_i, [C.POINTER(VitConfig), C.POINTER(VitWeights), C.POINTER(C.c_void_p)]),
     "excel_vit_destroy": (None, [C.c_void_p]),

@@ -8,7 +8,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libexcel_hip.so")
 SOURCES = ["gemm.hip", "gemm_bf16x3.hip", "norm.hip", "attn.hip", "attn_strip.hip", "cam.hip", "aff.hip", "par.hip", "attr.hip", "lvc.hip", "decoder.hip", "train.hip", "crf.hip", "abi.hip"]
-HEADERS = ["common.h", "excel_internal.h", "decoder_internal.h", os.path.join("..", "..", "include", "excel_hip.h")]
+# the translation units that depend on the 16-bit type of the split operand planes are compiled twice: bf16 (namespace excel_bf16) and,
+# with -DEXCEL_SPLIT_F16, IEEE half (namespace excel_f16, objects *_f16.o) - the "f16x3" matrix-core mode (common.h, excel_internal.h)
+SPLIT_SOURCES = ["gemm.hip", "gemm_bf16x3.hip", "norm.hip", "attn.hip", "attn_strip.hip", "cam.hip"]
+HEADERS = ["common.h", "excel_internal.h", "excel_split_api.inc", "decoder_internal.h", os.path.join("..", "..", "include", "excel_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
          # fully unroll the big register-tile epilogues (a partially unrolled loop indexes the accumulator array
          # dynamically and sends it to scratch)
@@ -28,7 +31,7 @@ def source_id(dev=None):
     `.so` whose time stamps happen to look fresh cannot be benchmarked unnoticed."""
     import hashlib
     h = hashlib.sha256()
-    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc")))
     for f in files:
         h.update(f.encode())
         h.update(open(os.path.join(CSRC, f), "rb").read())
@@ -74,13 +77,18 @@ def build(force=False, verbose=True):
             stale = stale or not os.path.exists(idstamp) or open(idstamp).read() != sid
         if stale:
             jobs.append([hipcc] + flags + extra + ["-c", src, "-o", obj])
+        if s in SPLIT_SOURCES:
+            obj16 = os.path.join(CSRC, s.replace(".hip", "_f16.o"))
+            objs.append(obj16)
+            if force or _stale(obj16, [src] + hdrs):
+                jobs.append([hipcc] + flags + ["-DEXCEL_SPLIT_F16", "-c", src, "-o", obj16])
     if jobs:
         with cf.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             for cmd, res in zip(jobs, ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs)):
                 if res.returncode != 0:
                     raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), res.stderr))
                 if verbose:
-                    print("[excel_amd.build] compiled", os.path.basename(cmd[-3]))
+                    print("[excel_amd.build] compiled", os.path.basename(cmd[-1]))
     if force or jobs or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         res = subprocess.run(cmd, capture_output=True, text=True)

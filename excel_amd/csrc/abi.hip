@@ -179,6 +179,19 @@ extern "C" int excel_gemm_bf16x3(const void* A_split, const void* W_split, float
     return excel_launch_gemm_bf16x3(g, ST(stream));
 }
 
+extern "C" int excel_split_f16(const float* in, void* out, long long rows, int K, void* stream) {
+    EXCEL_CHECK_ARG(in && out && rows > 0 && K > 0, "split_f16: bad argument");
+    return excel_f16::excel_launch_split_bf16(in, out, rows, K, ST(stream));
+}
+
+extern "C" int excel_gemm_f16x3(const void* A_split, const void* W_split, float* C, const float* bias, const float* residual,
+                                int M, int N, int K, int act, int split_out, void* stream) {
+    EXCEL_CHECK_ARG(A_split && W_split && C, "gemm_f16x3: null argument");
+    GemmBfArgs g = gemm_bf_args(A_split, (const unsigned short*)W_split, C, C, bias, residual, M, N, K, N, N, act,
+                                split_out ? GEMM_OUT_SPLIT_BF16 : GEMM_OUT_PLAIN);
+    return excel_f16::excel_launch_gemm_bf16x3(g, ST(stream));
+}
+
 extern "C" int excel_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int D, float eps, void* stream) {
     return excel_launch_layernorm(x, nullptr, 1, w, b, y, rows, D, eps, ST(stream));
 }
@@ -191,28 +204,36 @@ struct excel_vit {
     std::vector<excel_vit_block_weights> blocks;
     float* projT = nullptr;             // [C, D]
     std::map<int, float*> pos_cache;    // g -> [1+g*g, D]
-    int gemm_mode = 0;                  // 0: exact fp32 MFMA, 1: bf16x3 (split bf16, 3 MFMAs per product)
+    int gemm_mode = 0;                  // 0: exact fp32 MFMA, 1: bf16x3 (split bf16, 3 MFMAs per product), 2: f16x3 (split IEEE half)
+    int split_type = 0;                 // what the split weights hold: 0 nothing yet, 1 bf16 planes, 2 f16 planes
     unsigned short* split_arena = nullptr;   // all split weights in one allocation
     std::vector<SplitBlockW> sblocks;
     unsigned short *s_conv1 = nullptr, *s_projT = nullptr;
 };
 
-static int vit_prepare_split_weights(excel_vit* h) {
-    if (h->split_arena) return EXCEL_OK;
+static int vit_prepare_split_weights(excel_vit* h, int type) {
+    if (h->split_arena && h->split_type == type) return EXCEL_OK;
     const excel_vit_config& c = h->cfg;
     const size_t D = c.width, Kc = (size_t)3 * c.patch * c.patch;
     const size_t per_block = 3 * D * D + D * D + 4 * D * D + 4 * D * D;       // floats == split bytes / 4
     const size_t total = per_block * c.layers + D * Kc + (size_t)c.out_dim * D;
-    float* arena = nullptr;
-    if (hipMalloc(&arena, total * sizeof(float)) != hipSuccess) {
-        excel_set_error("excel_vit: hipMalloc(split weights) failed");
-        return EXCEL_ERR_ALLOC;
+    float* arena = (float*)h->split_arena;
+    if (!arena) {
+        if (hipMalloc(&arena, total * sizeof(float)) != hipSuccess) {
+            excel_set_error("excel_vit: hipMalloc(split weights) failed");
+            return EXCEL_ERR_ALLOC;
+        }
+    } else if (hipDeviceSynchronize() != hipSuccess) {      // re-splitting for the other type: nothing may still read the old planes
+        excel_set_error("excel_vit: device synchronize failed");
+        return EXCEL_ERR_LAUNCH;
     }
     h->split_arena = (unsigned short*)arena;
+    h->split_type = type;
     float* cur = arena;
     auto put = [&](const float* src, size_t rows, size_t K) -> unsigned short* {
         unsigned short* dst = (unsigned short*)cur;
-        excel_launch_split_bf16(src, dst, (long long)rows, (int)K, 0);
+        if (type == 2) excel_f16::excel_launch_split_bf16(src, dst, (long long)rows, (int)K, 0);
+        else excel_bf16::excel_launch_split_bf16(src, dst, (long long)rows, (int)K, 0);
         cur += rows * K;
         return dst;
     };
@@ -234,11 +255,11 @@ static int vit_prepare_split_weights(excel_vit* h) {
 }
 
 extern "C" int excel_vit_set_gemm_mode(excel_vit_t h, int mode) {
-    EXCEL_CHECK_ARG(h && (mode == 0 || mode == 1), "excel_vit_set_gemm_mode: mode must be 0 (f32) or 1 (bf16x3)");
-    if (mode == 1) {
+    EXCEL_CHECK_ARG(h && (mode == 0 || mode == 1 || mode == 2), "excel_vit_set_gemm_mode: mode must be 0 (f32), 1 (bf16x3) or 2 (f16x3)");
+    if (mode >= 1) {
         EXCEL_CHECK_ARG((h->cfg.width % 32) == 0 && ((3 * h->cfg.patch * h->cfg.patch) % 32) == 0,
-                        "bf16x3 mode needs width and 3*patch^2 to be multiples of 32");
-        TRY(vit_prepare_split_weights(h));
+                        "the split-plane modes need width and 3*patch^2 to be multiples of 32");
+        TRY(vit_prepare_split_weights(h, mode));
     }
     h->gemm_mode = mode;
     return EXCEL_OK;
@@ -271,9 +292,9 @@ extern "C" int excel_vit_create(const excel_vit_config* cfg, const excel_vit_wei
         return EXCEL_ERR_LAUNCH;
     }
     *out = h;
-    const char* mode = getenv("EXCEL_GEMM_MODE");     // default numerics of new handles: "f32" | "bf16x3"
-    if (mode && !strcmp(mode, "bf16x3") && (cfg->width % 32) == 0 && ((3 * cfg->patch * cfg->patch) % 32) == 0) {
-        int rc = excel_vit_set_gemm_mode(h, 1);
+    const char* mode = getenv("EXCEL_GEMM_MODE");     // default numerics of new handles: "f32" | "bf16x3" | "f16x3"
+    if (mode && (!strcmp(mode, "bf16x3") || !strcmp(mode, "f16x3")) && (cfg->width % 32) == 0 && ((3 * cfg->patch * cfg->patch) % 32) == 0) {
+        int rc = excel_vit_set_gemm_mode(h, !strcmp(mode, "f16x3") ? 2 : 1);
         if (rc) return rc;
     }
     return EXCEL_OK;
@@ -391,176 +412,25 @@ extern "C" int excel_attn_select_mean(const float* attn, int Lw, int B, int N, i
     return excel_launch_attn_select_mean(attn, Lw, B, N, first_layer, n_layers, seg_attn, w_out, workspace, ST(stream));
 }
 
-static int vit_forward_impl(excel_vit_t h, const float* img, int B, int S, void* workspace, size_t workspace_bytes,
-                            float* image_features, float* x_raw, float* w_aff, int aff_layers, float* attn_out,
-                            int n_attn_out, float* feats_out, const float* ex_attn, int flags, void* stream) {
-    const bool aliased_feats = feats_out && (flags & EXCEL_VIT_FEATS_AS_REFERENCE);
-    EXCEL_CHECK_ARG(h && img && workspace && (image_features || x_raw), "excel_vit_forward: null argument (image_features or x_raw is required)");
-    const excel_vit_config& c = h->cfg;
-    EXCEL_CHECK_ARG(B > 0 && S > 0 && S % c.patch == 0, "excel_vit_forward: S must be a positive multiple of the patch size");
-    const int ps = c.patch, g = S / ps, P = g * g, N = P + 1, D = c.width, H = c.heads, L = c.layers, C = c.out_dim;
-    EXCEL_CHECK_ARG(n_attn_out >= 0 && n_attn_out <= L && (n_attn_out == 0 || attn_out), "excel_vit_forward: bad attn_out request");
-    EXCEL_CHECK_ARG(!w_aff || (aff_layers >= 1 && aff_layers <= L), "excel_vit_forward: bad aff_layers");
-    hipStream_t st = ST(stream);
-    VitWs ws = vit_ws_layout(c, B, S, (char*)workspace);
-    EXCEL_CHECK_ARG(workspace_bytes >= ws.total, "excel_vit_forward: workspace too small (%zu < %zu)", workspace_bytes, ws.total);
-    const int M = B * N;
-    const float eps = 1e-5f;
-    const float scale = 0.125f;   // head_dim^-0.5 with head_dim = 64 (clip_surgery_model.py:82)
-
-    // positional embedding for this grid (cached)
-    const float* pos = h->w.pos_emb;
-    if (g != c.pos_grid) {
-        auto it = h->pos_cache.find(g);
-        if (it == h->pos_cache.end()) {
-            float* buf = nullptr;
-            if (hipMalloc(&buf, sizeof(float) * (size_t)N * D) != hipSuccess) {
-                excel_set_error("excel_vit_forward: hipMalloc(pos) failed");
-                return EXCEL_ERR_ALLOC;
-            }
-            hipLaunchKernelGGL(pos_resize_kernel, dim3((unsigned)cdivl((long long)N * D, 256)), dim3(256), 0, st, h->w.pos_emb, buf, c.pos_grid, g, D);
-            EXCEL_CHECK_LAUNCH("pos_resize");
-            // one-time per grid size: the cached table may be read from OTHER streams by later calls
-            if (hipStreamSynchronize(st) != hipSuccess) {
-                excel_set_error("excel_vit_forward: pos_resize failed");
-                return EXCEL_ERR_LAUNCH;
-            }
-            it = h->pos_cache.emplace(g, buf).first;
-        }
-        pos = it->second;
-    }
-
-    const bool bf = h->gemm_mode == 1;
-    // patch embedding: im2col -> GEMM (conv1 weight is [D, 3*ps*ps] K-major) -> +cls/pos, ln_pre
-    TRY(excel_launch_im2col(img, ws.hbuf, B, S, ps, st, bf ? 1 : 0));
-    {
-        const int Kc = 3 * ps * ps;
-        if (bf) {
-            GemmBfArgs ga = gemm_bf_args(ws.hbuf, h->s_conv1, ws.ao, nullptr, nullptr, nullptr, B * P, D, Kc, D, 0, GEMM_ACT_NONE, GEMM_OUT_PLAIN);
-            TRY(excel_launch_gemm_bf16x3(ga, st));
-        } else {
-            GemmArgs ga = gemm_args(ws.hbuf, h->w.conv1_w, ws.ao, nullptr, nullptr, B * P, D, Kc, Kc, Kc, D, 0, GEMM_ACT_NONE);
-            TRY(excel_launch_gemm(ga, true, 1, st));
-        }
-    }
-    TRY(excel_launch_assemble_ln_pre(ws.ao, h->w.class_emb, pos, h->w.ln_pre_w, h->w.ln_pre_b, ws.x, B, N, D, eps, st));
-
-    // linear layer helper: C = act(A . W^T + bias) + res, A produced in the mode's operand format.
-    // rows/lda_f/ldc/ldr default to the dense [M, .] case; the last block uses them to touch only the cls rows.
-    auto linear_ex = [&](const float* A, const float* Wf, const unsigned short* Ws, const float* bias, const float* res, float* Cout,
-                         int rows, int Nout, int K, long long lda_f, int ldc, int ldr, int act, int out_mode) -> int {
-        if (bf) {
-            GemmBfArgs ga = gemm_bf_args(A, Ws, Cout, Cout, bias, res, rows, Nout, K, ldc, ldr, act, out_mode);
-            ga.lda = (int)(2 * lda_f);
-            if (out_mode == GEMM_OUT_QKV_HEADMAJOR) { ga.tokN = N; ga.heads = H; ga.hd = 64; ga.qkv_split = (unsigned short*)ws.qkvs; }
-            return excel_launch_gemm_bf16x3(ga, st);
-        }
-        GemmArgs ga = gemm_args(A, Wf, Cout, bias, res, rows, Nout, K, (int)lda_f, K, ldc, ldr, act);
-        if (out_mode == GEMM_OUT_QKV_HEADMAJOR) { ga.out_mode = GEMM_OUT_QKV_HEADMAJOR; ga.tokN = N; ga.heads = H; ga.hd = 64; }
-        return excel_launch_gemm(ga, true, 1, st);
-    };
-    auto linear = [&](const float* A, const float* Wf, const unsigned short* Ws, const float* bias, const float* res, float* Cout,
-                      int Nout, int K, int act, int out_mode) -> int {
-        return linear_ex(A, Wf, Ws, bias, res, Cout, M, Nout, K, K, Nout, Nout, act, out_mode);
-    };
-    const int mid_mode = bf ? GEMM_OUT_SPLIT_BF16 : GEMM_OUT_PLAIN;   // format of GEMM->GEMM intermediates (MLP hidden)
-    const SplitBlockW nosplit{nullptr, nullptr, nullptr, nullptr};
-
-    const int first_surgery = L - c.n_surgery;
-    for (int l = 0; l < L; ++l) {
-        const excel_vit_block_weights& bw = h->blocks[l];
-        const SplitBlockW& sw = bf ? h->sblocks[l] : nosplit;
-        const bool surgery = l >= first_surgery;
-        float* src = (surgery && l > first_surgery) ? ws.xo : ws.x;   // :315 vs :323
-        TRY(excel_launch_layernorm(src, nullptr, 1, bw.ln1_w, bw.ln1_b, ws.y, M, D, eps, st, bf));
-        TRY(linear(ws.y, bw.in_proj_w, sw.in_proj, bw.in_proj_b, nullptr, ws.qkvh, 3 * D, D, GEMM_ACT_NONE, GEMM_OUT_QKV_HEADMAJOR));
-        const unsigned short* qkvs = bf ? (const unsigned short*)ws.qkvs : nullptr;
-        // last block: its original-path output feeds only x[0] = x_ori[0] (:442) -> attention output, out-proj and MLP are
-        // needed for the cls rows alone (the reference computes all rows; all_feats consumers still get them on request)
-        const bool cls_only = surgery && l == L - 1 && !feats_out;
-        if (bf && surgery)   // V^T in split format: B operand of A_sum.V (the row pass reads V through the LDS transpose read)
-            TRY(excel_launch_vt_from_planes(qkvs, (unsigned short*)ws.vt, B, H, N, ws.KP, st));
-        const bool in_aff = w_aff && l >= L - aff_layers;
-        float* attn_l = (n_attn_out && l >= L - n_attn_out) ? attn_out + (size_t)(l - (L - n_attn_out)) * B * N * N : nullptr;
-        // bf16x3 mode: the strip-resident kernel (attn_strip.hip) owns the softmax statistics of q.q / k.k / v.v and of the
-        // q.k weights, so the row pass only runs its flash part (attention output of the original path)
-        const bool strip = bf && excel_attn_strip_supported(N);
-        TRY(excel_launch_attn_rowpass(ws.qkvh, ws.ao, ws.stats, B, H, N, 64, scale, (surgery && !strip) ? 4 : 1, st, bf, qkvs,
-                                      cls_only ? 1 : (1 << 30), bf ? (const unsigned short*)ws.vt : nullptr, ws.KP));
-        if (surgery || in_aff || attn_l) {
-            if (strip) {
-                TRY(excel_launch_attn_strip(qkvs, surgery ? (unsigned short*)ws.a_sum : nullptr, in_aff ? w_aff : nullptr, attn_l, B, H, N, ws.KP,
-                                            64, scale, surgery ? 1 : 0, surgery ? 1.f : 1.f / (float)H, 1.f / (float)aff_layers,
-                                            (l == L - aff_layers) ? 1 : 0, ex_attn, st));
-            } else {
-                TRY(excel_launch_attn_accum(ws.qkvh, ws.stats, surgery ? ws.a_sum : nullptr, in_aff ? w_aff : nullptr, attn_l, B, H, N,
-                                            bf ? ws.KP : ws.NP, 64, scale, surgery ? 1 : 0, surgery ? 1.f : 1.f / (float)H,
-                                            1.f / (float)aff_layers, (l == L - aff_layers) ? 1 : 0, st, qkvs, bf ? 1 : 0, ex_attn));
-            }
-        }
-        if (!surgery) {
-            TRY(linear(ws.ao, bw.out_proj_w, sw.out_proj, bw.out_proj_b, ws.x, ws.x, D, D, GEMM_ACT_NONE, GEMM_OUT_PLAIN));   // x += out_proj(attn)
-            TRY(excel_launch_layernorm(ws.x, nullptr, 1, bw.ln2_w, bw.ln2_b, ws.y, M, D, eps, st, bf));
-            TRY(linear(ws.y, bw.fc1_w, sw.fc1, bw.fc1_b, nullptr, ws.hbuf, 4 * D, D, GEMM_ACT_QUICKGELU, mid_mode));
-            TRY(linear(ws.hbuf, bw.fc2_w, sw.fc2, bw.fc2_b, ws.x, ws.x, D, 4 * D, GEMM_ACT_NONE, GEMM_OUT_PLAIN));           // x += mlp(ln_2(x))
-            if (feats_out) hipMemcpyAsync(feats_out + (size_t)l * M * D, ws.x, sizeof(float) * (size_t)M * D, hipMemcpyDeviceToDevice, st);
-        } else {
-            // new path: (A_sum . V_h) for every head, heads concatenated -> y   (:149)
-            if (bf) {
-                // one bf16x3 NT GEMM per image: y[b] (split) = A_sum[b] [N x KP] . (V^T[b] [D x KP])^T
-                GemmBfArgs ga = gemm_bf_args(ws.a_sum, (const unsigned short*)ws.vt, ws.y, ws.y, nullptr, nullptr, N, D, ws.KP, D, 0,
-                                             GEMM_ACT_NONE, GEMM_OUT_SPLIT_BF16);
-                ga.batch = B;
-                ga.sA = (long long)N * 2 * ws.KP; ga.sB = (long long)D * 2 * ws.KP; ga.sC = 0; ga.sCs = (long long)N * 2 * D;
-                TRY(excel_launch_gemm_bf16x3(ga, st));
-            } else {   // exact fp32: batched NN GEMM over (b,h)
-                GemmArgs ga = gemm_args(ws.a_sum, ws.qkvh + (size_t)2 * H * N * 64, ws.y, nullptr, nullptr, N, 64, N, ws.NP, 64, D, 0, GEMM_ACT_NONE);
-                ga.Kld = ws.NP;
-                ga.zdiv = H;
-                ga.sA = (long long)N * ws.NP; ga.sA2 = 0;
-                ga.sB = (long long)3 * H * N * 64; ga.sB2 = (long long)N * 64;
-                ga.sC = (long long)N * D; ga.sC2 = 64;
-                TRY(excel_launch_gemm(ga, false, B * H, st));
-            }
-            // original path residual first (x_ori = src + proj(attn_ori.v), :317/:326), then the new path (x += proj(.), :319/:329)
-            if (cls_only) {
-                const long long rs = (long long)N * D;       // row stride between consecutive cls tokens
-                TRY(linear_ex(ws.ao, bw.out_proj_w, sw.out_proj, bw.out_proj_b, src, ws.xo, B, D, D, rs, (int)rs, (int)rs, GEMM_ACT_NONE, GEMM_OUT_PLAIN));
-                TRY(linear(ws.y, bw.out_proj_w, sw.out_proj, bw.out_proj_b, ws.x, ws.x, D, D, GEMM_ACT_NONE, GEMM_OUT_PLAIN));
-                TRY(excel_launch_layernorm(ws.xo, nullptr, 1, bw.ln2_w, bw.ln2_b, ws.y, B, D, eps, st, bf, rs));        // compact [B, D]
-                TRY(linear_ex(ws.y, bw.fc1_w, sw.fc1, bw.fc1_b, nullptr, ws.hbuf, B, 4 * D, D, D, 4 * D, 0, GEMM_ACT_QUICKGELU, mid_mode));
-                TRY(linear_ex(ws.hbuf, bw.fc2_w, sw.fc2, bw.fc2_b, ws.xo, ws.xo, B, D, 4 * D, 4 * D, (int)rs, (int)rs, GEMM_ACT_NONE, GEMM_OUT_PLAIN));
-            } else {
-                TRY(linear(ws.ao, bw.out_proj_w, sw.out_proj, bw.out_proj_b, src, ws.xo, D, D, GEMM_ACT_NONE, GEMM_OUT_PLAIN));
-                // quirk Q4 (what the reference's decoder really sees): the previous block's all_feats entry is a view of
-                // x_ori, and this block's `x_ori += x_ori_res` (:317) mutates it before the name is re-bound (:318)
-                if (aliased_feats && l > L - c.n_surgery)
-                    hipMemcpyAsync(feats_out + (size_t)(l - 1) * M * D, ws.xo, sizeof(float) * (size_t)M * D, hipMemcpyDeviceToDevice, st);
-                TRY(linear(ws.y, bw.out_proj_w, sw.out_proj, bw.out_proj_b, ws.x, ws.x, D, D, GEMM_ACT_NONE, GEMM_OUT_PLAIN));
-                TRY(excel_launch_layernorm(ws.xo, nullptr, 1, bw.ln2_w, bw.ln2_b, ws.y, M, D, eps, st, bf));
-                TRY(linear(ws.y, bw.fc1_w, sw.fc1, bw.fc1_b, nullptr, ws.hbuf, 4 * D, D, GEMM_ACT_QUICKGELU, mid_mode));
-                TRY(linear(ws.hbuf, bw.fc2_w, sw.fc2, bw.fc2_b, ws.xo, ws.xo, D, 4 * D, GEMM_ACT_NONE, GEMM_OUT_PLAIN));         // x_ori += mlp(ln_2(x_ori))
-            }
-            if (feats_out) hipMemcpyAsync(feats_out + (size_t)l * M * D, ws.xo, sizeof(float) * (size_t)M * D, hipMemcpyDeviceToDevice, st);
-        }
-    }
-    if (aliased_feats && c.n_surgery > 0 && c.n_surgery < L) {
-        // quirk Q4: the last single-path block's entry aliases the new-path x: all `x += x_res` (:319,:329) and the cls
-        // swap (:442) land in it
-        float* dst = feats_out + (size_t)(L - c.n_surgery - 1) * M * D;
-        hipMemcpyAsync(dst, ws.x, sizeof(float) * (size_t)M * D, hipMemcpyDeviceToDevice, st);
-        hipMemcpy2DAsync(dst, sizeof(float) * (size_t)N * D, ws.xo, sizeof(float) * (size_t)N * D, sizeof(float) * D, B,
-                         hipMemcpyDeviceToDevice, st);
-    }
-    // x[0] = x_ori[0] (:442) fused into ln_post (:445), then @ proj (:446)
-    TRY(excel_launch_layernorm(ws.x, c.n_surgery > 0 ? ws.xo : nullptr, N, h->w.ln_post_w, h->w.ln_post_b, ws.y, M, D, eps, st, bf));
-    float* fraw = x_raw ? x_raw : ws.fraw;
-    g_excel_prof_gemm_cat = PROF_CAM_PROJ;                     // the CAM's projection GEMM is reported on its own (bench.py roofline_sim_gemm)
-    const int rc_proj = linear(ws.y, h->projT, h->s_projT, nullptr, nullptr, fraw, C, D, GEMM_ACT_NONE, GEMM_OUT_PLAIN);
-    g_excel_prof_gemm_cat = -1;
-    TRY(rc_proj);
-    if (image_features) TRY(excel_launch_token_axis_normalize(fraw, ws.ss, image_features, B, N, C, st));   // clip.py:353 (the fused CAM kernel does it itself)
-    return EXCEL_OK;
+#define EXCEL_VIT_FWD_ARGS excel_vit_t h, const float* img, int B, int S, void* workspace, size_t workspace_bytes, float* image_features, \
+    float* x_raw, float* w_aff, int aff_layers, float* attn_out, int n_attn_out, float* feats_out, const float* ex_attn, int flags, void* stream
+static int vit_forward_bf16(EXCEL_VIT_FWD_ARGS) {
+#include "vit_forward_body.inc"
+}
+static int vit_forward_f16(EXCEL_VIT_FWD_ARGS) {
+    // IEEE-half split planes ("f16x3"): every split-type dependent launcher of the body comes from namespace excel_f16
+    using excel_f16::excel_launch_gemm; using excel_f16::excel_launch_gemm_bf16x3; using excel_f16::excel_launch_split_bf16;
+    using excel_f16::excel_launch_vt_from_planes; using excel_f16::excel_launch_layernorm; using excel_f16::excel_launch_assemble_ln_pre;
+    using excel_f16::excel_launch_token_axis_normalize; using excel_f16::excel_launch_im2col; using excel_f16::excel_launch_attn_rowpass;
+    using excel_f16::excel_launch_attn_accum; using excel_f16::excel_attn_strip_supported; using excel_f16::excel_launch_attn_strip;
+#include "vit_forward_body.inc"
+}
+static int vit_forward_impl(EXCEL_VIT_FWD_ARGS) {
+    EXCEL_CHECK_ARG(h, "excel_vit_forward: null handle");
+    return h->gemm_mode == 2 ? vit_forward_f16(h, img, B, S, workspace, workspace_bytes, image_features, x_raw, w_aff, aff_layers, attn_out,
+                                               n_attn_out, feats_out, ex_attn, flags, stream)
+                             : vit_forward_bf16(h, img, B, S, workspace, workspace_bytes, image_features, x_raw, w_aff, aff_layers, attn_out,
+                                                n_attn_out, feats_out, ex_attn, flags, stream);
 }
 
 // ------------------------------------------------------------------------------------ CAM
@@ -599,10 +469,13 @@ extern "C" size_t excel_patch_text_cam_workspace_bytes(int B, int N, int C, int 
 extern "C" int excel_patch_text_cam(const float* x_raw, const float* text, int B, int N, int C, int T, int F, float temperature, int mode,
                                     float* out_full, float* out_slice, float* image_features, void* workspace, void* stream) {
     EXCEL_CHECK_ARG(x_raw && text && workspace && (out_full || out_slice), "patch_text_cam: null argument");
-    EXCEL_CHECK_ARG(mode == 0 || mode == 1, "patch_text_cam: mode must be 0 (exact fp32) or 1 (bf16x3)");
+    EXCEL_CHECK_ARG(mode == 0 || mode == 1 || mode == 2, "patch_text_cam: mode must be 0 (exact fp32), 1 (bf16x3) or 2 (f16x3)");
     EXCEL_CHECK_ARG(B > 0 && N > 0 && C > 0 && T > 0, "patch_text_cam: bad shape");
     const int ldT = (T + 3) / 4 * 4;
     const PtcWs w = ptc_ws_layout(B, N, C, T, (char*)workspace);
+    if (mode == 2)
+        return excel_f16::excel_launch_patch_text_cam(x_raw, text, w.ts, w.sim, w.part, w.colsq, out_full, out_slice, image_features, B, N, C, T, F,
+                                                      ldT, temperature, 1, ST(stream));
     return excel_launch_patch_text_cam(x_raw, text, mode == 1 ? w.ts : nullptr, w.sim, w.part, w.colsq, out_full, out_slice, image_features, B, N, C,
                                        T, F, ldT, temperature, mode, ST(stream));
 }

@@ -21,6 +21,8 @@
 #include "common.h"
 #include "excel_internal.h"
 
+namespace EXCEL_SPLIT_NS {     // compiled once per 16-bit split type (excel_internal.h, build.py)
+
 #define HD 64
 #define KP 68   // LDS pitch (floats) of a [rows][64] operand tile read with ds_read_b128: slot = 17*row mod 16 -> conflict-free
 
@@ -67,15 +69,15 @@ __device__ __forceinline__ void rowpass_body(const RowpassArgs& p, float* smem, 
     const int q0 = qblk * 128 + wave * 32;
     const int qrow = min(q0 + r, N - 1);
     f32x4 xf[8];
-    bf16x8 xh[4], xl[4];
+    splitx8 xh[4], xl[4];
     const u16* Ysp = nullptr;
     if (BF) {
         const u16* Xsp = p.qkvs + (((long long)b * 3 + tx) * p.H + h) * (long long)N * 128;
         Ysp = p.qkvs + (((long long)b * 3 + ty) * p.H + h) * (long long)N * 128;
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
-            xh[s4] = *reinterpret_cast<const bf16x8*>(Xsp + (long long)qrow * 128 + s4 * 16 + kh * 8);
-            xl[s4] = *reinterpret_cast<const bf16x8*>(Xsp + (long long)qrow * 128 + 64 + s4 * 16 + kh * 8);
+            xh[s4] = *reinterpret_cast<const splitx8*>(Xsp + (long long)qrow * 128 + s4 * 16 + kh * 8);
+            xl[s4] = *reinterpret_cast<const splitx8*>(Xsp + (long long)qrow * 128 + 64 + s4 * 16 + kh * 8);
         }
     } else {
 #pragma unroll
@@ -143,11 +145,11 @@ __device__ __forceinline__ void rowpass_body(const RowpassArgs& p, float* smem, 
             const u16* kr = reinterpret_cast<const u16*>(Ks) + cur * 32 * 128 + r * 128;
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
-                const bf16x8 yh = *reinterpret_cast<const bf16x8*>(kr + (((s4 * 2 + kh) ^ (r & 15)) * 8));
-                const bf16x8 yl = *reinterpret_cast<const bf16x8*>(kr + (((8 + s4 * 2 + kh) ^ (r & 15)) * 8));
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl, xh[s4], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh, xl[s4], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh, xh[s4], s, 0, 0, 0);
+                const splitx8 yh = *reinterpret_cast<const splitx8*>(kr + (((s4 * 2 + kh) ^ (r & 15)) * 8));
+                const splitx8 yl = *reinterpret_cast<const splitx8*>(kr + (((8 + s4 * 2 + kh) ^ (r & 15)) * 8));
+                s = EXCEL_MFMA16(yl, xh[s4], s, 0, 0, 0);
+                s = EXCEL_MFMA16(yh, xl[s4], s, 0, 0, 0);
+                s = EXCEL_MFMA16(yh, xh[s4], s, 0, 0, 0);
             }
         } else {
 #pragma unroll
@@ -183,12 +185,12 @@ __device__ __forceinline__ void rowpass_body(const RowpassArgs& p, float* smem, 
             if (PVBF) {
                 // P (this lane: keys (e&3)+8(e>>2)+4kh of query r) -> bf16 hi/lo; MFMA k-step ks takes e = 8ks..8ks+7, i.e. keys
                 // {16ks+4kh+0..3, 16ks+8+4kh+0..3}: the V^T operand reads exactly those two 8-byte groups of row d.
-                bf16x8 ph[2], pl[2];
+                splitx8 ph[2], pl[2];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const __bf16 hi = (__bf16)s[e];
+                    const split_t hi = (split_t)s[e];
                     ph[e >> 3][e & 7] = hi;
-                    pl[e >> 3][e & 7] = (__bf16)(s[e] - (float)hi);
+                    pl[e >> 3][e & 7] = (split_t)(s[e] - (float)hi);
                 }
                 const u16* vt16 = reinterpret_cast<const u16*>(Vs) + cur * 64 * 64;
 #pragma unroll
@@ -197,17 +199,16 @@ __device__ __forceinline__ void rowpass_body(const RowpassArgs& p, float* smem, 
                     const u16* rowp = vt16 + d * 64;
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) {
-                        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
                         // 8-byte slot index of (chunk c, half kh) = 2c + kh; hi chunks 0..3, lo chunks 4..7
-                        const bf16x4 h0 = *reinterpret_cast<const bf16x4*>(rowp + (((2 * (2 * ks) + kh) ^ msk) * 4));
-                        const bf16x4 h1 = *reinterpret_cast<const bf16x4*>(rowp + (((2 * (2 * ks + 1) + kh) ^ msk) * 4));
-                        const bf16x4 l0 = *reinterpret_cast<const bf16x4*>(rowp + (((2 * (4 + 2 * ks) + kh) ^ msk) * 4));
-                        const bf16x4 l1 = *reinterpret_cast<const bf16x4*>(rowp + (((2 * (5 + 2 * ks) + kh) ^ msk) * 4));
-                        const bf16x8 vh = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-                        const bf16x8 vl = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
-                        oT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph[ks], oT[dt], 0, 0, 0);
-                        oT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl[ks], oT[dt], 0, 0, 0);
-                        oT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph[ks], oT[dt], 0, 0, 0);
+                        const splitx4 h0 = *reinterpret_cast<const splitx4*>(rowp + (((2 * (2 * ks) + kh) ^ msk) * 4));
+                        const splitx4 h1 = *reinterpret_cast<const splitx4*>(rowp + (((2 * (2 * ks + 1) + kh) ^ msk) * 4));
+                        const splitx4 l0 = *reinterpret_cast<const splitx4*>(rowp + (((2 * (4 + 2 * ks) + kh) ^ msk) * 4));
+                        const splitx4 l1 = *reinterpret_cast<const splitx4*>(rowp + (((2 * (5 + 2 * ks) + kh) ^ msk) * 4));
+                        const splitx8 vh = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                        const splitx8 vl = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                        oT[dt] = EXCEL_MFMA16(vl, ph[ks], oT[dt], 0, 0, 0);
+                        oT[dt] = EXCEL_MFMA16(vh, pl[ks], oT[dt], 0, 0, 0);
+                        oT[dt] = EXCEL_MFMA16(vh, ph[ks], oT[dt], 0, 0, 0);
                     }
                 }
             } else {
@@ -243,10 +244,10 @@ __device__ __forceinline__ void rowpass_body(const RowpassArgs& p, float* smem, 
             if (q >= N) break;
             const float v = ob[qq * 65 + lane];
             if (p.out_split) {
-                const __bf16 hi = (__bf16)v;
-                __bf16* o = reinterpret_cast<__bf16*>(p.out) + ((long long)b * N + q) * 2 * (p.H * HD) + split_off(h * HD + lane, 0);
+                const split_t hi = (split_t)v;
+                split_t* o = reinterpret_cast<split_t*>(p.out) + ((long long)b * N + q) * 2 * (p.H * HD) + split_off(h * HD + lane, 0);
                 o[0] = hi;
-                o[32] = (__bf16)(v - (float)hi);
+                o[32] = (split_t)(v - (float)hi);
             } else {
                 p.out[((long long)b * N + q) * (p.H * HD) + h * HD + lane] = v;
             }
@@ -285,11 +286,11 @@ __device__ __forceinline__ void rowpass_body_bf(const RowpassArgs& p, float* sme
 
     const int q0 = qblk * 128 + wave * 32;
     const int qrow = min(q0 + r, N - 1);
-    bf16x8 xh[4], xl[4];
+    splitx8 xh[4], xl[4];
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
-        xh[s4] = *reinterpret_cast<const bf16x8*>(Xsp + (long long)qrow * 128 + s4 * 16 + kh * 8);
-        xl[s4] = *reinterpret_cast<const bf16x8*>(Xsp + (long long)qrow * 128 + 64 + s4 * 16 + kh * 8);
+        xh[s4] = *reinterpret_cast<const splitx8*>(Xsp + (long long)qrow * 128 + s4 * 16 + kh * 8);
+        xl[s4] = *reinterpret_cast<const splitx8*>(Xsp + (long long)qrow * 128 + 64 + s4 * 16 + kh * 8);
     }
 
     // consume the query fragments once BEFORE any LDS-DMA is in flight: the compiler then places its wait for these ordinary loads
@@ -361,7 +362,7 @@ __device__ __forceinline__ void rowpass_body_bf(const RowpassArgs& p, float* sme
 #pragma unroll
         for (int e = 0; e < 16; ++e) s[e] = 0.f;
         {
-            bf16x8 yh[4], yl[4];
+            splitx8 yh[4], yl[4];
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 yh[s4] = lds_read16(kr + (((s4 * 2 + kh) ^ (r & 15)) * 16));
@@ -373,9 +374,9 @@ __device__ __forceinline__ void rowpass_body_bf(const RowpassArgs& p, float* sme
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 if (refill && s4 < PER_WAVE) issue_piece(kt + 2, rstage, s4);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl[s4], xh[s4], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[s4], xl[s4], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[s4], xh[s4], s, 0, 0, 0);
+                s = EXCEL_MFMA16(yl[s4], xh[s4], s, 0, 0, 0);
+                s = EXCEL_MFMA16(yh[s4], xl[s4], s, 0, 0, 0);
+                s = EXCEL_MFMA16(yh[s4], xh[s4], s, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -418,19 +419,19 @@ __device__ __forceinline__ void rowpass_body_bf(const RowpassArgs& p, float* sme
             // P (this lane: keys (e&3)+8(e>>2)+4kh of query r) -> bf16 hi/lo; MFMA k-step ks takes e = 8ks..8ks+7, i.e. keys
             // {16ks+4kh+0..3, 16ks+8+4kh+0..3}: the V operand (lane = d) takes exactly those two groups of 4 consecutive keys.
             // hi = p truncated to bf16 (bit mask), lo = bf16(p - hi): p - hi is exact, so hi + lo keeps 16 mantissa bits.
-            bf16x8 ph[2], pl[2];
+            splitx8 ph[2], pl[2];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const float hf = __uint_as_float(__float_as_uint(s[e]) & 0xFFFF0000u);
-                ph[e >> 3][e & 7] = (__bf16)hf;
-                pl[e >> 3][e & 7] = (__bf16)(s[e] - hf);
+                ph[e >> 3][e & 7] = (split_t)hf;
+                pl[e >> 3][e & 7] = (split_t)(s[e] - hf);
             }
             // lane (d = 32 dt + r, kh): sub-tile 2 dt + (r >> 4), its column r & 15; the 16 lanes of a group address the 16 row segments
             // (key = k0 + i / 4, d quarter i % 4) of the [4 keys][16 d] block whose column they receive
             const unsigned vb = ring_b + (stage * STAGE_EL + KT_EL) * 2 + ((lane >> 4) & 1) * VSUB + (4 * kh + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-                bf16x4 vq[8];                                   // [ks][h0 h1 l0 l1]
+                splitx4 vq[8];                                   // [ks][h0 h1 l0 l1]
                 const unsigned vbd = vb + dt * 2 * VSUB;        // (one address per d tile; everything else is the instruction's immediate)
                 vq[0] = lds_read8h_tr<0>(vbd);
                 vq[1] = lds_read8h_tr<256>(vbd);
@@ -443,12 +444,12 @@ __device__ __forceinline__ void rowpass_body_bf(const RowpassArgs& p, float* sme
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vq[0]), "+v"(vq[1]), "+v"(vq[2]), "+v"(vq[3]), "+v"(vq[4]), "+v"(vq[5]), "+v"(vq[6]), "+v"(vq[7])::"memory");
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    const bf16x4 h0 = vq[ks * 4], h1 = vq[ks * 4 + 1], l0 = vq[ks * 4 + 2], l1 = vq[ks * 4 + 3];
-                    const bf16x8 vh = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-                    const bf16x8 vl = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
-                    oT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph[ks], oT[dt], 0, 0, 0);
-                    oT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl[ks], oT[dt], 0, 0, 0);
-                    oT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph[ks], oT[dt], 0, 0, 0);
+                    const splitx4 h0 = vq[ks * 4], h1 = vq[ks * 4 + 1], l0 = vq[ks * 4 + 2], l1 = vq[ks * 4 + 3];
+                    const splitx8 vh = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                    const splitx8 vl = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                    oT[dt] = EXCEL_MFMA16(vl, ph[ks], oT[dt], 0, 0, 0);
+                    oT[dt] = EXCEL_MFMA16(vh, pl[ks], oT[dt], 0, 0, 0);
+                    oT[dt] = EXCEL_MFMA16(vh, ph[ks], oT[dt], 0, 0, 0);
                 }
             }
         }
@@ -472,10 +473,10 @@ __device__ __forceinline__ void rowpass_body_bf(const RowpassArgs& p, float* sme
             if (q >= N) break;
             const float v = ob[qq * 65 + lane];
             if (p.out_split) {
-                const __bf16 hi = (__bf16)v;
-                __bf16* o = reinterpret_cast<__bf16*>(p.out) + ((long long)b * N + q) * 2 * (p.H * HD) + split_off(h * HD + lane, 0);
+                const split_t hi = (split_t)v;
+                split_t* o = reinterpret_cast<split_t*>(p.out) + ((long long)b * N + q) * 2 * (p.H * HD) + split_off(h * HD + lane, 0);
                 o[0] = hi;
-                o[32] = (__bf16)(v - (float)hi);
+                o[32] = (split_t)(v - (float)hi);
             } else {
                 p.out[((long long)b * N + q) * (p.H * HD) + h * HD + lane] = v;
             }
@@ -596,11 +597,11 @@ __global__ __launch_bounds__(256, 1) void attn_accum_kernel(AccumArgs p) {
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4) {
                     const int ch = ((s4 * 2 + kh) ^ (r & 15)) * 8, cl = ((8 + s4 * 2 + kh) ^ (r & 15)) * 8;
-                    const bf16x8 yh = *reinterpret_cast<const bf16x8*>(y16 + ch), yl = *reinterpret_cast<const bf16x8*>(y16 + cl);
-                    const bf16x8 xh = *reinterpret_cast<const bf16x8*>(x16 + ch), xl = *reinterpret_cast<const bf16x8*>(x16 + cl);
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl, xh, s, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh, xl, s, 0, 0, 0);
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh, xh, s, 0, 0, 0);
+                    const splitx8 yh = *reinterpret_cast<const splitx8*>(y16 + ch), yl = *reinterpret_cast<const splitx8*>(y16 + cl);
+                    const splitx8 xh = *reinterpret_cast<const splitx8*>(x16 + ch), xl = *reinterpret_cast<const splitx8*>(x16 + cl);
+                    s = EXCEL_MFMA16(yl, xh, s, 0, 0, 0);
+                    s = EXCEL_MFMA16(yh, xl, s, 0, 0, 0);
+                    s = EXCEL_MFMA16(yh, xh, s, 0, 0, 0);
                 }
             } else {
 #pragma unroll
@@ -678,10 +679,10 @@ __global__ __launch_bounds__(256, 1) void attn_accum_kernel(AccumArgs p) {
                     // LVC branch (clip_surgery_model.py:140-141): every head's attn[1:,1:] += ex_attn -> head-sum gains H x ex_attn
                     if (p.ex_attn && qg >= 1 && kg >= 1 && kg < N) av += p.ex_scale * p.ex_attn[((long long)b * (N - 1) + (qg - 1)) * (N - 1) + (kg - 1)];
                     if (p.a_sum_split) {
-                        __bf16* o = reinterpret_cast<__bf16*>(p.a_sum) + ((long long)b * N + qg) * 2 * p.NP + split_off(kg, 0);
-                        const __bf16 hi = (__bf16)av;
+                        split_t* o = reinterpret_cast<split_t*>(p.a_sum) + ((long long)b * N + qg) * 2 * p.NP + split_off(kg, 0);
+                        const split_t hi = (split_t)av;
                         o[0] = hi;
-                        o[32] = (__bf16)(av - (float)hi);
+                        o[32] = (split_t)(av - (float)hi);
                     } else {
                         p.a_sum[((long long)b * N + qg) * p.NP + kg] = av;
                     }
@@ -804,11 +805,11 @@ __global__ __launch_bounds__(512, 2) void attn_accum_bf_kernel(AccumArgs p) {
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
             const int ch = ((s4 * 2 + kh) ^ (r & 15)) * 8, cl = ((8 + s4 * 2 + kh) ^ (r & 15)) * 8;
-            const bf16x8 yh = *reinterpret_cast<const bf16x8*>(y16 + ch), yl = *reinterpret_cast<const bf16x8*>(y16 + cl);
-            const bf16x8 xh = *reinterpret_cast<const bf16x8*>(x16 + ch), xl = *reinterpret_cast<const bf16x8*>(x16 + cl);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl, xh, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh, xl, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh, xh, s, 0, 0, 0);
+            const splitx8 yh = *reinterpret_cast<const splitx8*>(y16 + ch), yl = *reinterpret_cast<const splitx8*>(y16 + cl);
+            const splitx8 xh = *reinterpret_cast<const splitx8*>(x16 + ch), xl = *reinterpret_cast<const splitx8*>(x16 + cl);
+            s = EXCEL_MFMA16(yl, xh, s, 0, 0, 0);
+            s = EXCEL_MFMA16(yh, xl, s, 0, 0, 0);
+            s = EXCEL_MFMA16(yh, xh, s, 0, 0, 0);
         }
         if (last_kt) {
 #pragma unroll
@@ -897,10 +898,10 @@ __global__ __launch_bounds__(512, 2) void attn_accum_bf_kernel(AccumArgs p) {
                     // LVC branch (clip_surgery_model.py:140-141): every head's attn[1:,1:] += ex_attn -> head-sum gains H x ex_attn
                     if (p.ex_attn && qg >= 1 && kg >= 1 && kg < N) av += p.ex_scale * p.ex_attn[((long long)b * (N - 1) + (qg - 1)) * (N - 1) + (kg - 1)];
                     if (p.a_sum_split) {
-                        __bf16* o = reinterpret_cast<__bf16*>(p.a_sum) + ((long long)b * N + qg) * 2 * p.NP + split_off(kg, 0);
-                        const __bf16 hi = (__bf16)av;
+                        split_t* o = reinterpret_cast<split_t*>(p.a_sum) + ((long long)b * N + qg) * 2 * p.NP + split_off(kg, 0);
+                        const split_t hi = (split_t)av;
                         o[0] = hi;
-                        o[32] = (__bf16)(av - (float)hi);
+                        o[32] = (split_t)(av - (float)hi);
                     } else {
                         p.a_sum[((long long)b * N + qg) * p.NP + kg] = av;
                     }
@@ -958,3 +959,5 @@ int excel_launch_attn_accum(const float* qkvh, const float* stats, float* a_sum,
     EXCEL_CHECK_LAUNCH("attn_accum");
     return EXCEL_OK;
 }
+
+}  // namespace EXCEL_SPLIT_NS

@@ -21,12 +21,14 @@
 #include "common.h"
 #include "excel_internal.h"
 
+namespace EXCEL_SPLIT_NS {     // compiled once per 16-bit split type (excel_internal.h, build.py)
+
 typedef unsigned short u16;
 
 template <class F, int... I> __device__ __forceinline__ void static_for_seq(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_seq(f, std::make_integer_sequence<int, N>{}); }
 
-#define STRIP_VAR 0          // the variant the shipped library runs (see the kernel header)
+#define STRIP_VAR 3          // the variant the shipped library runs (see the kernel header)
 #define GLDS(src, dst) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
 struct StripArgs {
@@ -46,12 +48,16 @@ struct StripArgs {
     int split_c;          // > 0: the two sweeps of a strip are separate workgroups, split_c strips per XCD (see the launcher)
 };
 
-// VAR (round 4; bit set = on):
-//   bit0  the 12 MFMAs of a score tile alternate between TWO accumulators per k-step (the first MFMA of each takes C = 0), summed at
-//         the end: the DMA instalments / address updates between k-steps then sit between MFMAs on DIFFERENT accumulators (an extra
-//         issue slot between two MFMAs on the same accumulator costs ~43 cycles on this core, MI355X_MICROARCH.md); all folds early
-//   bit1  the key fragments of tile j+1 are read into the registers tile j's MFMAs have just released, one k-step at a time, behind
-//         those MFMAs: the LDS round trip (and the wait for the tile's DMA) leaves the wave's critical path
+// VAR (round 4; bit set = on; STRIP_VAR is what ships):
+//   bit0  fragment read-ahead: the key fragments of tile j+1 are read into the registers tile j's MFMAs have just released, one k-step
+//         at a time, behind those MFMAs (needs the next tile landed: counted vmcnt(2) behind the first instalment) - the LDS round trip
+//         and the wait for the tile's DMA leave the wave's stream                                                       (-0.6 % same-box)
+//   bit1  static DMA cursor: which (phase, tile) the tile two ahead in the stream is, is known per unrolled tile up to one scalar
+//         select on the wave's tile count - replaces the branchy run-time cursor (-77 SALU, -14 branches per phase; the kernel did
+//         not notice: -0.3 %, SALU issues beside the vector stream); tile maxima by explicit v_max3_f32       (both: -1.4 % same-box)
+// Measured and dropped in round 4: two accumulators per tile alternating per k-step (+7.5 %: eight more packed adds per
+// tile), the softmax of tile j-1 as scalar VALU inside tile j's MFMA gaps (+30 %: the kernel is bound by VALU issue, and unpacking
+// adds 48 VALU per tile).
 template <int NTW, int DBG, int VAR>
 __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
     constexpr int TILE_EL = 32 * 128;                                    // u16 elements of a 32-row operand tile (8 KB)
@@ -148,6 +154,15 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_bptr)(unsigned long long)(xb + pi * 1024), 16, voff[pi & 3], soff + (pi >> 2) * 4096, 0, 0);
     };
 
+    // VAR bit 1: static cursor.  While tile j of phase t is multiplied, the tile two ahead in the stream goes out: (t, j + 2) if the wave
+    // has that many tiles, else (t + 1, j + 2 - cnt); poff_cur / poff_nxt are the plane offsets of phases t and min(t + 1, t1 - 1).
+    int poff_cur = 0, poff_nxt = 0;
+    auto issue_part_static = [&](int j, int part, int gcnt) {
+        const bool same = j + 2 < cnt;
+        const int tix = same ? j + 2 : j + 2 - cnt;
+        dma_pieces((same ? poff_cur : poff_nxt) + (first + tix) * 8192, ring_addr + (gcnt & 1) * (TILE_EL * 2), 2 * part, 2 * part + 2);
+    };
+
     const float c2 = p.scale * 1.4426950408889634f;              // scores enter the softmax in log2 units
     const int last_tile = p.ntiles - 1;
     const bool ragged = (N & 31) != 0;
@@ -185,9 +200,9 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
         f32x16 s[NTW];
         float mref[NTW];                                           // running maximum (log2 units) tile j was exponentiated against
         bool pending = false;
-        const bool late_f = (VAR & 7) ? false : (wave & 4) != 0;
-        bf16x8 yh[4], yl[4];                                       // key fragments (VAR bit 1: carried from tile to tile)
-        if constexpr ((VAR & 6) != 0) {
+        const bool late_f = (wave & 4) != 0;
+        splitx8 yh[4], yl[4];                                       // key fragments (VAR bit 0: carried from tile to tile)
+        if constexpr ((VAR & 1) != 0) {
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // tile 0 of the stream landed (tile 1 may be in flight)
             const unsigned k0 = ring_addr + (r * 128) * 2;
 #pragma unroll
@@ -227,8 +242,12 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
         };
         for (int t = t0; t < t1; ++t) {
             const int par = (t - t0) & 1;
+            if constexpr ((VAR & 2) != 0) {
+                poff_cur = (t == t0) ? plane_off(t0, false) : poff_nxt;
+                poff_nxt = plane_off(min(t + 1, t1 - 1), false);
+            }
             // query-strip fragments (B operand): row r, k-step s4 -> chunk (2 s4 + kh) of hi, 8 + (2 s4 + kh) of lo
-            bf16x8 xh[4], xl[4];
+            splitx8 xh[4], xl[4];
             {
                 const unsigned xr = xs_addr + (par * TILE_EL + r * 128) * 2;
 #pragma unroll
@@ -242,9 +261,18 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
             // finite "minus infinity": a lane whose 16 keys of the (ragged) last tile are all padding must not form (-inf) - (-inf)
             float m_run = -1e30f, l_run = 0.f;
             auto softmax_tile = [&](int j) {
-                float tm = fmaxf(s[j][0], s[j][1]);
+                float tm;
+                if constexpr ((VAR & 2) != 0) {
+                    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tm) : "v"(s[j][0]), "v"(s[j][1]), "v"(s[j][2]));
+                    asm("v_max3_f32 %0, %0, %1, %2" : "+v"(tm) : "v"(s[j][3]), "v"(s[j][4]));
 #pragma unroll
-                for (int e = 2; e < 16; e += 2) tm = fmaxf(fmaxf(tm, s[j][e]), s[j][e + 1]);       // v_max3_f32
+                    for (int e = 5; e < 15; e += 2) asm("v_max3_f32 %0, %0, %1, %2" : "+v"(tm) : "v"(s[j][e]), "v"(s[j][e + 1]));
+                    asm("v_max_f32 %0, %0, %1" : "+v"(tm) : "v"(s[j][15]));
+                } else {
+                    tm = fmaxf(s[j][0], s[j][1]);
+#pragma unroll
+                    for (int e = 2; e < 16; e += 2) tm = fmaxf(fmaxf(tm, s[j][e]), s[j][e + 1]);   // v_max3_f32
+                }
                 const float m_new = fmaxf(m_run, tm * c2);
                 l_run *= __builtin_amdgcn_exp2f(m_run - m_new);    // first tile: 2^(-inf) = 0
                 const f32x2 c22 = {c2, c2}, nm2 = {-m_new, -m_new};
@@ -261,106 +289,21 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
                 m_run = m_new;
                 mref[j] = m_new;
             };
-            if constexpr ((VAR & 4) != 0) {
-                // ---- VAR bit 2: the softmax of tile j-1 runs INSIDE tile j's MFMA block, a few single-issue VALU per MFMA gap (an MFMA
-                // occupies the matrix pipe for 32 cycles = ~8 issue slots of this wave), and consecutive MFMAs alternate between the two
-                // accumulators (k-steps {0,1} and {2,3} interleaved), so no filler sits between two MFMAs on the SAME accumulator.
-                // Scalar fma / add instead of the packed forms (packed fp32 beside MFMAs is slower than two scalar ops on this core);
-                // even / odd partial sums like the packed version -> the same bits.
-                float sm_tm = 0.f, sm_mnew = 0.f, sm_pe = 0.f, sm_po = 0.f;
-                auto sm_chunk = [&](int jp, auto cc) {
-                    constexpr int c = decltype(cc)::value;
-                    if constexpr (c == 0) {
-                        sm_tm = fmaxf(s[jp][0], s[jp][1]);
-#pragma unroll
-                        for (int e = 2; e < 8; e += 2) sm_tm = fmaxf(fmaxf(sm_tm, s[jp][e]), s[jp][e + 1]);
-                        asm volatile("" : "+v"(sm_tm));            // (pins: the optimiser otherwise sinks the whole chain to its last use)
-                    }
-                    if constexpr (c == 1) {
-#pragma unroll
-                        for (int e = 8; e < 16; e += 2) sm_tm = fmaxf(fmaxf(sm_tm, s[jp][e]), s[jp][e + 1]);
-                        sm_mnew = fmaxf(m_run, sm_tm * c2);
-                        asm volatile("" : "+v"(sm_mnew));
-                    }
-                    if constexpr (c == 2) {
-                        l_run *= __builtin_amdgcn_exp2f(m_run - sm_mnew);
-                        sm_pe = 0.f; sm_po = 0.f;
-                        asm volatile("" : "+v"(l_run));
-                    }
-                    if constexpr (c >= 2 && c <= 9) {
-                        constexpr int e0 = 2 * (c - 2);
-                        const float a0 = fmaf(s[jp][e0], c2, -sm_mnew), a1 = fmaf(s[jp][e0 + 1], c2, -sm_mnew);
-                        const float p0 = __builtin_amdgcn_exp2f(a0), p1 = __builtin_amdgcn_exp2f(a1);
-                        s[jp][e0] = p0; s[jp][e0 + 1] = p1;
-                        sm_pe += p0; sm_po += p1;
-                        asm volatile("" : "+v"(s[jp][e0]), "+v"(s[jp][e0 + 1]), "+v"(sm_pe), "+v"(sm_po));
-                    }
-                    if constexpr (c == 9) {
-                        l_run += sm_pe + sm_po;
-                        m_run = sm_mnew;
-                        mref[jp] = sm_mnew;
-                    }
-                };
-#define STRIP_GAP() __builtin_amdgcn_sched_barrier(0)
-#define STRIP_CH(c) do { if (j > 0) sm_chunk(j - 1, std::integral_constant<int, c>{}); } while (0)
-#define STRIP_RD(s4) do { yh[s4] = lds_read16(kn + ((((s4) * 2 + kh) ^ (r & 15)) * 16)); yl[s4] = lds_read16(kn + (((8 + (s4) * 2 + kh) ^ (r & 15)) * 16)); } while (0)
-#define STRIP_MF(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+            {
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) {
                     if (j < NTW - 1 || full) {
-                        lds_wait8(yh, yl);                                                      // this tile's fragments (read behind the previous tile's MFMAs)
-                        ++gc;
-                        const unsigned kn = ring_addr + ((gc & 1) * TILE_EL + r * 128) * 2;      // the next tile of the stream
-                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        f32x16 sa, sb;
-                        STRIP_GAP(); issue_next_part(0); STRIP_GAP();
-                        sa = STRIP_MF(yl[0], xh[0], zero); STRIP_GAP(); STRIP_CH(0); STRIP_GAP();
-                        sb = STRIP_MF(yl[1], xh[1], zero); STRIP_GAP(); STRIP_CH(1); STRIP_GAP();
-                        sa = STRIP_MF(yh[0], xl[0], sa); STRIP_GAP(); STRIP_CH(2); STRIP_GAP();
-                        sb = STRIP_MF(yh[1], xl[1], sb); STRIP_GAP(); STRIP_CH(3); STRIP_GAP();
-                        sa = STRIP_MF(yh[0], xh[0], sa); STRIP_GAP();
-                        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                        // all but the two pieces just issued: the next tile landed
-                        STRIP_RD(0); STRIP_CH(4); STRIP_GAP();
-                        sb = STRIP_MF(yh[1], xh[1], sb); STRIP_GAP(); STRIP_RD(1); issue_next_part(1); STRIP_GAP();
-                        sa = STRIP_MF(yl[2], xh[2], sa); STRIP_GAP(); STRIP_CH(5); STRIP_GAP();
-                        sb = STRIP_MF(yl[3], xh[3], sb); STRIP_GAP(); STRIP_CH(6); STRIP_GAP();
-                        sa = STRIP_MF(yh[2], xl[2], sa); STRIP_GAP(); STRIP_CH(7); issue_next_part(2); STRIP_GAP();
-                        sb = STRIP_MF(yh[3], xl[3], sb); STRIP_GAP(); STRIP_CH(8); STRIP_GAP();
-                        sa = STRIP_MF(yh[2], xh[2], sa); STRIP_GAP(); STRIP_RD(2); STRIP_CH(9); STRIP_GAP();
-                        sb = STRIP_MF(yh[3], xh[3], sb); STRIP_GAP(); STRIP_RD(3); issue_next_part(3); STRIP_GAP();
-                        f32x16 sj = sa + sb;
-                        if (ragged && first + j == last_tile) {                                 // wave-uniform: keys >= N only here
-                            int lim = nvalid_last;
-                            asm volatile("" : "+v"(lim));
-#pragma unroll
-                            for (int e = 0; e < 16; ++e)
-                                if ((e & 3) + 8 * (e >> 2) >= lim) sj[e] = -INFINITY;
-                        }
-                        s[j] = sj;
-                    }
-                }
-                {   // the last tile's softmax has no MFMA block to hide in
-                    const int jl = full ? NTW - 1 : (NTW > 1 ? NTW - 2 : 0);
-                    static_for<10>([&](auto cc) { sm_chunk(jl, cc); });
-                }
-#undef STRIP_GAP
-#undef STRIP_CH
-#undef STRIP_RD
-#undef STRIP_MF
-            } else
-            if constexpr ((VAR & 3) == 0) {
-#pragma unroll
-                for (int j = 0; j < NTW; ++j) {
-                    if (j < NTW - 1 || full) {
-                        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                        // tile gc landed (gc+1 may be in flight)
-                        const unsigned kr = ring_addr + ((gc & 1) * TILE_EL + r * 128) * 2;
-                        bf16x8 yh[4], yl[4];
+                        if constexpr ((VAR & 1) == 0) {
+                            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                    // tile gc landed (gc+1 may be in flight)
+                            const unsigned kr = ring_addr + ((gc & 1) * TILE_EL + r * 128) * 2;
     #pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4) {
-                            yh[s4] = lds_read16(kr + (((s4 * 2 + kh) ^ (r & 15)) * 16));
-                            yl[s4] = lds_read16(kr + (((8 + s4 * 2 + kh) ^ (r & 15)) * 16));
+                            for (int s4 = 0; s4 < 4; ++s4) {
+                                yh[s4] = lds_read16(kr + (((s4 * 2 + kh) ^ (r & 15)) * 16));
+                                yl[s4] = lds_read16(kr + (((8 + s4 * 2 + kh) ^ (r & 15)) * 16));
+                            }
                         }
                         lds_wait8(yh, yl);                                                      // fragments in registers: the slot is free
+                        const unsigned kn = ring_addr + (((gc + 1) & 1) * TILE_EL + r * 128) * 2;  // (VAR bit 0) the next tile of the stream
                         if ((DBG & 1) && !(DBG & 2)) issue_next();                              // tile gc+2 -> this slot
                         ++gc;
                         f32x16 sj;
@@ -369,11 +312,19 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
                         if (!(DBG & 1)) {
     #pragma unroll
                             for (int s4 = 0; s4 < 4; ++s4) {
-                                if (!(DBG & 2)) issue_next_part(s4);                            // tile gc+2 -> this slot, two pieces per k-step
-                                sj = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl[s4], xh[s4], sj, 0, 0, 0);
-                                sj = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[s4], xl[s4], sj, 0, 0, 0);
-                                sj = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[s4], xh[s4], sj, 0, 0, 0);
+                                if constexpr ((VAR & 2) != 0) issue_part_static(j, s4, gc + 1);     // (gc was advanced: this tile's slot)
+                                else if (!(DBG & 2)) issue_next_part(s4);                       // tile gc+2 -> this slot, two pieces per k-step
+                                sj = EXCEL_MFMA16(yl[s4], xh[s4], sj, 0, 0, 0);
+                                sj = EXCEL_MFMA16(yh[s4], xl[s4], sj, 0, 0, 0);
+                                sj = EXCEL_MFMA16(yh[s4], xh[s4], sj, 0, 0, 0);
                                 __builtin_amdgcn_sched_barrier(0);                              // keep the instalments where they are
+                                if constexpr ((VAR & 1) != 0) {
+                                    // bit 0: the next tile's fragments of this k-step into the registers these MFMAs have just read
+                                    if (s4 == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // all but the two pieces just issued: it landed
+                                    yh[s4] = lds_read16(kn + (((s4 * 2 + kh) ^ (r & 15)) * 16));
+                                    yl[s4] = lds_read16(kn + (((8 + s4 * 2 + kh) ^ (r & 15)) * 16));
+                                    __builtin_amdgcn_sched_barrier(0);
+                                }
                             }
                         } else {
                             sj[0] = (float)yl[0][0] + (float)yh[3][1] + (float)xh[0][0] + (float)xl[3][1];
@@ -392,74 +343,8 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
                         s[j] = sj;
                     }
                 }
-} else {
-                // ---- round-4 tile loop (VAR bits 0 / 1, see the kernel header)
-#pragma unroll
-                for (int j = 0; j < NTW; ++j) {
-                    if (j < NTW - 1 || full) {
-                        if constexpr (VAR & 2) {
-                            lds_wait8(yh, yl);                                                  // this tile's fragments (read behind the previous tile's MFMAs)
-                        } else {
-                            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                    // tile gc landed (gc+1 may be in flight)
-                            const unsigned kr = ring_addr + ((gc & 1) * TILE_EL + r * 128) * 2;
-#pragma unroll
-                            for (int s4 = 0; s4 < 4; ++s4) {
-                                yh[s4] = lds_read16(kr + (((s4 * 2 + kh) ^ (r & 15)) * 16));
-                                yl[s4] = lds_read16(kr + (((8 + s4 * 2 + kh) ^ (r & 15)) * 16));
-                            }
-                            lds_wait8(yh, yl);                                                  // fragments in registers: the slot is free
-                        }
-                        ++gc;
-                        const unsigned kn = ring_addr + ((gc & 1) * TILE_EL + r * 128) * 2;      // the NEXT tile of the stream (VAR bit 1)
-                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        f32x16 sa, sb;
-#pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4) {
-                            issue_next_part(s4);                                                // tile gc+1 -> this tile's slot, two pieces per k-step
-                            __builtin_amdgcn_sched_barrier(0);                                  // ... BETWEEN the MFMA groups (different accumulators)
-                            if (s4 == 0) {
-                                sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl[0], xh[0], zero, 0, 0, 0);
-                                sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[0], xl[0], sa, 0, 0, 0);
-                                sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[0], xh[0], sa, 0, 0, 0);
-                            } else if (s4 == 1) {
-                                sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl[1], xh[1], zero, 0, 0, 0);
-                                sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[1], xl[1], sb, 0, 0, 0);
-                                sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[1], xh[1], sb, 0, 0, 0);
-                            } else if (s4 == 2) {
-                                sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl[2], xh[2], sa, 0, 0, 0);
-                                sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[2], xl[2], sa, 0, 0, 0);
-                                sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[2], xh[2], sa, 0, 0, 0);
-                            } else {
-                                sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yl[3], xh[3], sb, 0, 0, 0);
-                                sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[3], xl[3], sb, 0, 0, 0);
-                                sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yh[3], xh[3], sb, 0, 0, 0);
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-                            if constexpr (VAR & 2) {
-                                // everything older than the 2 (s4 + 1) pieces just issued has landed: the next tile is in its slot
-                                if (s4 == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                                yh[s4] = lds_read16(kn + (((s4 * 2 + kh) ^ (r & 15)) * 16));
-                                yl[s4] = lds_read16(kn + (((8 + s4 * 2 + kh) ^ (r & 15)) * 16));
-                                __builtin_amdgcn_sched_barrier(0);
-                            }
-                        }
-                        if (NTW < 5) {
-                            if (j > 0 && !(DBG & 4)) softmax_tile(j - 1);                       // in the shadow of these MFMAs
-                        }
-                        f32x16 sj = sa + sb;
-                        if (ragged && first + j == last_tile) {                                 // wave-uniform: keys >= N only here
-                            int lim = nvalid_last;
-                            asm volatile("" : "+v"(lim));
-#pragma unroll
-                            for (int e = 0; e < 16; ++e)
-                                if ((e & 3) + 8 * (e >> 2) >= lim) sj[e] = -INFINITY;
-                        }
-                        s[j] = sj;
-                    }
-                }
-            }
-            if constexpr ((VAR & 4) != 0) {
-            } else if (!(DBG & 4)) {
+}
+            if (!(DBG & 4)) {
                 if (NTW < 5) {
                     if (full) softmax_tile(NTW - 1);
                     else if (NTW > 1) softmax_tile(NTW > 1 ? NTW - 2 : 0);
@@ -529,15 +414,15 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
                     }
                 }
                 if (qg < N) {
-                    bf16x8 hi, lo;
+                    splitx8 hi, lo;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
-                        hi[k] = (__bf16)v[k];
-                        lo[k] = (__bf16)(v[k] - (float)hi[k]);
+                        hi[k] = (split_t)v[k];
+                        lo[k] = (split_t)(v[k] - (float)hi[k]);
                     }
                     u16* o = p.a_sum + ((long long)b * N + qg) * 2 * p.KP + tile * 64 + g8 * 8;
-                    *reinterpret_cast<bf16x8*>(o) = hi;
-                    *reinterpret_cast<bf16x8*>(o + 32) = lo;
+                    *reinterpret_cast<splitx8*>(o) = hi;
+                    *reinterpret_cast<splitx8*>(o + 32) = lo;
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -618,21 +503,22 @@ int excel_launch_attn_strip(const unsigned short* qkvs, unsigned short* a_sum, f
         switch (var) {
             case 0: hipLaunchKernelGGL((attn_strip_kernel<4, 0, 0>), grid, block, 0, st, a); break;
             case 1: hipLaunchKernelGGL((attn_strip_kernel<4, 0, 1>), grid, block, 0, st, a); break;
-            case 2: hipLaunchKernelGGL((attn_strip_kernel<4, 0, 2>), grid, block, 0, st, a); break;
-            case 3: hipLaunchKernelGGL((attn_strip_kernel<4, 0, 3>), grid, block, 0, st, a); break;
-            default: hipLaunchKernelGGL((attn_strip_kernel<4, 0, 7>), grid, block, 0, st, a); break;
+            default: hipLaunchKernelGGL((attn_strip_kernel<4, 0, 2>), grid, block, 0, st, a); break;
         }
         EXCEL_CHECK_LAUNCH("attn_strip");
         return EXCEL_OK;
     }
 #endif
     switch (ntw) {
-        case 1: hipLaunchKernelGGL((attn_strip_kernel<1, 0, STRIP_VAR>), grid, block, 0, st, a); break;
-        case 2: hipLaunchKernelGGL((attn_strip_kernel<2, 0, STRIP_VAR>), grid, block, 0, st, a); break;
+        // (the round-4 variants for 3 and 4 tiles per wave: the static cursor needs >= 2 tiles per wave, 5 tiles have no register room)
+        case 1: hipLaunchKernelGGL((attn_strip_kernel<1, 0, 0>), grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((attn_strip_kernel<2, 0, 0>), grid, block, 0, st, a); break;
         case 3: hipLaunchKernelGGL((attn_strip_kernel<3, 0, STRIP_VAR>), grid, block, 0, st, a); break;
         case 4: hipLaunchKernelGGL((attn_strip_kernel<4, 0, STRIP_VAR>), grid, block, 0, st, a); break;
-        default: hipLaunchKernelGGL((attn_strip_kernel<5, 0, STRIP_VAR>), grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL((attn_strip_kernel<5, 0, 0>), grid, block, 0, st, a); break;
     }
     EXCEL_CHECK_LAUNCH("attn_strip");
     return EXCEL_OK;
 }
+
+}  // namespace EXCEL_SPLIT_NS

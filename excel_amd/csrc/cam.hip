@@ -8,6 +8,8 @@
 #include "common.h"
 #include "excel_internal.h"
 
+namespace EXCEL_SPLIT_NS {     // compiled once per 16-bit split type (excel_internal.h, build.py)
+
 #define CAM_TMAX 128
 
 __global__ __launch_bounds__(1024) void cam_epilogue_kernel(float* __restrict__ S, float* __restrict__ out_full,
@@ -134,10 +136,10 @@ __global__ __launch_bounds__(256) void patch_text_prep_kernel(PtcArgs p, unsigne
             const long long row = e / p.C;
             const int k = (int)(e - row * p.C);
             const f32x4 v = *reinterpret_cast<const f32x4*>(p.text + e);
-            __bf16 hi[4], lo[4];
+            split_t hi[4], lo[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { hi[j] = (__bf16)v[j]; lo[j] = (__bf16)(v[j] - (float)hi[j]); }
-            __bf16* o = reinterpret_cast<__bf16*>(text_split_out) + row * 2 * p.C + split_off(k, 0);
+            for (int j = 0; j < 4; ++j) { hi[j] = (split_t)v[j]; lo[j] = (split_t)(v[j] - (float)hi[j]); }
+            split_t* o = reinterpret_cast<split_t*>(text_split_out) + row * 2 * p.C + split_off(k, 0);
             *reinterpret_cast<uint2*>(o) = *reinterpret_cast<const uint2*>(hi);
             *reinterpret_cast<uint2*>(o + 32) = *reinterpret_cast<const uint2*>(lo);
         }
@@ -282,21 +284,21 @@ __global__ __launch_bounds__(PTC_NW * 64) void patch_text_sim_kernel(PtcArgs p) 
                     const f32x4 fb = *reinterpret_cast<const f32x4*>(&xt[r * PTC_XP + cb + 4]) * ib;
                     if (frow) { *reinterpret_cast<f32x4*>(frow + c0) = fa; *reinterpret_cast<f32x4*>(frow + c0 + 4) = fb; }
                     if (BF) {
-                        bf16x8 xh, xl;
+                        splitx8 xh, xl;
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             const float v = (j < 4) ? fa[j] : fb[j - 4];
-                            xh[j] = (__bf16)v;
-                            xl[j] = (__bf16)(v - (float)xh[j]);
+                            xh[j] = (split_t)v;
+                            xl[j] = (split_t)(v - (float)xh[j]);
                         }
 #pragma unroll
                         for (int ct = 0; ct < CT; ++ct) {
                             const unsigned short* tp = trow[ct] + split_off(c0, 0);
-                            bf16x8 h = *reinterpret_cast<const bf16x8*>(tp), l = *reinterpret_cast<const bf16x8*>(tp + 32);
-                            if (ct * 32 + r >= T) { h = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; l = h; }
-                            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(l, xh, acc[ct], 0, 0, 0);
-                            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h, xl, acc[ct], 0, 0, 0);
-                            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h, xh, acc[ct], 0, 0, 0);
+                            splitx8 h = *reinterpret_cast<const splitx8*>(tp), l = *reinterpret_cast<const splitx8*>(tp + 32);
+                            if (ct * 32 + r >= T) { h = splitx8{0, 0, 0, 0, 0, 0, 0, 0}; l = h; }
+                            acc[ct] = EXCEL_MFMA16(l, xh, acc[ct], 0, 0, 0);
+                            acc[ct] = EXCEL_MFMA16(h, xl, acc[ct], 0, 0, 0);
+                            acc[ct] = EXCEL_MFMA16(h, xh, acc[ct], 0, 0, 0);
                         }
                     } else {
                         // exact fp32: v_mfma_f32_32x32x2_f32 takes k = {kh}: feed the lane's 8 columns as 8 k-pairs (kh selects the column
@@ -463,3 +465,5 @@ int excel_launch_patch_text_cam(const float* x_raw, const float* text, unsigned 
     EXCEL_CHECK_LAUNCH("patch_text_cam");
     return EXCEL_OK;
 }
+
+}  // namespace EXCEL_SPLIT_NS

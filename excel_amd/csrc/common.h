@@ -162,17 +162,30 @@ struct ProfScope {
 
 
 // ---------------------------------------------------------------- LDS reads that the compiler's wait-count pass does not see
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+// The 16-bit type of the "split" operand planes (x = hi + lo, three MFMAs per product).  bf16 (default): 8 + 8 mantissa bits at the fp32
+// exponent range - no overflow or underflow concerns.  EXCEL_SPLIT_F16 (build-time experiment, `EXCEL_SPLIT_F16=1 python -m
+// excel_amd.build`): IEEE half, 11 + 11 bits where lo stays a normal half (|x| >= 2^-3; fewer below: lo goes denormal under 6e-5), range
+// 65 504 - same MFMA rate (v_mfma_f32_32x32x16_f16), same layouts.
+#ifdef EXCEL_SPLIT_F16
+typedef _Float16 split_t;
+#define EXCEL_MFMA16(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z)
+#define EXCEL_SPLIT_NAME "f16"
+#else
+typedef __bf16 split_t;
+#define EXCEL_MFMA16(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z)
+#define EXCEL_SPLIT_NAME "bf16"
+#endif
+typedef split_t splitx8 __attribute__((ext_vector_type(8)));
+typedef split_t splitx4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // LDS accesses of the streaming loop are written as inline asm: the compiler's wait-count pass treats every ds_read as a
 // possible reader of a pending global_load_lds and drains the whole DMA queue (s_waitcnt vmcnt(0)) in front of it, which
 // serialises the tile stream (that is what held attn_accum_bf_kernel at ~20 % matrix-core busy).  The waits here are explicit.
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)p; }
-__device__ __forceinline__ bf16x8 lds_read16(unsigned addr) {
+__device__ __forceinline__ splitx8 lds_read16(unsigned addr) {
     f32x4 v;
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
-    return __builtin_bit_cast(bf16x8, v);
+    return __builtin_bit_cast(splitx8, v);
 }
 __device__ __forceinline__ float2 lds_read8(unsigned addr) {
     float2 v;
@@ -181,21 +194,21 @@ __device__ __forceinline__ float2 lds_read8(unsigned addr) {
 }
 __device__ __forceinline__ void lds_write8(unsigned addr, float2 v) { asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
 // s_waitcnt lgkmcnt(0) that the consumers of the eight fragments depend on (keeps the MFMAs behind the wait)
-__device__ __forceinline__ bf16x4 lds_read8h(unsigned addr) {
+__device__ __forceinline__ splitx4 lds_read8h(unsigned addr) {
     f32x2 v;
     asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr) : "memory");
-    return __builtin_bit_cast(bf16x4, v);
+    return __builtin_bit_cast(splitx4, v);
 }
 // hardware transpose read (gfx950): the 16 lanes of a group each address one 8-byte row segment of a [4 rows][16 columns] block of
 // 16-bit elements (segment i = row i / 4, columns 4 (i % 4) ..+3, any row stride); lane c of the group receives column c, rows 0..3
 template <int OFF>
-__device__ __forceinline__ bf16x4 lds_read8h_tr(unsigned addr) {      // address + compile-time byte offset (the instruction's immediate)
+__device__ __forceinline__ splitx4 lds_read8h_tr(unsigned addr) {      // address + compile-time byte offset (the instruction's immediate)
     static_assert(OFF >= 0 && OFF < 65536, "ds_read_b64_tr_b16 immediate offset");
     f32x2 v;
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
-    return __builtin_bit_cast(bf16x4, v);
+    return __builtin_bit_cast(splitx4, v);
 }
-__device__ __forceinline__ void lds_wait8(bf16x8 (&a)[4], bf16x8 (&b)[4]) {
+__device__ __forceinline__ void lds_wait8(splitx8 (&a)[4], splitx8 (&b)[4]) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])::"memory");
 }
 

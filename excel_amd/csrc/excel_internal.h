@@ -24,7 +24,6 @@ struct GemmArgs {
     float alpha;
 };
 
-int excel_launch_gemm(const GemmArgs& p, bool b_kmajor, int batch, hipStream_t stream);
 
 // bf16x3 GEMM (gemm_bf16x3.hip): A, B are "split" tensors [rows][2][K] bf16 (hi plane, lo plane)
 struct GemmBfArgs {
@@ -44,34 +43,8 @@ struct GemmBfArgs {
     long long sA, sB, sC, sCs;
     int mix_tall, mix_short;     // set by the launcher (mixed-height 320x256 / 256x256 row tiles, gemm_bf16x3.hip); 0 = uniform tiles
 };
-int excel_launch_gemm_bf16x3(const GemmBfArgs& p, hipStream_t stream);
-int excel_launch_split_bf16(const float* in, void* out, long long R, int K, hipStream_t st);
-int excel_launch_vt_from_planes(const unsigned short* qkvs, unsigned short* vt, int B, int H, int N, int KP, hipStream_t st);
 
-int excel_launch_layernorm(const float* x, const float* cls_src, int tokN, const float* w, const float* b, float* y,
-                           int rows, int D, float eps, hipStream_t st, int split_out = 0, long long in_stride = 0);
-int excel_launch_assemble_ln_pre(const float* patch, const float* cls_emb, const float* pos, const float* w, const float* b,
-                                 float* x, int B, int tokN, int D, float eps, hipStream_t st);
-int excel_launch_token_axis_normalize(const float* f, float* ss, float* out, int B, int tokN, int C, hipStream_t st);
-int excel_launch_im2col(const float* img, float* col, int B, int S, int ps, hipStream_t st, int split_out = 0);
 
-int excel_launch_attn_rowpass(const float* qkvh, float* out, float* stats, int B, int H, int N, int hd, float scale,
-                              int ntypes, hipStream_t st, int split_out = 0, const unsigned short* qkvs = nullptr, int flash_nq = 1 << 30,
-                              const unsigned short* vt = nullptr, int KP = 0);
-int excel_launch_attn_accum(const float* qkvh, const float* stats, float* a_sum, float* w_aff, float* attn_out, int B, int H,
-                            int N, int NP, int hd, float scale, int surgery, float w_scale, float aff_scale, int aff_init,
-                            hipStream_t st, const unsigned short* qkvs = nullptr, int a_sum_split = 0, const float* ex_attn = nullptr);
-// the strip-resident kernel keeps 32 query rows x ALL keys of an image in registers: at most 8 waves x 5 key tiles of 32
-bool excel_attn_strip_supported(int N);
-int excel_launch_attn_strip(const unsigned short* qkvs, unsigned short* a_sum, float* w_aff, float* attn_out, int B, int H, int N,
-                            int KP, int hd, float scale, int surgery, float w_scale, float aff_scale, int aff_init, const float* ex_attn,
-                            hipStream_t st);
-int excel_launch_cam_epilogue(float* S, float* out_full, float* out_slice, int B, int N, int T, int ldS, int F, float temp,
-                              hipStream_t st);
-size_t excel_patch_text_cam_ws_floats(int B, int N, int C, int T, int which);     // which: 0 sim, 1 min/max partials, 2 column-norm partials
-int excel_launch_patch_text_cam(const float* x_raw, const float* text, unsigned short* text_split_out, float* sim_ws, float* part_ws,
-                                float* colsq_ws, float* out_full, float* out_slice, float* feats, int B, int N, int C, int T, int F, int ldT,
-                                float temp, int bf, hipStream_t st);
 int excel_launch_trans_mat_sym(const float* W, float* T, float* Tsym, float* cs, int B, int P, hipStream_t st);
 int excel_launch_cls_compact(const float* onehot, int B, int F, int Smax, int* cls_idx, int* ncls, int* nchan, hipStream_t st);
 int excel_launch_bbox_mask(const float* attr, const int* cls_idx, const int* ncls, int B, int g, int F, int Smax, double thre,
@@ -126,3 +99,18 @@ int excel_launch_feature_affinity(const float* feats, int B, int C, int P, float
 size_t excel_attn_select_ws_bytes(int B, int n_layers);
 int excel_launch_attn_select_mean(const float* attn, int Lw, int B, int N, int first_layer, int n_layers, const float* seg_attn,
                                   float* out, void* ws, hipStream_t st);
+
+// ---------------------------------------------------------------- the split-type dependent launchers, once per 16-bit type
+namespace excel_bf16 {
+#include "excel_split_api.inc"
+}
+namespace excel_f16 {
+#include "excel_split_api.inc"
+}
+#ifdef EXCEL_SPLIT_F16
+#define EXCEL_SPLIT_NS excel_f16
+#else
+#define EXCEL_SPLIT_NS excel_bf16
+#endif
+// unqualified calls (decoder.hip, lvc.hip, train.hip, ...: exact-fp32 paths that never write split planes) mean the bf16 build
+using namespace excel_bf16;

@@ -15,6 +15,8 @@
 #include "common.h"
 #include "excel_internal.h"
 
+namespace EXCEL_SPLIT_NS {     // compiled once per 16-bit split type (excel_internal.h, build.py)
+
 #define BM 128
 #define BN 128
 #define BK 32
@@ -175,11 +177,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
                 if (p.out_mode == GEMM_OUT_SPLIT_BF16) {
                     // split-bf16 output [rows][2][ldc]: plane width ldc, z2 offsets columns (in bf16 elements)
                     // (z2 offsets columns by sC2 elements of the logical row; blocked hi/lo layout, see split_off)
-                    __bf16* o = reinterpret_cast<__bf16*>(p.C + (long long)z1 * p.sC) + (long long)row * 2 * p.ldc +
+                    split_t* o = reinterpret_cast<split_t*>(p.C + (long long)z1 * p.sC) + (long long)row * 2 * p.ldc +
                                 split_off((int)(z2 * p.sC2) + col, 0);
-                    const __bf16 hi = (__bf16)v;
+                    const split_t hi = (split_t)v;
                     o[0] = hi;
-                    o[32] = (__bf16)(v - (float)hi);
+                    o[32] = (split_t)(v - (float)hi);
                 } else if (p.out_mode == GEMM_OUT_QKV_HEADMAJOR) {
                     const int b = row / p.tokN, n = row % p.tokN;
                     C[((((long long)b * 3 + qt) * p.heads + qh) * p.tokN + n) * p.hd + qd] = v;
@@ -212,3 +214,5 @@ int excel_launch_gemm(const GemmArgs& p, bool b_kmajor, int batch, hipStream_t s
     EXCEL_CHECK_LAUNCH("gemm_f32");
     return EXCEL_OK;
 }
+
+}  // namespace EXCEL_SPLIT_NS

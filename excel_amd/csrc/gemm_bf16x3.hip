@@ -24,7 +24,8 @@
 #include "common.h"
 #include "excel_internal.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+namespace EXCEL_SPLIT_NS {     // compiled once per 16-bit split type (excel_internal.h, build.py)
+
 typedef unsigned short u16;
 
 #define TBM 128
@@ -65,20 +66,20 @@ __device__ __forceinline__ void bf_epilogue(const GemmBfArgs& p, const f32x16 (&
                 if (p.act == GEMM_ACT_QUICKGELU) v = v * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v));
                 if (p.res) v += p.res[(long long)row * p.ldr + col];
                 if (OUT_MODE == GEMM_OUT_SPLIT_BF16) {
-                    const __bf16 hi = (__bf16)v;
-                    __bf16* o = reinterpret_cast<__bf16*>(p.Cs) + (long long)row * 2 * p.N + split_off(col, 0);
+                    const split_t hi = (split_t)v;
+                    split_t* o = reinterpret_cast<split_t*>(p.Cs) + (long long)row * 2 * p.N + split_off(col, 0);
                     o[0] = hi;
-                    o[32] = (__bf16)(v - (float)hi);
+                    o[32] = (split_t)(v - (float)hi);
                 } else if (OUT_MODE == GEMM_OUT_QKV_HEADMAJOR) {
                     int n = qn + dr, b = qb;
                     while (n >= p.tokN) { n -= p.tokN; ++b; }
                     const long long off = qcol_off + ((long long)b * 3 * p.heads * p.tokN + n) * p.hd;
                     if (!p.qkv_split) p.C[off] = v;
                     if (p.qkv_split) {     // same (b,type,head,n) row, [hi hd | lo hd] bf16: operand of the bf16x3 attention scores
-                        __bf16* o = reinterpret_cast<__bf16*>(p.qkv_split) + (off - qd) * 2 + qd;
-                        const __bf16 hi = (__bf16)v;
+                        split_t* o = reinterpret_cast<split_t*>(p.qkv_split) + (off - qd) * 2 + qd;
+                        const split_t hi = (split_t)v;
                         o[0] = hi;
-                        o[p.hd] = (__bf16)(v - (float)hi);
+                        o[p.hd] = (split_t)(v - (float)hi);
                     }
                 } else {
                     p.C[(long long)row * p.ldc + col] = v;
@@ -132,11 +133,11 @@ __device__ __forceinline__ void bf_epilogue_lds(const GemmBfArgs& p, const f32x1
             if (OUT_MODE == GEMM_OUT_PLAIN) {
                 *reinterpret_cast<f32x4*>(p.C + (long long)row * p.ldc + col) = v;
             } else {
-                __bf16 hi[4], lo[4];
+                split_t hi[4], lo[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { hi[q] = (__bf16)v[q]; lo[q] = (__bf16)(v[q] - (float)hi[q]); }
+                for (int q = 0; q < 4; ++q) { hi[q] = (split_t)v[q]; lo[q] = (split_t)(v[q] - (float)hi[q]); }
                 if (OUT_MODE == GEMM_OUT_SPLIT_BF16) {
-                    __bf16* o = reinterpret_cast<__bf16*>(p.Cs) + (long long)row * 2 * p.N + split_off(col, 0);
+                    split_t* o = reinterpret_cast<split_t*>(p.Cs) + (long long)row * 2 * p.N + split_off(col, 0);
                     *reinterpret_cast<uint2*>(o) = *reinterpret_cast<const uint2*>(hi);
                     *reinterpret_cast<uint2*>(o + 32) = *reinterpret_cast<const uint2*>(lo);
                 } else {   // q|k|v head-major: fp32 for P.V / A.V, and [hi hd | lo hd] bf16 for the bf16x3 scores
@@ -145,7 +146,7 @@ __device__ __forceinline__ void bf_epilogue_lds(const GemmBfArgs& p, const f32x1
                     // the fp32 copy is not consumed when the split copy exists (bf16x3 attention; V^T is cut from the split planes)
                     if (!p.qkv_split) *reinterpret_cast<f32x4*>(p.C + rowidx * p.hd + qd) = v;
                     if (p.qkv_split) {
-                        __bf16* o = reinterpret_cast<__bf16*>(p.qkv_split) + rowidx * 2 * p.hd + qd;
+                        split_t* o = reinterpret_cast<split_t*>(p.qkv_split) + rowidx * 2 * p.hd + qd;
                         *reinterpret_cast<uint2*>(o) = *reinterpret_cast<const uint2*>(hi);
                         *reinterpret_cast<uint2*>(o + p.hd) = *reinterpret_cast<const uint2*>(lo);
                     }
@@ -262,38 +263,38 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16x3_kernel(GemmBfArgs
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             const int ch = ((s2 * 2 + kh) ^ sw) * 8, cl = ((4 + s2 * 2 + kh) ^ sw) * 8;
-            bf16x8 bh[2], bl[2];
+            splitx8 bh[2], bl[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const u16* rowp = bs + (wn * 64 + j * 32 + r) * TROW;
-                bh[j] = *reinterpret_cast<const bf16x8*>(rowp + ch);
-                bl[j] = *reinterpret_cast<const bf16x8*>(rowp + cl);
+                bh[j] = *reinterpret_cast<const splitx8*>(rowp + ch);
+                bl[j] = *reinterpret_cast<const splitx8*>(rowp + cl);
             }
             if (TI <= 4) {
-                bf16x8 ah[TI], al[TI];
+                splitx8 ah[TI], al[TI];
 #pragma unroll
                 for (int i = 0; i < TI; ++i) {
                     const u16* rowp = as + (wm * (TI * 32) + i * 32 + r) * TROW;
-                    ah[i] = *reinterpret_cast<const bf16x8*>(rowp + ch);
-                    al[i] = *reinterpret_cast<const bf16x8*>(rowp + cl);
+                    ah[i] = *reinterpret_cast<const splitx8*>(rowp + ch);
+                    al[i] = *reinterpret_cast<const splitx8*>(rowp + cl);
                 }
 #pragma unroll
                 for (int i = 0; i < TI; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         // small terms first, the dominant hi.hi product last
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = EXCEL_MFMA16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = EXCEL_MFMA16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = EXCEL_MFMA16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                     }
             } else {
                 // register-tight variant (TI*2*16 accumulator registers leave < 100 for everything else): A fragments
                 // are streamed one row tile ahead instead of all at once, and the scheduler may not hoist them
-                bf16x8 ah[2], al[2];
+                splitx8 ah[2], al[2];
                 {
                     const u16* rowp = as + (wm * wm_rows + r) * TROW;
-                    ah[0] = *reinterpret_cast<const bf16x8*>(rowp + ch);
-                    al[0] = *reinterpret_cast<const bf16x8*>(rowp + cl);
+                    ah[0] = *reinterpret_cast<const splitx8*>(rowp + ch);
+                    al[0] = *reinterpret_cast<const splitx8*>(rowp + cl);
                 }
 #pragma unroll
                 for (int i = 0; i < TI; ++i) {
@@ -301,14 +302,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16x3_kernel(GemmBfArgs
                     if (MIX && i >= nti) continue;                  // short tile: this wave has TI - 1 row tiles (the DMA piece above still goes out)
                     if (i + 1 < TI && (!MIX || i + 1 < nti)) {
                         const u16* rowp = as + (wm * wm_rows + (i + 1) * 32 + r) * TROW;
-                        ah[(i + 1) & 1] = *reinterpret_cast<const bf16x8*>(rowp + ch);
-                        al[(i + 1) & 1] = *reinterpret_cast<const bf16x8*>(rowp + cl);
+                        ah[(i + 1) & 1] = *reinterpret_cast<const splitx8*>(rowp + ch);
+                        al[(i + 1) & 1] = *reinterpret_cast<const splitx8*>(rowp + cl);
                     }
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i & 1], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i & 1], bl[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i & 1], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = EXCEL_MFMA16(al[i & 1], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = EXCEL_MFMA16(ah[i & 1], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = EXCEL_MFMA16(ah[i & 1], bh[j], acc[i][j], 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -319,9 +320,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16x3_kernel(GemmBfArgs
     if (EXCEL_DBG(p.dbg) & 4) {
         // dev arm "MFMA only": the kernel's own MFMA count per k-step, operands in registers, no LDS, no DMA, no barrier - the
         // power-limited ceiling of this instruction mix on this part (profiles/r03_gemm_ceiling.json)
-        bf16x8 fa, fb;
+        splitx8 fa, fb;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { fa[q] = (__bf16)(0.001f * (float)(lane + q)); fb[q] = (__bf16)(0.002f * (float)(lane ^ q)); }
+        for (int q = 0; q < 8; ++q) { fa[q] = (split_t)(0.001f * (float)(lane + q)); fb[q] = (split_t)(0.002f * (float)(lane ^ q)); }
         for (int kt = 0; kt < nk; ++kt)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
@@ -329,9 +330,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16x3_kernel(GemmBfArgs
                 for (int i = 0; i < TI; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, fa, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fa, acc[i][j], 0, 0, 0);
+                        acc[i][j] = EXCEL_MFMA16(fb, fa, acc[i][j], 0, 0, 0);
+                        acc[i][j] = EXCEL_MFMA16(fa, fb, acc[i][j], 0, 0, 0);
+                        acc[i][j] = EXCEL_MFMA16(fa, fa, acc[i][j], 0, 0, 0);
                     }
     } else if (NSTAGE == 2) {
         issue_tile(0, 0);
@@ -390,13 +391,13 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
     const long long row = i / K;
     const int k = (int)(i % K);
     const f32x4 v = *reinterpret_cast<const f32x4*>(in + i);
-    __bf16 hi[4], lo[4];
+    split_t hi[4], lo[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        hi[j] = (__bf16)v[j];
-        lo[j] = (__bf16)(v[j] - (float)hi[j]);
+        hi[j] = (split_t)v[j];
+        lo[j] = (split_t)(v[j] - (float)hi[j]);
     }
-    __bf16* o = reinterpret_cast<__bf16*>(out) + row * 2 * K + split_off(k, 0);
+    split_t* o = reinterpret_cast<split_t*>(out) + row * 2 * K + split_off(k, 0);
     *reinterpret_cast<uint2*>(o) = *reinterpret_cast<const uint2*>(hi);
     *reinterpret_cast<uint2*>(o + 32) = *reinterpret_cast<const uint2*>(lo);
 }
@@ -530,3 +531,5 @@ int excel_launch_split_bf16(const float* in, void* out, long long R, int K, hipS
     EXCEL_CHECK_LAUNCH("split_bf16");
     return EXCEL_OK;
 }
+
+}  // namespace EXCEL_SPLIT_NS

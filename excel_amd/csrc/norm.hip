@@ -6,6 +6,8 @@
 #include "common.h"
 #include "excel_internal.h"
 
+namespace EXCEL_SPLIT_NS {     // compiled once per 16-bit split type (excel_internal.h, build.py)
+
 __device__ __forceinline__ void ln_row(const float* __restrict__ src, const float* __restrict__ add,
                                        const float* __restrict__ w, const float* __restrict__ b,
                                        float* __restrict__ dst, int D, float eps, int lane, bool split = false) {
@@ -33,10 +35,10 @@ __device__ __forceinline__ void ln_row(const float* __restrict__ src, const floa
         const f32x4 bb = *reinterpret_cast<const f32x4*>(b + c);
         v = (v - mean) * rstd * ww + bb;
         if (split) {   // bf16 hi/lo planes [2][D] in the same D*4 bytes (operand format of the bf16x3 GEMM)
-            __bf16 hi[4], lo[4];
+            split_t hi[4], lo[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { hi[j] = (__bf16)v[j]; lo[j] = (__bf16)(v[j] - (float)hi[j]); }
-            __bf16* o = reinterpret_cast<__bf16*>(dst);
+            for (int j = 0; j < 4; ++j) { hi[j] = (split_t)v[j]; lo[j] = (split_t)(v[j] - (float)hi[j]); }
+            split_t* o = reinterpret_cast<split_t*>(dst);
             *reinterpret_cast<uint2*>(o + split_off(c, 0)) = *reinterpret_cast<const uint2*>(hi);
             *reinterpret_cast<uint2*>(o + split_off(c, 1)) = *reinterpret_cast<const uint2*>(lo);
         } else {
@@ -75,10 +77,10 @@ __device__ __forceinline__ void ln_row_reg(const float* __restrict__ src, const 
         const f32x4 bb = *reinterpret_cast<const f32x4*>(b + c);
         const f32x4 o4 = v[i] * rstd * ww + bb;
         if (split) {
-            __bf16 hi[4], lo[4];
+            split_t hi[4], lo[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { hi[j] = (__bf16)o4[j]; lo[j] = (__bf16)(o4[j] - (float)hi[j]); }
-            __bf16* o = reinterpret_cast<__bf16*>(dst);
+            for (int j = 0; j < 4; ++j) { hi[j] = (split_t)o4[j]; lo[j] = (split_t)(o4[j] - (float)hi[j]); }
+            split_t* o = reinterpret_cast<split_t*>(dst);
             *reinterpret_cast<uint2*>(o + split_off(c, 0)) = *reinterpret_cast<const uint2*>(hi);
             *reinterpret_cast<uint2*>(o + split_off(c, 1)) = *reinterpret_cast<const uint2*>(lo);
         } else {
@@ -164,10 +166,10 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ i
     const int c = k / (ps * ps), py = (k / ps) % ps, px = k % ps;   // px multiple of 4
     const f32x4 v = *reinterpret_cast<const f32x4*>(img + (((long long)b * 3 + c) * S + gy * ps + py) * S + gx * ps + px);
     if (split_out) {
-        __bf16 hi[4], lo[4];
+        split_t hi[4], lo[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { hi[j] = (__bf16)v[j]; lo[j] = (__bf16)(v[j] - (float)hi[j]); }
-        __bf16* o = reinterpret_cast<__bf16*>(col) + pr * 2 * Kc + split_off(k, 0);
+        for (int j = 0; j < 4; ++j) { hi[j] = (split_t)v[j]; lo[j] = (split_t)(v[j] - (float)hi[j]); }
+        split_t* o = reinterpret_cast<split_t*>(col) + pr * 2 * Kc + split_off(k, 0);
         *reinterpret_cast<uint2*>(o) = *reinterpret_cast<const uint2*>(hi);
         *reinterpret_cast<uint2*>(o + 32) = *reinterpret_cast<const uint2*>(lo);
     } else {
@@ -213,3 +215,5 @@ int excel_launch_im2col(const float* img, float* col, int B, int S, int ps, hipS
     EXCEL_CHECK_LAUNCH("im2col");
     return EXCEL_OK;
 }
+
+}  // namespace EXCEL_SPLIT_NS

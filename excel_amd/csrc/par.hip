@@ -221,6 +221,8 @@ __global__ __launch_bounds__(512, 4) void par_iterate_guide_kernel(const float* 
         const int plane_off = (is_g ? p : p - 3) * (int)(HW * 4);
         unsigned dst = tile_b + (buf * TR + wave * RPW) * (TP * 4);
         asm volatile("" : "+s"(dst));
+        // dev arm (timing only, wrong results): stage 48 of the 64 rows = roughly the +-12-pixel apron of the round-3 review's proposal
+        if ((EXCEL_DBG(dbg) & 8) && (wave == 0 || wave == 7)) return;
         if (interior) {
             int half = lane >> 5;                                // opaque: the per-lane source offsets are recomputed per plane (hoisted out of
             asm volatile("" : "+v"(half));                       // the plane loops they were live across the weight registers and spilled)
@@ -297,6 +299,20 @@ __global__ __launch_bounds__(512, 4) void par_iterate_guide_kernel(const float* 
         });
     };
 
+    // dev arm (timing only): what reading the eight d = 24 taps of a plane from global / L2 instead of LDS would ADD - 8 edge-clamped
+    // float2 loads per thread per plane, summed into the result
+    auto far_taps = [&](const float* plane) -> f32x2 {
+        f32x2 sum = {0.f, 0.f};
+        const int yu = max(py - 24, 0), yd = min(py + 24, H - 1), ym = min(py, H - 1);
+        const int xl = max(min(px, Wp - 2) - 24, 0), xr = min(min(px, Wp - 2) + 24, Wp - 2), xm = min(px, Wp - 2);
+        const int ys[8] = {yu, yu, yu, ym, ym, yd, yd, yd}, xs[8] = {xl, xm, xr, xl, xr, xl, xm, xr};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float2 v = *reinterpret_cast<const float2*>(plane + (long long)ys[k] * Wp + (xs[k] & ~1));
+            sum += f32x2{v.x, v.y};
+        }
+        return sum;
+    };
     const int np = 3 + nch;
     stage(0, 0);
 #pragma unroll 1
@@ -311,6 +327,7 @@ __global__ __launch_bounds__(512, 4) void par_iterate_guide_kernel(const float* 
         f32x2 ctr;
         asm volatile("ds_read_b64 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(ctr) : "v"(org + (p & 1) * (TR * TP * 4)), "n"((HALO * TP + HALO) * 4) : "memory");
         f32x2 nctr = -ctr;
+        if (EXCEL_DBG(dbg) & 16) nctr += 1e-30f * far_taps(guide + 3 * tg.base + (long long)p * HW);
         asm volatile("" : "+v"(nctr));
         taps(p & 1, [&](int di, int k, const f32x2 nb) {
             const f32x2 dv = nb + nctr;
@@ -340,6 +357,7 @@ __global__ __launch_bounds__(512, 4) void par_iterate_guide_kernel(const float* 
         if (p + 1 < np) stage(p + 1, (p + 1) & 1);
         if (EXCEL_DBG(dbg) & 4) continue;
         f32x2 acc = {0.f, 0.f};
+        if (EXCEL_DBG(dbg) & 16) acc = 1e-30f * far_taps(in + (long long)Cmax * tg.base + (long long)(p - 3) * HW);
         // (acc is pinned per tap row: it is only stored under `valid`, and the whole fma chain was otherwise sunk into that branch,
         //  behind all 50 reads of the plane)
         taps(p & 1, [&](int di, int k, const f32x2 nb) { acc = __builtin_elementwise_fma(nb, wall[di][k], acc); },   // tap order, fused
@@ -377,6 +395,8 @@ __global__ __launch_bounds__(512, 4) void par_stats_tile_kernel(const float* __r
         const int plane_off = p * (int)(HW * 4);
         unsigned dst = tile_b + (buf * TR + wave * RPW) * (TP * 4);
         asm volatile("" : "+s"(dst));
+        // dev arm (timing only, wrong results): stage 48 of the 64 rows = roughly the +-12-pixel apron of the round-3 review's proposal
+        if ((EXCEL_DBG(dbg) & 8) && (wave == 0 || wave == 7)) return;
         if (interior) {
             int half = lane >> 5;
             asm volatile("" : "+v"(half));

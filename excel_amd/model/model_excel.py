@@ -118,26 +118,33 @@ class ExCEL_model:
     __call__ = forward
 
     def check_numerics(self, img, tol=5e-4, fallback=True):
-        """Guard of the default "bf16x3" matrix-core mode on the caller's OWN weights and images.  bf16x3 carries 16 mantissa bits per
-        operand; measured against a float64 run of the oracle its CAM error is ~14x that of fp32 arithmetic.  On benign networks
-        that is 1e-5 (gate 1e-3); on an ill-conditioned network (massive-activation channels + near-one-hot attention rows:
-        tests/test_gpu_ops.py::test_vit_b16_448_clip_like_outlier_net) fp32 itself sits at 2e-4 and bf16x3 exceeds the gate.  This
-        runs ViT + CAM of `img` [b,3,S,S] in the current mode and in exact fp32 ("f32") and compares the attr maps - the quantity the
-        gate is stated on.  -> {"max_abs_diff", "tol", "mode_before", "mode_after"}; with `fallback`, a difference above `tol` (half
-        the gate by default) switches this model to exact fp32 for everything that follows."""
+        """Guard of the fast matrix-core modes on the caller's OWN weights and images.  "bf16x3" carries 16 mantissa bits per operand:
+        measured against a float64 run of the oracle its CAM error is ~12x that of fp32 arithmetic - 1e-5 on well-conditioned networks
+        (gate 1e-3), but on an ill-conditioned one (massive-activation channels + near-one-hot attention rows:
+        tests/test_gpu_ops.py::test_vit_b16_448_clip_like_outlier_net) fp32 itself sits at 2e-4 and bf16x3 exceeds the gate; "f16x3"
+        (IEEE-half planes, 22 bits) stays within 1.4x of fp32 there at ~2.5 % less throughput.  This runs ViT + CAM of `img`
+        [b,3,S,S] in the current mode and in exact fp32 ("f32") and compares the attr maps - the quantity the gate is stated on.
+        With `fallback`, a difference above `tol` (half the gate by default) moves this model one step down the ladder
+        bf16x3 -> f16x3 -> f32 (re-checked at every step) for everything that follows.
+        -> {"max_abs_diff" (of the mode it started in), "tol", "mode_before", "mode_after", "ladder": [(mode, diff), ...]}"""
         h = self.encoder.visual.handle()
         before = h.gemm_mode()
         if before == "f32":
-            return {"max_abs_diff": 0.0, "tol": tol, "mode_before": before, "mode_after": before}
-        fast = self.forward(img)[2].clone()
+            return {"max_abs_diff": 0.0, "tol": tol, "mode_before": before, "mode_after": before, "ladder": []}
         h.set_gemm_mode("f32")
         try:
-            exact = self.forward(img)[2]
-            diff = float((fast - exact).abs().max())
+            exact = self.forward(img)[2].clone()
         finally:
             h.set_gemm_mode(before)
-        after = before
-        if not (diff <= tol) and fallback:              # (NaN compares false: falls back too)
-            h.set_gemm_mode("f32")
+        ladder, after = [], before
+        for mode in (["bf16x3", "f16x3"] if before == "bf16x3" else [before]):
+            h.set_gemm_mode(mode)
+            diff = float((self.forward(img)[2] - exact).abs().max())
+            ladder.append((mode, diff))
+            after = mode
+            if diff <= tol or not fallback:              # (NaN compares false: moves on)
+                break
+        else:
             after = "f32"
-        return {"max_abs_diff": diff, "tol": tol, "mode_before": before, "mode_after": after}
+        h.set_gemm_mode(after if fallback else before)
+        return {"max_abs_diff": ladder[0][1], "tol": tol, "mode_before": before, "mode_after": after if fallback else before, "ladder": ladder}

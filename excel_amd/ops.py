@@ -54,21 +54,27 @@ def gemm(A, Bm, bias=None, residual=None, act=0, b_kmajor=True):
     return out if batched else out[0]
 
 
-def split_bf16(x):
-    """fp32 [R,K] -> split operand [R,2,K] (bf16 bit patterns in an int16 tensor)."""
+GEMM_MODES = {"f32": 0, "bf16x3": 1, "f16x3": 2}      # excel_vit_set_gemm_mode (include/excel_hip.h)
+
+
+def split_bf16(x, f16=False):
+    """fp32 [R,K] -> split operand [R,2,K] (bf16 - or, with f16, IEEE-half - bit patterns in an int16 tensor)."""
     x = f32c(x)
     R, K = x.shape
     out = torch.empty((R, 2, K), dtype=torch.int16, device=x.device)
-    check(lib().excel_split_bf16(_p(x), _p(out, torch.int16), R, K, _stream()), "excel_split_bf16")
+    fn = lib().excel_split_f16 if f16 else lib().excel_split_bf16
+    check(fn(_p(x), _p(out, torch.int16), R, K, _stream()), "excel_split_f16" if f16 else "excel_split_bf16")
     return out
 
 
-def gemm_bf16x3(A_split, W_split, bias=None, residual=None, act=0, split_out=False):
+def gemm_bf16x3(A_split, W_split, bias=None, residual=None, act=0, split_out=False, f16=False):
+    """C = act(A . W^T + bias) + residual from two split operands (three 16-bit MFMAs per product); f16: IEEE-half planes (split_bf16(f16=True))."""
     M, _, K = A_split.shape
     N = W_split.shape[0]
     out = torch.empty((M, N), dtype=torch.float32, device=A_split.device)
-    check(lib().excel_gemm_bf16x3(_p(A_split, torch.int16), _p(W_split, torch.int16), _p(out), _p(bias), _p(residual), M, N, K, act,
-                                  1 if split_out else 0, _stream()), "excel_gemm_bf16x3")
+    fn = lib().excel_gemm_f16x3 if f16 else lib().excel_gemm_bf16x3
+    check(fn(_p(A_split, torch.int16), _p(W_split, torch.int16), _p(out), _p(bias), _p(residual), M, N, K, act,
+             1 if split_out else 0, _stream()), "excel_gemm_f16x3" if f16 else "excel_gemm_bf16x3")
     return out.view(torch.int16).view(M, 2, N) if split_out else out
 
 
@@ -130,9 +136,10 @@ class VitHandle:
         with torch.cuda.device(self.device):
             check(lib().excel_vit_create(C.byref(cfg), C.byref(w), C.byref(self._h)), "excel_vit_create")
             # numerics of the linear layers and attention scores: "bf16x3" (default; fp32 operands as bf16 hi+lo, 3 bf16
-            # MFMAs per product, CAM error ~1e-5 against exact fp32) or "f32" (exact fp32 MFMA).  EXCEL_GEMM_MODE overrides.
+            # MFMAs per product, CAM error ~1e-5 against exact fp32 on well-conditioned weights), "f16x3" (IEEE-half planes: fp32-grade
+            # results, ~2.5 % slower) or "f32" (exact fp32 MFMA).  EXCEL_GEMM_MODE overrides.
             mode = gemm_mode or os.environ.get("EXCEL_GEMM_MODE", "bf16x3")
-            if mode == "bf16x3" and (width % 32 or (3 * patch * patch) % 32):
+            if mode != "f32" and (width % 32 or (3 * patch * patch) % 32):
                 mode = "f32"
             self.set_gemm_mode(mode)
         self._ws = {}          # one workspace per launch stream: the same weights can serve concurrent streams
@@ -146,11 +153,11 @@ class VitHandle:
             pass
 
     def set_gemm_mode(self, mode):
-        """'f32' (exact fp32 MFMA) or 'bf16x3' (split-bf16 operands, 3 bf16 MFMAs per product)."""
-        check(lib().excel_vit_set_gemm_mode(self._h, {"f32": 0, "bf16x3": 1}[mode]), "excel_vit_set_gemm_mode")
+        """'f32' (exact fp32 MFMA), 'bf16x3' (split-bf16 operands, 3 bf16 MFMAs per product) or 'f16x3' (IEEE-half planes)."""
+        check(lib().excel_vit_set_gemm_mode(self._h, GEMM_MODES[mode]), "excel_vit_set_gemm_mode")
 
     def gemm_mode(self):
-        return {0: "f32", 1: "bf16x3"}[lib().excel_vit_get_gemm_mode(self._h)]
+        return {v: k for k, v in GEMM_MODES.items()}[lib().excel_vit_get_gemm_mode(self._h)]
 
     def workspace(self, B, S):
         need = lib().excel_vit_workspace_bytes(self._h, B, S)
@@ -522,7 +529,7 @@ def patch_text_cam(x_raw, text_features, num_fg=None, t=2.0, want_full=False, wa
     if full is None and sl is None:
         raise ValueError("patch_text_cam: nothing to compute (want_full=False and num_fg=None)")
     ws = _ws(lib().excel_patch_text_cam_workspace_bytes(B, N, Cc, T), dev)
-    check(lib().excel_patch_text_cam(_p(x_raw), _p(text_features), B, N, Cc, T, F_, float(t), 1 if mode == "bf16x3" else 0, _p(full), _p(sl),
+    check(lib().excel_patch_text_cam(_p(x_raw), _p(text_features), B, N, Cc, T, F_, float(t), GEMM_MODES[mode], _p(full), _p(sl),
                                      _p(feats), _p(ws, torch.uint8), _stream()), "excel_patch_text_cam")
     return full, sl, feats
 

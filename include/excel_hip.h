@@ -47,6 +47,11 @@ int excel_gemm_f32(const float* A, const float* Bm, float* C, const float* bias,
 int excel_split_bf16(const float* in, void* out, long long rows, int K, void* stream);
 int excel_gemm_bf16x3(const void* A_split, const void* W_split, float* C, const float* bias, const float* residual,
                       int M, int N, int K, int act, int split_out, void* stream);
+/* The same two building blocks with IEEE-half planes ("f16x3": hi = half(x), lo = half(x - hi); 11 + 11 mantissa bits where lo stays
+ * a normal half, range 65 504; v_mfma_f32_32x32x16_f16, same layouts and rate). */
+int excel_split_f16(const float* in, void* out, long long rows, int K, void* stream);
+int excel_gemm_f16x3(const void* A_split, const void* W_split, float* C, const float* bias, const float* residual,
+                     int M, int N, int K, int act, int split_out, void* stream);
 
 /* LayerNorm over the last dim, fp32, eps as given (clip/clip_surgery_model.py:271-277). */
 int excel_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int D, float eps, void* stream);
@@ -86,9 +91,15 @@ typedef struct excel_vit* excel_vit_t;
 int excel_vit_create(const excel_vit_config* cfg, const excel_vit_weights* w, excel_vit_t* out);
 void excel_vit_destroy(excel_vit_t h);
 
-/* GEMM numerics of the linear layers of this handle: 0 = exact fp32 (v_mfma_f32_32x32x2_f32), 1 = "bf16x3" (operands as
- * bf16 hi+lo planes, 3 bf16 MFMAs per product, ~2^-17 relative per product; CAM moves < 1e-5).
- * Default 0, or 1 when the environment variable EXCEL_GEMM_MODE=bf16x3 is set at create time. */
+/* GEMM numerics of the linear layers (and attention products) of this handle:
+ *   0 = exact fp32 (v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak);
+ *   1 = "bf16x3": operands as bf16 hi+lo planes, 3 bf16 MFMAs per product, 16 mantissa bits per operand at the fp32 exponent range -
+ *       the fastest mode; its CAM error is ~12x that of fp32 arithmetic (1e-5 on well-conditioned weights);
+ *   2 = "f16x3": the same scheme on IEEE-half planes (22 mantissa bits where lo stays normal): fp32-grade results (within 1.4x of fp32
+ *       arithmetic's own error on every network measured), ~2.5 % slower than mode 1 (the part is power-limited), values beyond 65 504
+ *       overflow.
+ * Default 0, or the mode named by the environment variable EXCEL_GEMM_MODE (bf16x3 | f16x3) at create time.  Switching between 1 and
+ * 2 re-splits the weights (synchronises the device). */
 int excel_vit_set_gemm_mode(excel_vit_t h, int mode);
 int excel_vit_get_gemm_mode(excel_vit_t h);
 
@@ -243,7 +254,7 @@ int excel_clip_feature_surgery(const float* image_features, const float* text, i
  * launches, each over the whole chip: column sums of squares in image-aligned row blocks (fixed order: an image's maps do not depend
  * on its position in the batch), the similarity tiles (one wave per 32-token tile, >= 7 workgroups per image), and the min-max
  * normalisation over a two-stage (exact) min / max reduction.
- *   mode 1: bf16x3 (fp32 operands as bf16 hi+lo, 3 MFMAs per product), mode 0: exact fp32 MFMA.
+ *   mode 1: bf16x3 (fp32 operands as bf16 hi+lo, 3 MFMAs per product), mode 2: f16x3 (IEEE-half planes), mode 0: exact fp32 MFMA.
  *   image_features [B,N,C] (optional): the normalised features generate_clip_fts returns.
  * T <= 128, C % 32 == 0, C <= 1024; x_raw, text, image_features and the workspace 16-byte aligned. */
 size_t excel_patch_text_cam_workspace_bytes(int B, int N, int C, int T);

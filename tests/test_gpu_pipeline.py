@@ -1002,6 +1002,38 @@ def test_infer_lam_data_folder_runs_ragged_batches_of_32(gpu, tmp_path):
     assert np.array_equal(host(t_any), host(crf_total))
 
 
+def test_batched_pipeline_tiny_f16x3_mode_vs_oracle(gpu):
+    """The third matrix-core mode through the whole batched chain: "f16x3" (IEEE-half split planes) - CAMs, refined maps and labels of
+    the tiny net against the oracle at the exact mode's tolerances (its results are fp32-grade), integer-exact histogram on equal labels."""
+    from excel_amd.pipeline import TrainingFreePipeline
+    rs = np.random.RandomState(78)
+    text = rs.standard_normal((9, 64)).astype(np.float32)
+    text /= np.linalg.norm(text, axis=1, keepdims=True)
+    model, w = tiny_model(text.T.copy(), gemm_mode="f16x3")
+    assert model.encoder.visual.handle().gemm_mode() == "f16x3"
+    wo = oracle.vit.reload_self_attn(w, TINY, 6, "train")
+    B, S, F = 3, 96, 4
+    imgs = rs.standard_normal((B, 3, S, S)).astype(np.float32)
+    gts = rs.randint(0, 5, (B, S, S)).astype(np.uint8)
+    cls = np.zeros((B, F), np.float32)
+    for b, c in enumerate([[0, 3], [1], [2, 1, 0]]):
+        cls[b, c] = 1
+    pipe = TrainingFreePipeline(model, num_classes=5, smax=4)
+    labels, inter = pipe.run_batch(dev(imgs), dev(cls), dev(gts), return_intermediates=True)
+    ref = _oracle_batch(imgs, gts, cls, wo, TINY, text.T.copy(), F, S)
+    lab = host(labels)
+    ref_hist = np.zeros((5, 5), np.int64)
+    for b in range(B):
+        k = int(cls[b].sum())
+        assert maxabs(host(inter["attr"])[b], ref[b]["attr_maps_raw"][0]) < 2e-4
+        assert maxabs(host(inter["cams"])[b, :k + 1], ref[b]["cams"]) < 1e-3
+        assert int((lab[b] != ref[b]["label"]).sum()) <= _label_budget(lab[b].size, "f32") + 4
+        ref_hist += oracle.evaluate.fast_hist(gts[b].flatten(), lab[b].flatten(), 5)
+    assert np.array_equal(host(pipe.hist), ref_hist)
+    res = model.check_numerics(dev(imgs))
+    assert res["mode_after"] == "f16x3" and res["max_abs_diff"] < 5e-4
+
+
 def test_device_feeder_hands_out_batches_and_closes(gpu):
     """datasets/loader.DeviceFeeder: the device tensors it hands out equal the host batches; leaving the loop early (break) or dropping
     the feeder right after the last batch stops the staging thread and waits for the consumer's kernels before the ring is freed
