@@ -406,9 +406,12 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
 // A_sum . V GEMM, cut from the split q|k|v the QKV epilogue wrote (rows [hi 64 | lo 64] of v): a pure 16-bit transpose.  Since round 3 only the surgery blocks' A_sum.V GEMM needs it (the row pass reads V
 // row-major through the LDS transpose read).
 __global__ __launch_bounds__(256) void vt_from_planes_kernel(const u16* __restrict__ qkvs, u16* __restrict__ vt, int H, int N, int KP) {
-    // 64 tokens x [hi 64 | lo 64] u16 as 64 dwords per row, pitch 65: the 4-byte writes of the load phase (row m, chunk c8: bank m + 4 c8 + k)
-    // and the 4-byte reads of the transpose phase (row 4 g4 + j, d pair: bank 4 g4 + j + dpair) are conflict-free (rounds 1-2 read single
-    // u16 down the rows of a 136-u16 pitch: LDS conflict rate 0.82)
+    // 64 tokens x [hi 64 | lo 64] u16 as 64 dwords per row, pitch 65.  Both phases keep a 2-way LDS bank conflict (SQ_LDS_BANK_CONFLICT /
+    // SQ_LDS_IDX_ACTIVE = 0.49 in profiles/r03_pipe_busy.txt - round 3's commit called this layout "conflict-free", which it is not): the
+    // 32 lanes of a service group are 2 tokens x 16 chunks in the load phase (bank m + 4 c8: chunks c8 and c8 + 8 collide) and 16 token
+    // groups x 2 d-pairs in the transpose phase (bank 4 g4 + dpair: g4 and g4 + 8 collide).  Rounds 1-2 read single u16 down the rows of a
+    // 136-u16 pitch (conflict rate 0.82).  Making the transpose reads conflict-free (lanes along dpair) would turn the 128-byte coalesced
+    // global stores into 32 scattered 8-byte ones - the worse trade for a 30-us kernel (0.14 ms per step).
     __shared__ unsigned t32[64 * 65];
     const int mt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const u16* src = qkvs + ((((long long)b * 3 + 2) * H + h) * (long long)N) * 128;
