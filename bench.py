@@ -107,7 +107,14 @@ def cpu_baseline(max_images, seed, budget_s=60.0):
         phys = len(pairs) or ncpu
     except OSError:
         pass
+    quota = None
+    try:        # the container's CPU quota (cgroup v2): "max" or "<quota_us> <period_us>" - what the host REALLY grants, next to cpu_count()
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else round(int(q) / int(per), 2)
+    except (OSError, ValueError):
+        pass
     return {"value": n / dt, "unit": "images/s", "cores": int(threads), "threads_used": int(threads), "host_physical_cores": phys,
+            "host_cpu_quota": quota,
             "host_logical_cpus": ncpu, "kind": "port", "cpu": model_name, "images_done": n, "images_requested": max_images,
             "vit_seconds_by_thread_count": tried,
             "seconds_per_image_by_stage": {k: round(v / n, 4) for k, v in stage.items()},
