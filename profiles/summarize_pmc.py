@@ -14,6 +14,7 @@ from collections import defaultdict
 
 def short(name):
     name = re.sub(r"^void ", "", name)
+    name = re.sub(r"\bexcel_(bf16|f16)::", lambda m: "" if m.group(1) == "bf16" else "f16::", name)   # (the split-type namespaces of round 4)
     return name.split("(")[0][:60]
 
 
