@@ -188,9 +188,9 @@ __device__ __forceinline__ void rowpass_body(const RowpassArgs& p, float* smem, 
                 splitx8 ph[2], pl[2];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const split_t hi = (split_t)s[e];
+                    const split_t hi = split_hi(s[e]);
                     ph[e >> 3][e & 7] = hi;
-                    pl[e >> 3][e & 7] = (split_t)(s[e] - (float)hi);
+                    pl[e >> 3][e & 7] = split_hi(s[e] - (float)hi);
                 }
                 const u16* vt16 = reinterpret_cast<const u16*>(Vs) + cur * 64 * 64;
 #pragma unroll
@@ -244,10 +244,10 @@ __device__ __forceinline__ void rowpass_body(const RowpassArgs& p, float* smem, 
             if (q >= N) break;
             const float v = ob[qq * 65 + lane];
             if (p.out_split) {
-                const split_t hi = (split_t)v;
+                const split_t hi = split_hi(v);
                 split_t* o = reinterpret_cast<split_t*>(p.out) + ((long long)b * N + q) * 2 * (p.H * HD) + split_off(h * HD + lane, 0);
                 o[0] = hi;
-                o[32] = (split_t)(v - (float)hi);
+                o[32] = split_hi(v - (float)hi);
             } else {
                 p.out[((long long)b * N + q) * (p.H * HD) + h * HD + lane] = v;
             }
@@ -423,8 +423,8 @@ __device__ __forceinline__ void rowpass_body_bf(const RowpassArgs& p, float* sme
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const float hf = __uint_as_float(__float_as_uint(s[e]) & 0xFFFF0000u);
-                ph[e >> 3][e & 7] = (split_t)hf;
-                pl[e >> 3][e & 7] = (split_t)(s[e] - hf);
+                ph[e >> 3][e & 7] = split_hi(hf);
+                pl[e >> 3][e & 7] = split_hi(s[e] - hf);
             }
             // lane (d = 32 dt + r, kh): sub-tile 2 dt + (r >> 4), its column r & 15; the 16 lanes of a group address the 16 row segments
             // (key = k0 + i / 4, d quarter i % 4) of the [4 keys][16 d] block whose column they receive
@@ -473,10 +473,10 @@ __device__ __forceinline__ void rowpass_body_bf(const RowpassArgs& p, float* sme
             if (q >= N) break;
             const float v = ob[qq * 65 + lane];
             if (p.out_split) {
-                const split_t hi = (split_t)v;
+                const split_t hi = split_hi(v);
                 split_t* o = reinterpret_cast<split_t*>(p.out) + ((long long)b * N + q) * 2 * (p.H * HD) + split_off(h * HD + lane, 0);
                 o[0] = hi;
-                o[32] = (split_t)(v - (float)hi);
+                o[32] = split_hi(v - (float)hi);
             } else {
                 p.out[((long long)b * N + q) * (p.H * HD) + h * HD + lane] = v;
             }
@@ -680,9 +680,9 @@ __global__ __launch_bounds__(256, 1) void attn_accum_kernel(AccumArgs p) {
                     if (p.ex_attn && qg >= 1 && kg >= 1 && kg < N) av += p.ex_scale * p.ex_attn[((long long)b * (N - 1) + (qg - 1)) * (N - 1) + (kg - 1)];
                     if (p.a_sum_split) {
                         split_t* o = reinterpret_cast<split_t*>(p.a_sum) + ((long long)b * N + qg) * 2 * p.NP + split_off(kg, 0);
-                        const split_t hi = (split_t)av;
+                        const split_t hi = split_hi(av);
                         o[0] = hi;
-                        o[32] = (split_t)(av - (float)hi);
+                        o[32] = split_hi(av - (float)hi);
                     } else {
                         p.a_sum[((long long)b * N + qg) * p.NP + kg] = av;
                     }
@@ -899,9 +899,9 @@ __global__ __launch_bounds__(512, 2) void attn_accum_bf_kernel(AccumArgs p) {
                     if (p.ex_attn && qg >= 1 && kg >= 1 && kg < N) av += p.ex_scale * p.ex_attn[((long long)b * (N - 1) + (qg - 1)) * (N - 1) + (kg - 1)];
                     if (p.a_sum_split) {
                         split_t* o = reinterpret_cast<split_t*>(p.a_sum) + ((long long)b * N + qg) * 2 * p.NP + split_off(kg, 0);
-                        const split_t hi = (split_t)av;
+                        const split_t hi = split_hi(av);
                         o[0] = hi;
-                        o[32] = (split_t)(av - (float)hi);
+                        o[32] = split_hi(av - (float)hi);
                     } else {
                         p.a_sum[((long long)b * N + qg) * p.NP + kg] = av;
                     }

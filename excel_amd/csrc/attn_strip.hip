@@ -417,8 +417,8 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
                     splitx8 hi, lo;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
-                        hi[k] = (split_t)v[k];
-                        lo[k] = (split_t)(v[k] - (float)hi[k]);
+                        hi[k] = split_hi(v[k]);
+                        lo[k] = split_hi(v[k] - (float)hi[k]);
                     }
                     u16* o = p.a_sum + ((long long)b * N + qg) * 2 * p.KP + tile * 64 + g8 * 8;
                     *reinterpret_cast<splitx8*>(o) = hi;

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void patch_text_prep_kernel(PtcArgs p, unsigne
             const f32x4 v = *reinterpret_cast<const f32x4*>(p.text + e);
             split_t hi[4], lo[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { hi[j] = (split_t)v[j]; lo[j] = (split_t)(v[j] - (float)hi[j]); }
+            for (int j = 0; j < 4; ++j) { hi[j] = split_hi(v[j]); lo[j] = split_hi(v[j] - (float)hi[j]); }
             split_t* o = reinterpret_cast<split_t*>(text_split_out) + row * 2 * p.C + split_off(k, 0);
             *reinterpret_cast<uint2*>(o) = *reinterpret_cast<const uint2*>(hi);
             *reinterpret_cast<uint2*>(o + 32) = *reinterpret_cast<const uint2*>(lo);
@@ -288,8 +288,8 @@ __global__ __launch_bounds__(PTC_NW * 64) void patch_text_sim_kernel(PtcArgs p) 
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             const float v = (j < 4) ? fa[j] : fb[j - 4];
-                            xh[j] = (split_t)v;
-                            xl[j] = (split_t)(v - (float)xh[j]);
+                            xh[j] = split_hi(v);
+                            xl[j] = split_hi(v - (float)xh[j]);
                         }
 #pragma unroll
                         for (int ct = 0; ct < CT; ++ct) {

@@ -177,6 +177,16 @@ typedef __bf16 split_t;
 #endif
 typedef split_t splitx8 __attribute__((ext_vector_type(8)));
 typedef split_t splitx4 __attribute__((ext_vector_type(4)));
+// fp32 -> one 16-bit plane (hi = split_hi(x), lo = split_hi(x - hi)).  IEEE half saturates at +-65 504 instead of becoming inf: lo then
+// carries the next 65 504, so values up to 131 008 keep 11+ bits and anything beyond is clamped - a finite, visibly wrong product that
+// check_numerics catches, not a NaN; bf16 has the fp32 range.
+__device__ __forceinline__ split_t split_hi(float x) {
+#ifdef EXCEL_SPLIT_F16
+    return (split_t)__builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
+#else
+    return (split_t)x;
+#endif
+}
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // LDS accesses of the streaming loop are written as inline asm: the compiler's wait-count pass treats every ds_read as a
 // possible reader of a pending global_load_lds and drains the whole DMA queue (s_waitcnt vmcnt(0)) in front of it, which

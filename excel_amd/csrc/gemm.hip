@@ -179,9 +179,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs p) {
                     // (z2 offsets columns by sC2 elements of the logical row; blocked hi/lo layout, see split_off)
                     split_t* o = reinterpret_cast<split_t*>(p.C + (long long)z1 * p.sC) + (long long)row * 2 * p.ldc +
                                 split_off((int)(z2 * p.sC2) + col, 0);
-                    const split_t hi = (split_t)v;
+                    const split_t hi = split_hi(v);
                     o[0] = hi;
-                    o[32] = (split_t)(v - (float)hi);
+                    o[32] = split_hi(v - (float)hi);
                 } else if (p.out_mode == GEMM_OUT_QKV_HEADMAJOR) {
                     const int b = row / p.tokN, n = row % p.tokN;
                     C[((((long long)b * 3 + qt) * p.heads + qh) * p.tokN + n) * p.hd + qd] = v;

@@ -66,10 +66,10 @@ __device__ __forceinline__ void bf_epilogue(const GemmBfArgs& p, const f32x16 (&
                 if (p.act == GEMM_ACT_QUICKGELU) v = v * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v));
                 if (p.res) v += p.res[(long long)row * p.ldr + col];
                 if (OUT_MODE == GEMM_OUT_SPLIT_BF16) {
-                    const split_t hi = (split_t)v;
+                    const split_t hi = split_hi(v);
                     split_t* o = reinterpret_cast<split_t*>(p.Cs) + (long long)row * 2 * p.N + split_off(col, 0);
                     o[0] = hi;
-                    o[32] = (split_t)(v - (float)hi);
+                    o[32] = split_hi(v - (float)hi);
                 } else if (OUT_MODE == GEMM_OUT_QKV_HEADMAJOR) {
                     int n = qn + dr, b = qb;
                     while (n >= p.tokN) { n -= p.tokN; ++b; }
@@ -77,9 +77,9 @@ __device__ __forceinline__ void bf_epilogue(const GemmBfArgs& p, const f32x16 (&
                     if (!p.qkv_split) p.C[off] = v;
                     if (p.qkv_split) {     // same (b,type,head,n) row, [hi hd | lo hd] bf16: operand of the bf16x3 attention scores
                         split_t* o = reinterpret_cast<split_t*>(p.qkv_split) + (off - qd) * 2 + qd;
-                        const split_t hi = (split_t)v;
+                        const split_t hi = split_hi(v);
                         o[0] = hi;
-                        o[p.hd] = (split_t)(v - (float)hi);
+                        o[p.hd] = split_hi(v - (float)hi);
                     }
                 } else {
                     p.C[(long long)row * p.ldc + col] = v;
@@ -135,7 +135,7 @@ __device__ __forceinline__ void bf_epilogue_lds(const GemmBfArgs& p, const f32x1
             } else {
                 split_t hi[4], lo[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { hi[q] = (split_t)v[q]; lo[q] = (split_t)(v[q] - (float)hi[q]); }
+                for (int q = 0; q < 4; ++q) { hi[q] = split_hi(v[q]); lo[q] = split_hi(v[q] - (float)hi[q]); }
                 if (OUT_MODE == GEMM_OUT_SPLIT_BF16) {
                     split_t* o = reinterpret_cast<split_t*>(p.Cs) + (long long)row * 2 * p.N + split_off(col, 0);
                     *reinterpret_cast<uint2*>(o) = *reinterpret_cast<const uint2*>(hi);
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16x3_kernel(GemmBfArgs
         // power-limited ceiling of this instruction mix on this part (profiles/r03_gemm_ceiling.json)
         splitx8 fa, fb;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { fa[q] = (split_t)(0.001f * (float)(lane + q)); fb[q] = (split_t)(0.002f * (float)(lane ^ q)); }
+        for (int q = 0; q < 8; ++q) { fa[q] = split_hi(0.001f * (float)(lane + q)); fb[q] = split_hi(0.002f * (float)(lane ^ q)); }
         for (int kt = 0; kt < nk; ++kt)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
@@ -394,8 +394,8 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
     split_t hi[4], lo[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        hi[j] = (split_t)v[j];
-        lo[j] = (split_t)(v[j] - (float)hi[j]);
+        hi[j] = split_hi(v[j]);
+        lo[j] = split_hi(v[j] - (float)hi[j]);
     }
     split_t* o = reinterpret_cast<split_t*>(out) + row * 2 * K + split_off(k, 0);
     *reinterpret_cast<uint2*>(o) = *reinterpret_cast<const uint2*>(hi);

@@ -37,7 +37,7 @@ __device__ __forceinline__ void ln_row(const float* __restrict__ src, const floa
         if (split) {   // bf16 hi/lo planes [2][D] in the same D*4 bytes (operand format of the bf16x3 GEMM)
             split_t hi[4], lo[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { hi[j] = (split_t)v[j]; lo[j] = (split_t)(v[j] - (float)hi[j]); }
+            for (int j = 0; j < 4; ++j) { hi[j] = split_hi(v[j]); lo[j] = split_hi(v[j] - (float)hi[j]); }
             split_t* o = reinterpret_cast<split_t*>(dst);
             *reinterpret_cast<uint2*>(o + split_off(c, 0)) = *reinterpret_cast<const uint2*>(hi);
             *reinterpret_cast<uint2*>(o + split_off(c, 1)) = *reinterpret_cast<const uint2*>(lo);
@@ -79,7 +79,7 @@ __device__ __forceinline__ void ln_row_reg(const float* __restrict__ src, const 
         if (split) {
             split_t hi[4], lo[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { hi[j] = (split_t)o4[j]; lo[j] = (split_t)(o4[j] - (float)hi[j]); }
+            for (int j = 0; j < 4; ++j) { hi[j] = split_hi(o4[j]); lo[j] = split_hi(o4[j] - (float)hi[j]); }
             split_t* o = reinterpret_cast<split_t*>(dst);
             *reinterpret_cast<uint2*>(o + split_off(c, 0)) = *reinterpret_cast<const uint2*>(hi);
             *reinterpret_cast<uint2*>(o + split_off(c, 1)) = *reinterpret_cast<const uint2*>(lo);
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ i
     if (split_out) {
         split_t hi[4], lo[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { hi[j] = (split_t)v[j]; lo[j] = (split_t)(v[j] - (float)hi[j]); }
+        for (int j = 0; j < 4; ++j) { hi[j] = split_hi(v[j]); lo[j] = split_hi(v[j] - (float)hi[j]); }
         split_t* o = reinterpret_cast<split_t*>(col) + pr * 2 * Kc + split_off(k, 0);
         *reinterpret_cast<uint2*>(o) = *reinterpret_cast<const uint2*>(hi);
         *reinterpret_cast<uint2*>(o + 32) = *reinterpret_cast<const uint2*>(lo);

@@ -395,8 +395,6 @@ __global__ __launch_bounds__(512, 4) void par_stats_tile_kernel(const float* __r
         const int plane_off = p * (int)(HW * 4);
         unsigned dst = tile_b + (buf * TR + wave * RPW) * (TP * 4);
         asm volatile("" : "+s"(dst));
-        // dev arm (timing only, wrong results): stage 48 of the 64 rows = roughly the +-12-pixel apron of the round-3 review's proposal
-        if ((EXCEL_DBG(dbg) & 8) && (wave == 0 || wave == 7)) return;
         if (interior) {
             int half = lane >> 5;
             asm volatile("" : "+v"(half));

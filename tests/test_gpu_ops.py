@@ -921,6 +921,18 @@ def test_gemm_f16x3(ops, M, N, K):
     assert np.array_equal(hi2, out.astype(np.float16).astype(np.float32))
 
 
+def test_split_f16_saturates_instead_of_overflowing(ops):
+    """IEEE-half planes have a range of 65 504: the split saturates (hi = +-65504, lo = the next 65 504) instead of producing inf, so values
+    up to 131 008 keep their leading bits and a product with huge activations stays finite; bf16 planes are unaffected (fp32 range)."""
+    x = np.array([[7.0e4, -1.2e5, 3.0e5, 6.0e4] + [1.0] * 28], np.float32)
+    hi, lo = _unsplit_f16(host(ops.split_bf16(dev(x), f16=True)))
+    assert np.all(np.isfinite(hi)) and np.all(np.isfinite(lo))
+    assert hi[0, 0] == 65504.0 and abs((hi + lo)[0, 0] - 7.0e4) <= 32 and abs((hi + lo)[0, 1] + 1.2e5) <= 64
+    assert (hi + lo)[0, 2] == 2 * 65504.0 and abs((hi + lo)[0, 3] - 6.0e4) <= 1
+    hb, lb = _unsplit(host(ops.split_bf16(dev(x))))
+    assert np.max(np.abs((hb.astype(np.float64) + lb) - x) / np.abs(x)) < 2.0 ** -16
+
+
 def test_vit_b16_448_bf16x3_mode(ops):
     """Same BASELINE-shape check as the fp32 test, with the linear layers on the bf16x3 path: the CAM gate (1e-3)
     must hold with a wide margin (measured ~1e-5)."""
