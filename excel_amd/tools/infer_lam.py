@@ -63,7 +63,9 @@ def get_parser():
     p.add_argument("--seed", default=1234, type=int)
     p.add_argument("--api_path", default=False, type=_bool, help="per-image reference call sequence instead of the batched pipeline")
     p.add_argument("--ragged", default=False, type=_bool, help="synthetic samples with VOC-like, per-image sizes (uint8 images), fed as ragged batches like real data")
-    p.add_argument("--num_workers", default=16, type=int, help="background decoders of the ragged path (the reference's DataLoader uses 2 worker processes, :167)")
+    p.add_argument("--num_workers", default=-1, type=int,
+                   help="background decoders of the ragged path (the reference's DataLoader uses 2 worker processes, :167); -1 = from the CPUs "
+                        "this rank may really use (affinity and the container's cgroup quota, shared by the ranks of the node): at most 16")
     p.add_argument("--decode", default="threads", choices=["threads", "processes"],
                    help="threads: a decode thread pool in this process (Pillow releases the GIL; default); processes: forked DataLoader "
                         "workers like the reference - after such workers exit, host-side GPU event waits of this process were measured "
@@ -86,6 +88,25 @@ def get_parser():
 def shard_indices(n, rank, world):
     """Subset(np.arange(i, len, n_gpus)) (tools/infer_lam.py:166)."""
     return np.arange(rank, n, world)
+
+
+def host_cpu_budget():
+    """CPUs this process may really use: the affinity mask capped by the container's cgroup-v2 quota (`cpu.max`; the GPU boxes of this
+    project report 256 logical CPUs and grant 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def default_decode_workers(local_world=1):
+    """Decode threads per rank: this rank's share of the CPU budget minus the launching thread, between 2 and 16 (measured: 16 threads are
+    best for one rank on 16 granted CPUs, 8 per rank for 8 ranks)."""
+    return max(2, min(16, host_cpu_budget() // max(local_world, 1) - (1 if local_world > 1 else 0)))
 
 
 def pin_rank_to_cores(local_rank, local_world):
@@ -168,7 +189,9 @@ def build_validation(model=None, par=None, dataset=None, indices=None, device="c
         from ..utils import imutils
         pipe.hist = hist
         keep = bool(getattr(args, "crf_post", False))
-        nw = int(getattr(args, "num_workers", 16))
+        nw = int(getattr(args, "num_workers", -1))
+        if nw < 0:
+            nw = default_decode_workers(int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", 1))))
         if getattr(args, "decode", "threads") == "processes" and nw > 0:    # the reference's mechanism (DataLoader worker processes, :167)
             batches = ragged_batches(dataset, indices, args.batch_size, num_workers=nw, pin_memory=False)
         else:                                                               # default: a thread pool (datasets/loader.threaded_batches)

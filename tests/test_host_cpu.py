@@ -421,6 +421,16 @@ def test_pin_rank_to_cores_disjoint_shares():
         os.sched_setaffinity(0, saved)
 
 
+def test_default_decode_workers_follow_the_cpu_budget():
+    """infer_lam: the default decode-pool size is this rank's share of the CPUs the process may really use (affinity, cgroup quota), 2..16."""
+    from excel_amd.tools import infer_lam
+    budget = infer_lam.host_cpu_budget()
+    assert 1 <= budget <= (os.cpu_count() or 1)
+    assert infer_lam.default_decode_workers(1) == max(2, min(16, budget))
+    assert infer_lam.default_decode_workers(8) == max(2, min(16, budget // 8 - 1))
+    assert infer_lam.get_parser().parse_args([]).num_workers == -1
+
+
 def test_loaded_library_is_built_from_these_sources():
     """excel_build_id(): the id compiled into libexcel_hip.so equals the id of the sources in the tree (excel_amd/build.py:source_id)."""
     from excel_amd import _lib, build
