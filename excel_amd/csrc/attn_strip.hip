@@ -56,8 +56,12 @@ struct StripArgs {
 //         select on the wave's tile count - replaces the branchy run-time cursor (-77 SALU, -14 branches per phase; the kernel did
 //         not notice: -0.3 %, SALU issues beside the vector stream); tile maxima by explicit v_max3_f32       (both: -1.4 % same-box)
 // Measured and dropped in round 4: two accumulators per tile alternating per k-step (+7.5 %: eight more packed adds per
-// tile), the softmax of tile j-1 as scalar VALU inside tile j's MFMA gaps (+30 %: the kernel is bound by VALU issue, and unpacking
-// adds 48 VALU per tile).
+// tile), the softmax of tile j-1 as scalar VALU inside tile j's MFMA gaps (+30 %: unpacking adds 48 VALU per tile), and a
+// producer / consumer version (waves 0-3 only DMA + MFMA, waves 4-7 only softmax / fold, score tiles through a 2-slot LDS mailbox per
+// pair with polled counters: parity-green, +31 % - its skeleton alone, with MFMAs, softmax, DMA and polls removed, ran 2.5 ms against
+// 1.57 ms for this kernel's; kept as tools_dev/attn_strip2_kernel.inc).  The ablation that matters: with ALL work removed (no MFMA, no
+// DMA, no softmax) this kernel still takes 1.57 of its 3.43 ms - fragment reads, statistics exchange, barrier, fold and epilogue of 48
+// phases; removing only the MFMAs saves 0.53, only the DMA 0.39, only the softmax 0.61.
 template <int NTW, int DBG, int VAR>
 __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
     constexpr int TILE_EL = 32 * 128;                                    // u16 elements of a 32-row operand tile (8 KB)
