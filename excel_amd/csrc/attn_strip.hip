@@ -62,6 +62,9 @@ struct StripArgs {
 // 1.57 ms for this kernel's; kept as tools_dev/attn_strip2_kernel.inc).  The ablation that matters: with ALL work removed (no MFMA, no
 // DMA, no softmax) this kernel still takes 1.57 of its 3.43 ms - fragment reads, statistics exchange, barrier, fold and epilogue of 48
 // phases; removing only the MFMAs saves 0.53, only the DMA 0.39, only the softmax 0.61.
+// Two direct attempts at that skeleton lost as well (profiles/r04_ab_experiments.txt): folding the previous phase's statistics behind
+// tile 0's MFMAs on EVERY wave instead of waves 4-7 (+1.3 %, 4 VGPRs spill), and a third query-strip slot so the next phase's x
+// fragments are read before the phase barrier, behind the last softmax (+0.6 %).
 template <int NTW, int DBG, int VAR>
 __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
     constexpr int TILE_EL = 32 * 128;                                    // u16 elements of a 32-row operand tile (8 KB)
