@@ -42,6 +42,7 @@ struct GemmBfArgs {
     int batch;                   // >= 1: blockIdx.y; operands advance by sA / sB bf16 elements, C by sC floats, Cs by sCs bf16 elements
     long long sA, sB, sC, sCs;
     int mix_tall, mix_short;     // set by the launcher (mixed-height 320x256 / 256x256 row tiles, gemm_bf16x3.hip); 0 = uniform tiles
+    int mix_first;               // short tiles dispatched FIRST in every XCD's chunk (the rest follow the tall ones): staggers the epilogues
 };
 
 

@@ -116,35 +116,70 @@ __device__ __forceinline__ void bf_epilogue_lds(const GemmBfArgs& p, const f32x1
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) scratch[c32_row(e, lane) * 68 + j * 32 + r] = acc[i][j][e];
+            for (int e = 0; e < 16; ++e) { if (EXCEL_DBG(p.dbg) & 32) break; scratch[c32_row(e, lane) * 68 + j * 32 + r] = acc[i][j][e]; }
         __builtin_amdgcn_s_waitcnt(0xc07f);               // this wave's LDS writes landed (same-wave read back)
+        // Batched by hand: 8 LDS reads, then (residual) 8 global loads, then the math, then the stores.  Written as one loop with the row
+        // test in front, every iteration was its own chain of basic blocks - ds_read, lgkmcnt(0), residual load, vmcnt(0) (which also waits
+        // for the previous iteration's stores), stores - 40 times in series per wave.
+        constexpr int EB = 4;                              // iterations per batch (8 at once spill: the later row tiles' accumulators are still live)
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int row_l = it * 4 + (lane >> 4);
-            const int row = m0 + wm * (nti * 32) + i * 32 + row_l;
-            f32x4 v = *reinterpret_cast<const f32x4*>(&scratch[row_l * 68 + c4]);
-            if (row >= p.M || !col_ok) continue;
-            v += bias4;
+        for (int h0 = 0; h0 < 8; h0 += EB) {
+        f32x4 v[EB];
+#pragma unroll
+        for (int it = 0; it < EB; ++it) {
+            const int row_l = (h0 + it) * 4 + (lane >> 4);
+            if (EXCEL_DBG(p.dbg) & 32) { v[it][0] = acc[i][0][h0 + it]; v[it][1] = acc[i][0][h0 + it + 8]; v[it][2] = acc[i][1][h0 + it]; v[it][3] = acc[i][1][h0 + it + 8]; }   // dev arm: no LDS transpose (wrong values, same registers live)
+            else v[it] = *reinterpret_cast<const f32x4*>(&scratch[row_l * 68 + c4]);
+        }
+        const int row0 = m0 + wm * (nti * 32) + i * 32 + (lane >> 4);
+        const int colc = col_ok ? col : 0;
+        int qb0 = 0, qn0 = 0;
+        if (OUT_MODE == GEMM_OUT_QKV_HEADMAJOR) { qb0 = row0 / p.tokN; qn0 = row0 - qb0 * p.tokN; }
+        if (p.res) {
+            f32x4 rs[EB];
+#pragma unroll
+            for (int it = 0; it < EB; ++it) rs[it] = *reinterpret_cast<const f32x4*>(p.res + (long long)min(row0 + (h0 + it) * 4, p.M - 1) * p.ldr + colc);
+#pragma unroll
+            for (int it = 0; it < EB; ++it) v[it] += bias4;
             if (p.act == GEMM_ACT_QUICKGELU) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = v[q] * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v[q]));
+                for (int it = 0; it < EB; ++it)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[it][q] = v[it][q] * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v[it][q]));
             }
-            if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (long long)row * p.ldr + col);
+#pragma unroll
+            for (int it = 0; it < EB; ++it) v[it] += rs[it];
+        } else {
+#pragma unroll
+            for (int it = 0; it < EB; ++it) v[it] += bias4;
+            if (p.act == GEMM_ACT_QUICKGELU) {
+#pragma unroll
+                for (int it = 0; it < EB; ++it)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[it][q] = v[it][q] * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v[it][q]));
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < EB; ++it) {
+            const int row = row0 + (h0 + it) * 4;
+            if ((EXCEL_DBG(p.dbg) & 16) && v[it][0] + v[it][1] + v[it][2] + v[it][3] != 1.2345e-30f) continue;          // dev arm: no global stores
+            if (row >= p.M || !col_ok) continue;
             if (OUT_MODE == GEMM_OUT_PLAIN) {
-                *reinterpret_cast<f32x4*>(p.C + (long long)row * p.ldc + col) = v;
+                *reinterpret_cast<f32x4*>(p.C + (long long)row * p.ldc + col) = v[it];
             } else {
                 split_t hi[4], lo[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { hi[q] = split_hi(v[q]); lo[q] = split_hi(v[q] - (float)hi[q]); }
+                for (int q = 0; q < 4; ++q) { hi[q] = split_hi(v[it][q]); lo[q] = split_hi(v[it][q] - (float)hi[q]); }
                 if (OUT_MODE == GEMM_OUT_SPLIT_BF16) {
                     split_t* o = reinterpret_cast<split_t*>(p.Cs) + (long long)row * 2 * p.N + split_off(col, 0);
                     *reinterpret_cast<uint2*>(o) = *reinterpret_cast<const uint2*>(hi);
                     *reinterpret_cast<uint2*>(o + 32) = *reinterpret_cast<const uint2*>(lo);
                 } else {   // q|k|v head-major: fp32 for P.V / A.V, and [hi hd | lo hd] bf16 for the bf16x3 scores
-                    const int b = row / p.tokN, n = row - b * p.tokN;
+                    int b = qb0, n = qn0 + (h0 + it) * 4;                     // (one division per row tile, not per store)
+                    while (n >= p.tokN) { n -= p.tokN; ++b; }
                     const long long rowidx = (((long long)b * 3 + qt) * p.heads + qh) * p.tokN + n;
                     // the fp32 copy is not consumed when the split copy exists (bf16x3 attention; V^T is cut from the split planes)
-                    if (!p.qkv_split) *reinterpret_cast<f32x4*>(p.C + rowidx * p.hd + qd) = v;
+                    if (!p.qkv_split) *reinterpret_cast<f32x4*>(p.C + rowidx * p.hd + qd) = v[it];
                     if (p.qkv_split) {
                         split_t* o = reinterpret_cast<split_t*>(p.qkv_split) + rowidx * 2 * p.hd + qd;
                         *reinterpret_cast<uint2*>(o) = *reinterpret_cast<const uint2*>(hi);
@@ -152,6 +187,7 @@ __device__ __forceinline__ void bf_epilogue_lds(const GemmBfArgs& p, const f32x1
                     }
                 }
             }
+        }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);               // reads done before the next round overwrites the scratch
     }
@@ -193,13 +229,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16x3_kernel(GemmBfArgs
         const int tq = T >> 3, tr = T & 7, aq = A >> 3, ar = A & 7;
         const int tbase = x * tq + min(x, tr), tcount = tq + (x < tr ? 1 : 0);
         const int abase = x * aq + min(x, ar);
+        const int first = min(p.mix_first, aq + (x < ar ? 1 : 0) - tcount);     // short tiles of this XCD that go out before its tall ones
         int rt, tn;
-        if (loc < tcount) {
-            const int k = tbase + loc;
+        if (loc >= first && loc < first + tcount) {
+            const int k = tbase + (loc - first);
             rt = k / tiles_n; tn = k - rt * tiles_n;
             m0 = rt * BM;
         } else {
-            const int k = (abase - tbase) + (loc - tcount);          // index among the short tiles
+            const int k = (abase - tbase) + (loc < first ? loc : loc - tcount);   // index among the short tiles
             rt = k / tiles_n; tn = k - rt * tiles_n;
             m0 = p.mix_tall * BM + rt * (BM - 64);
             nti = TI - 1;
@@ -370,6 +407,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16x3_kernel(GemmBfArgs
         __syncthreads();
     }
 
+    if (EXCEL_DBG(p.dbg) & 8) {
+        // dev arm "no epilogue": the k-loop alone (the accumulators stay live through a store that never happens)
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sum += acc[i][j][e];
+        if (sum == 1.2345e-30f) p.C[0] = sum;
+        return;
+    }
     const bool vec = (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 && (p.hd & 3) == 0;
     if (vec) {
         // every wave is past the last barrier of the k-loop: the staging ring is free -> per-wave transpose scratch
@@ -507,8 +556,14 @@ int excel_launch_gemm_bf16x3(const GemmBfArgs& p_in, hipStream_t stream) {
         if (tall < 0) tall = 0;
         int shrt = nt - tall;
         while (shrt > 0 && 10 * tall + 8 * (shrt - 1) >= units) --shrt;      // no more row tiles than M needs
-        if (R >= 2 && shrt > 0 && tall <= nt && 10 * tall + 8 * shrt >= units && tall * tiles_n <= (R - 1) * n_cu2) {
-            p.mix_tall = tall; p.mix_short = shrt;
+        int first = 0;
+        bool one_round = false;
+#ifdef EXCEL_DEV
+        { static const char* e = getenv("EXCEL_BF_FIRST"); if (e) first = atoi(e); }
+        { static const char* e = getenv("EXCEL_BF_MIX1"); one_round = e && R == 1; }
+#endif
+        if ((R >= 2 || one_round) && shrt > 0 && tall <= nt && 10 * tall + 8 * shrt >= units && (one_round || tall * tiles_n <= (R - 1) * n_cu2)) {
+            p.mix_tall = tall; p.mix_short = shrt; p.mix_first = first;
             hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 4, 5, 2, true>), dim3((tall + shrt) * tiles_n, 1), dim3(512), 0, stream, p);
             EXCEL_CHECK_LAUNCH("gemm_bf16x3");
             return EXCEL_OK;

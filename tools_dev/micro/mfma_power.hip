@@ -1,0 +1,104 @@
+// dev micro-benchmark (gfx950): is the bf16 matrix pipe clock- / power-limited when the WHOLE chip runs the GEMM's MFMA stream, and does
+// the operand data matter?  One 512-thread workgroup per CU (two waves per SIMD, as the bf16x3 GEMM), every wave runs `iters` blocks of
+// 30 v_mfma_f32_32x32x16_bf16 on 10 accumulators (three dependent MFMAs per accumulator, the GEMM's order), operands in registers, no
+// memory traffic.  Grid = 32 ... 256 workgroups; operand data = zeros / smooth values / random mantissas and exponents.
+//   per SIMD: 2 waves x iters x 30 MFMAs x 32 cycles  ->  effective clock = cycles / time
+//   hipcc --offload-arch=gfx950 -O3 -o mfma_power mfma_power.hip && ./mfma_power
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ inline unsigned hash32(unsigned x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+
+template <int F16, int ORDER>
+__global__ __launch_bounds__(512) void k(float* out, int iters, int data) {
+    f32x16 acc[10];
+    for (int i = 0; i < 10; ++i)
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    // eight operand fragments (the GEMM holds 2 B hi/lo + A hi/lo of two row tiles): distinct data per fragment
+    unsigned short raw[8][8];
+    for (int f = 0; f < 8; ++f)
+        for (int q = 0; q < 8; ++q) {
+            const unsigned h = hash32((blockIdx.x * 512 + threadIdx.x) * 64 + f * 8 + q);
+            unsigned short v;
+            if (data == 0) v = 0;
+            else if (data == 1) v = F16 ? 0x2c00 + ((threadIdx.x + q) & 0xff) : 0x3c00 + ((threadIdx.x + q) & 0x3f);       // smooth: one exponent, low mantissa bits
+            else v = F16 ? (unsigned short)(((h & 0x8000)) | (0x2400 + (h & 0x0fff))) : (unsigned short)((h & 0x8000) | (0x3a00 + (h & 0x03ff)));   // random sign / mantissa, 3-4 exponents
+            raw[f][q] = v;
+        }
+    auto frag = [&](int f) {
+        if constexpr (F16) { f16x8 x; __builtin_memcpy(&x, raw[f], 16); return x; }
+        else { bf16x8 x; __builtin_memcpy(&x, raw[f], 16); return x; }
+    };
+    auto ah0 = frag(0), al0 = frag(1), ah1 = frag(2), al1 = frag(3), bh0 = frag(4), bl0 = frag(5), bh1 = frag(6), bl1 = frag(7);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const auto& ah = (i & 1) ? ah1 : ah0;
+            const auto& al = (i & 1) ? al1 : al0;
+            if constexpr (ORDER == 1 && !F16) {
+                // operand-reuse order: A changes twice, B five times per six MFMAs (shipped order: 4 + 6); the three products of an accumulator
+                // are still al.bh, ah.bh, ah.bl but interleaved over the two accumulators of the row tile
+                acc[i * 2 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh0, acc[i * 2 + 0], 0, 0, 0);
+                acc[i * 2 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh1, acc[i * 2 + 1], 0, 0, 0);
+                acc[i * 2 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh1, acc[i * 2 + 1], 0, 0, 0);
+                acc[i * 2 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh0, acc[i * 2 + 0], 0, 0, 0);
+                acc[i * 2 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl0, acc[i * 2 + 0], 0, 0, 0);
+                acc[i * 2 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl1, acc[i * 2 + 1], 0, 0, 0);
+                continue;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const auto& bh = j ? bh1 : bh0;
+                const auto& bl = j ? bl1 : bl0;
+                if constexpr (F16) {
+                    acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[i * 2 + j], 0, 0, 0);
+                    acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[i * 2 + j], 0, 0, 0);
+                    acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i * 2 + j], 0, 0, 0);
+                } else {
+                    acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i * 2 + j], 0, 0, 0);
+                    acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i * 2 + j], 0, 0, 0);
+                    acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i * 2 + j], 0, 0, 0);
+                }
+            }
+        }
+        // keep the accumulators bounded (random data would overflow over thousands of blocks): nothing - fp32 inf is still an MFMA
+    }
+    float s = 0.f;
+    for (int i = 0; i < 10; ++i)
+        for (int e = 0; e < 16; ++e) s += acc[i][e];
+    if (s == 1.2345e-30f) out[0] = s;
+}
+
+int main(int argc, char** argv) {
+    const int iters = argc > 1 ? atoi(argv[1]) : 2000;       // 2000 x 30 x 32 x 2 = 3.84 M cycles per SIMD (~2 ms)
+    float* out;
+    hipMalloc(&out, 4);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const char* dn[3] = {"zeros ", "smooth", "random"};
+    const int norder = argc > 2 ? 2 : 1;                      // any second argument: also the operand-reuse order (bf16, random data)
+    for (int order = 0; order < norder; ++order)
+    for (int f16 = 0; f16 < (order ? 1 : 2); ++f16)
+        for (int data = (order ? 2 : 0); data < 3; ++data)
+            for (int grid : {32, 64, 128, 192, 256}) {
+                float best = 1e30f, last = 0.f;
+                for (int rep = 0; rep < 6; ++rep) {              // back to back: the later repetitions see the steady-state clock
+                    hipEventRecord(e0);
+                    if (order) hipLaunchKernelGGL((k<0, 1>), dim3(grid), dim3(512), 0, 0, out, iters, data);
+                    else if (f16) hipLaunchKernelGGL((k<1, 0>), dim3(grid), dim3(512), 0, 0, out, iters, data);
+                    else hipLaunchKernelGGL((k<0, 0>), dim3(grid), dim3(512), 0, 0, out, iters, data);
+                    hipEventRecord(e1);
+                    hipEventSynchronize(e1);
+                    hipEventElapsedTime(&last, e0, e1);
+                    if (last < best) best = last;
+                }
+                const double cyc = 2.0 * iters * 30 * 32;
+                printf("%s%s %s grid %3d: best %8.1f us  last %8.1f us  -> %.2f GHz effective (last), %.0f TFLOP/s dense-equivalent\n", order ? "reuse-order " : "", f16 ? "f16 " : "bf16", dn[data], grid,
+                       best * 1e3, last * 1e3, cyc / (last * 1e-3) * 1e-9, grid * 8.0 * iters * 30 * 32768.0 / (last * 1e-3) * 1e-12);
+            }
+    return 0;
+}
