@@ -111,24 +111,28 @@ struct Tile {
 };
 // blockIdx -> tile.  Uniform launches use grid (cdiv(W,64), cdiv(H,16), B); ragged launches grid.x = total tiles.  All values are
 // wave-uniform (scalar loads / SALU only).
+__device__ __forceinline__ Tile tile_of_ragged(const TileGeo& g, int tile) {     // tile = index into the ragged tile list
+    Tile t;
+    const int* __restrict__ tab = g.tab;
+    t.b = tab[EXCEL_RAG_REC * (g.B + 1) + tile];
+    const int* rec = tab + EXCEL_RAG_REC * t.b;
+    t.H = rec[0]; t.W = rec[1];
+    t.Wp = (t.W + 3) & ~3;
+    t.base = rec[2];
+    t.lab = rec[4];
+    const int loc = tile - rec[3];
+    const int ntx = (t.W + 63) >> 6;
+    const int ty = loc / ntx;
+    t.x0 = (loc - ty * ntx) * 64;
+    t.y0 = ty * 16;
+    t.HW = (long long)t.H * t.Wp;
+    return t;
+}
 template <bool RAGGED>
 __device__ __forceinline__ Tile tile_of(const TileGeo& g) {
     Tile t;
     if (RAGGED) {
-        const int* __restrict__ tab = g.tab;
-        const int tile = blockIdx.x;
-        t.b = tab[EXCEL_RAG_REC * (g.B + 1) + tile];
-        const int* rec = tab + EXCEL_RAG_REC * t.b;
-        t.H = rec[0]; t.W = rec[1];
-        t.Wp = (t.W + 3) & ~3;
-        t.base = rec[2];
-        t.lab = rec[4];
-        const int loc = tile - rec[3];
-        const int ntx = (t.W + 63) >> 6;
-        const int ty = loc / ntx;
-        t.x0 = (loc - ty * ntx) * 64;
-        t.y0 = ty * 16;
-        t.HW = (long long)t.H * t.Wp;
+        t = tile_of_ragged(g, blockIdx.x);
     } else {
         t.b = blockIdx.z; t.x0 = blockIdx.x * 64; t.y0 = blockIdx.y * 16;
         t.H = g.H; t.W = g.W; t.Wp = g.W;
