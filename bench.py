@@ -294,17 +294,26 @@ def main(argv=None, hooks=None):
         if on_gpu:
             torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        pipe.run_batch(*batches[i % n_batches])
-    pipe.reset()
     timing = on_gpu and not args.no_kernel_timing
     gmode = model.encoder.visual.handle().gemm_mode() if on_gpu else "stub"
     dom_cat = "gemm_bf16x3" if gmode in ("bf16x3", "f16x3") else "gemm_nt"
+    if timing:
+        # the warm-up runs with the same event bracketing as the timed region, so nothing is used for the first time inside it
+        ops.prof_enable(True, categories=[dom_cat, "par_iterate"], every=4)
+    for i in range(args.warmup):
+        pipe.run_batch(*batches[i % n_batches])
+    pipe.reset()
     if timing:
         # inside the timed region the two roofline kernels are bracketed with HIP events on their launch stream, every 4th
         # launch of each (an event pair costs ~10 us of GPU idle: all ~290 launches/step would take 5 % off `value`)
         ops.prof_collect()
         ops.prof_enable(True, categories=[dom_cat, "par_iterate"], every=4)
+    # no cyclic-GC pass inside the timed loop (what `timeit` does too): a full collection over the interpreter's heap (torch, numpy, the
+    # data set) takes 40-70 ms of host time, and the allocation count that triggers it landed in timed step 0 or 1 - on a fresh box, where
+    # the GPU had no queued work to hide it behind, 1 080-1 230 instead of 1 370 img/s over 10 steps (found with host_enqueue_ms_steps)
+    import gc
+    gc.collect()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     if args.overlap:
@@ -313,12 +322,17 @@ def main(argv=None, hooks=None):
         step_fn = lambda *b: pipe.run_batch_split(*b, nsplit=args.split)
     else:
         step_fn = pipe.run_batch
+    host_marks = []
     for i in range(args.steps):
+        th = time.perf_counter()
         step_fn(*batches[i % n_batches])
+        host_marks.append(time.perf_counter() - th)                      # host time to ENQUEUE step i: a host-side self-check
     pipe.drain()
     per_rank, total = gather_hists(pipe.hist)                       # the one collective (RCCL all-gather)
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
+    host_steps = host_marks
     prof = None
     if timing:
         ops.prof_enable(False)
@@ -359,6 +373,11 @@ def main(argv=None, hooks=None):
             # the library that ran: the id of the sources it was compiled from (excel_build_id) next to the id of the sources in the tree
             "lib_build_id": _lib.build_id() if on_gpu else None, "csrc_sha16": csrc_sha16(),
             "lib_built_from_these_sources": on_gpu and _lib.build_id().replace("-dev", "") == csrc_sha16(),
+            # host side of the timed loop: time to enqueue a step's launches (must stay well under ms_per_step, else the GPU waits for
+            # Python) - mean and worst step; a cold process or a throttled container shows here, not in the kernel times
+            "host_enqueue_ms_per_step": round(sum(host_steps) / max(len(host_steps), 1) * 1e3, 3),
+            "host_enqueue_ms_max_step": round(max(host_steps) * 1e3, 3) if host_steps else None,
+            "host_enqueue_ms_steps": [round(x * 1e3, 2) for x in host_steps],
             "rccl_ranks": int(dist.get_world_size()) if world > 1 else 1,
             "per_rank_hist_mass": [int(x) for x in per_rank.reshape(per_rank.shape[0], -1).sum(1).tolist()],
         }

@@ -438,6 +438,11 @@ def validate(args=None, dataset=None, pipe=None):
                             dataset_name=args.dataset_name, num_classes=args.num_classes, num_atrr_clusters=args.num_attri,
                             json_file=args.attr_json, img_size=args.resize_size, mode=args.infer_set, device=device,
                             gemm_mode=getattr(args, "gemm_mode", None), **resolve_model_inputs(args))
+    # everything built so far (torch, the weights, the data set index) lives for the whole run: move it out of the cyclic collector's
+    # reach, or every full collection walks it again - 40-70 ms of host time each (measured in bench.py, where one landed in a timed step)
+    import gc
+    gc.collect()
+    gc.freeze()
     par = PAR(num_iter=20, dilations=[1, 2, 4, 8, 12, 24])                                  # :168
     idx = shard_indices(len(dataset), rank, world)                                          # :166
     if model is not None and getattr(args, "gemm_check", True) and len(idx) > 0:
