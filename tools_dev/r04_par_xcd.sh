@@ -1,19 +1,20 @@
 #!/bin/bash
-# round-4: PAR step with an XCD-aware tile order (dev library, EXCEL_PAR_DBG 32 = whole images per XCD, 64 = + 2-row column-major bands):
-# time per step, label agreement (the remap is a permutation: results must not change), fabric fetch per launch
+# round-4: PAR step in plain grid order (dev library, EXCEL_PAR_DBG=32) against the shipped XCD-aware tile order (0): time per step, label
+# agreement (the order is a permutation: results must not change), fabric fetch / write per launch.  (As first run the bits meant the
+# opposite - 32 = remap, 64 = remap + 2-row bands, 0 = plain order: profiles/r04_ab_experiments.txt holds those lines.)
 set -u
 cd "$GRAFT_REPO_ROOT"
 OUT=$PWD/gpurun_out/${1:-r04n}; mkdir -p $OUT
 export TMPDIR=/tmp
 for rep in 1 2; do
-for D in 0 32 64; do
+for D in 0 32; do
   EXCEL_PAR_DBG=$D EXCEL_AB_LIB=tools_dev/ab/dev.so timeout 300 python tools_dev/ab_bench.py --cpu-images 0 --ragged-images 0 --steps 10 --warmup 3 2>$OUT/err_$D.txt | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); k=d['kernel_ms_per_step']; print('par dbg=$D', 'par_iterate %.4f' % k['par_iterate'], 'step', d['ms_per_step'], 'hist_sha', str(d.get('hist_sha16', d.get('miou_synthetic'))))" | tee -a $OUT/par_xcd.txt
 done
 done
 cd /tmp
-for D in 0 32 64; do
+for D in 0 32; do
   for C in FETCH_SIZE WRITE_SIZE; do
   EXCEL_PAR_DBG=$D EXCEL_AB_LIB=$GRAFT_REPO_ROOT/tools_dev/ab/dev.so rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/f$D -o f -- python $GRAFT_REPO_ROOT/tools_dev/ab_bench.py --steps 2 --warmup 1 --cpu-images 0 --ragged-images 0 --no-kernel-timing > /dev/null 2> $OUT/f$D.err
   python - <<PY | tee -a $OUT/par_xcd.txt
