@@ -6,7 +6,7 @@ There are no VOC images and no ViT-B-16.pt in this image: the tree is synthetic 
 counts, JPEG quality 90), the checkpoint is a seeded random ViT-B/16 visual tower + a small text tower in the published key layout.  The
 mIoU of the record is plumbing; images, sizes, file formats, batch shape and the code path are the real harness's.
 
-  step 1 (no GPU, forks):  python tools_dev/voc_full_run.py write /tmp/voc_syn 10582
+  step 1 (no GPU, forks):  python tools_dev/voc_full_run.py write /tmp/voc_syn 10582        (... write /tmp/coco_syn 5063 coco: a COCO-format tree)
   step 2:                  python tools_dev/voc_full_run.py run /tmp/voc_syn gpurun_out/<tag>/voc_full_n1.json
 """
 import gzip
@@ -22,22 +22,26 @@ MERGES = ["a n", "t h", "i n", "e r", "o n", "r e", "th e</w>", "c l", "o r", "i
 
 
 def _write_slice(job):
-    root, lo, hi, n, seed = job
+    root, lo, hi, n, seed, coco = job
     from PIL import Image
     from excel_amd.tools.synthetic import SyntheticSegDataset
     from excel_amd.utils import imutils
-    ds = SyntheticSegDataset(n, num_classes=21, seed=seed, ragged=True)
+    nc = 81 if coco else 21
+    ds = SyntheticSegDataset(n, num_classes=nc, seed=seed, ragged=True)
     palette = imutils.colormap().flatten().tolist()
     out, npix = {}, 0
     for i in range(lo, hi):
         _, img, gt, cls = ds[i]
-        name = "2008_%06d" % i
-        Image.fromarray(img).save(os.path.join(root, "JPEGImages", name + ".jpg"), quality=90)
+        # (datasets/coco.py: JPEGImages/val/COCO_val2014_<12 digits>.jpg, SegmentationClass/val/<12 digits>.png)
+        name = ("COCO_val2014_%012d" % i) if coco else ("2008_%06d" % i)
+        img_dir = os.path.join(root, "JPEGImages", "val") if coco else os.path.join(root, "JPEGImages")
+        lab_path = os.path.join(root, "SegmentationClass", "val", name[13:] + ".png") if coco else os.path.join(root, "SegmentationClassAug", name + ".png")
+        Image.fromarray(img).save(os.path.join(img_dir, name + ".jpg"), quality=90)
         im = Image.fromarray(gt, mode="P")
         im.putpalette(palette)
-        im.save(os.path.join(root, "SegmentationClassAug", name + ".png"))
+        im.save(lab_path)
         out[name] = cls
-        npix += int((gt < 21).sum())
+        npix += int((gt < nc).sum())
     return out, npix
 
 
@@ -64,21 +68,23 @@ def text_tower(vocab, width=512, layers=2, embed=512, ctx=77, seed=5):
     return w
 
 
-def write(base, n, procs=16, seed=1234):
+def write(base, n, procs=16, seed=1234, coco=False):
     from concurrent.futures import ProcessPoolExecutor
-    root, lists = os.path.join(base, "VOC2012"), os.path.join(base, "lists")
-    for d in (os.path.join(root, "JPEGImages"), os.path.join(root, "SegmentationClassAug"), lists):
+    root, lists = os.path.join(base, "COCO" if coco else "VOC2012"), os.path.join(base, "lists")
+    dirs = (os.path.join(root, "JPEGImages", "val"), os.path.join(root, "SegmentationClass", "val")) if coco else \
+           (os.path.join(root, "JPEGImages"), os.path.join(root, "SegmentationClassAug"))
+    for d in dirs + (lists,):
         os.makedirs(d, exist_ok=True)
     t0 = time.time()
     step = (n + 4 * procs - 1) // (4 * procs)
-    jobs = [(root, lo, min(lo + step, n), n, seed) for lo in range(0, n, step)]
+    jobs = [(root, lo, min(lo + step, n), n, seed, coco) for lo in range(0, n, step)]
     onehot, npix = {}, 0
     with ProcessPoolExecutor(procs) as ex:
         for o, p in ex.map(_write_slice, jobs):
             onehot.update(o)
             npix += p
     ids = sorted(onehot)
-    with open(os.path.join(lists, "train.txt"), "w") as f:
+    with open(os.path.join(lists, "val.txt" if coco else "train.txt"), "w") as f:
         f.write("\n".join(ids) + "\n")
     np.save(os.path.join(lists, "cls_labels_onehot.npy"), onehot)
     # checkpoint + BPE file in the published formats
@@ -90,8 +96,8 @@ def write(base, n, procs=16, seed=1234):
     full = {"visual." + k: v for k, v in synthetic.make_vit_state_dict(seed=0).items()}
     full.update(text_tower(256 + 256 + len(MERGES) + 2))
     torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in full.items()}, os.path.join(base, "ViT-B-16.pt"))
-    nbytes = sum(os.path.getsize(os.path.join(root, "JPEGImages", i + ".jpg")) for i in ids)
-    meta = {"images": n, "scored_pixels": int(npix), "jpeg_bytes": int(nbytes), "write_seconds": round(time.time() - t0, 1)}
+    nbytes = sum(os.path.getsize(os.path.join(dirs[0], i + ".jpg")) for i in ids)
+    meta = {"dataset": "coco" if coco else "voc", "images": n, "scored_pixels": int(npix), "jpeg_bytes": int(nbytes), "write_seconds": round(time.time() - t0, 1)}
     json.dump(meta, open(os.path.join(base, "meta.json"), "w"))
     print("wrote", meta)
 
@@ -100,16 +106,23 @@ def run(base, json_out, extra):
     import logging
     logging.basicConfig(level=logging.INFO, format="%(message)s")
     from excel_amd.tools import infer_lam
-    argv = ["--data_folder", os.path.join(base, "VOC2012"), "--list_folder", os.path.join(base, "lists"), "--infer_set", "train",
-            "--model", os.path.join(base, "ViT-B-16.pt"), "--bpe_path", os.path.join(base, "bpe_tiny_vocab.txt.gz"),
-            "--batch_size", "32", "--json_out", json_out] + extra
-    t0 = time.time()
-    score, total = infer_lam.validate(infer_lam.get_parser().parse_args(argv))
-    wall = time.time() - t0
     meta = json.load(open(os.path.join(base, "meta.json")))
+    coco = meta.get("dataset") == "coco"
+    argv = ["--model", os.path.join(base, "ViT-B-16.pt"), "--bpe_path", os.path.join(base, "bpe_tiny_vocab.txt.gz"),
+            "--list_folder", os.path.join(base, "lists"), "--json_out", json_out]
+    if coco:   # BASELINE configs[4]: 80 classes + background, 512 x 512, batch 16
+        argv += ["--data_folder", os.path.join(base, "COCO"), "--dataset_name", "ms_coco", "--num_classes", "81", "--infer_set", "val",
+                 "--resize_size", "512", "--batch_size", "16", "--num_attri", "224"]      # (the shipped COCO bank has 224 clusters)
+    else:
+        argv += ["--data_folder", os.path.join(base, "VOC2012"), "--infer_set", "train", "--batch_size", "32"]
+    t0 = time.time()
+    score, total = infer_lam.validate(infer_lam.get_parser().parse_args(argv + extra))
+    wall = time.time() - t0
     rec = json.load(open(json_out))
     tot = int(total.sum().item()) if hasattr(total, "sum") else 0
-    rec.update({"workload": "BASELINE configs[3] list size on one GPU: on-disk VOC-format tree, JPEG/PNG decode, ragged batches",
+    rec.update({"workload": ("one rank's shard of BASELINE configs[4] (COCO val2014 / 8 = 5 063 images, 80 classes, 512 x 512, batch 16, single scale) on one GPU: "
+                             "on-disk COCO-format tree, JPEG/PNG decode, ragged batches") if coco else
+                            "BASELINE configs[3] list size on one GPU: on-disk VOC-format tree, JPEG/PNG decode, ragged batches",
                 "data": "synthetic images / seeded random checkpoint in the published file formats (mIoU is plumbing)",
                 "wall_seconds_incl_model_build": round(wall, 2), "scored_pixels_expected": meta["scored_pixels"], "scored_pixels": tot,
                 "every_pixel_scored_once": tot == meta["scored_pixels"], "jpeg_megabytes": round(meta["jpeg_bytes"] / 1e6, 1),
@@ -120,6 +133,6 @@ def run(base, json_out, extra):
 
 if __name__ == "__main__":
     if sys.argv[1] == "write":
-        write(sys.argv[2], int(sys.argv[3]))
+        write(sys.argv[2], int(sys.argv[3]), coco=len(sys.argv) > 4 and sys.argv[4] == "coco")
     else:
         run(sys.argv[2], sys.argv[3], sys.argv[4:])
