@@ -173,10 +173,16 @@ struct ProfScope {
 #ifdef EXCEL_SPLIT_F16
 typedef _Float16 split_t;
 #define EXCEL_MFMA16(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z)
+#define EXCEL_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
 #define EXCEL_SPLIT_NAME "f16"
 #else
 typedef __bf16 split_t;
 #define EXCEL_MFMA16(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z)
+// 16x16x32: the same flops per cycle, K = 32 inside one instruction - half the accumulator read-modify-writes per flop.  Under the chip's
+// power cap that is the cheaper form: the GEMM's MFMA stream alone sustains 2 127 TFLOP/s with it against 1 800 with 32x32x16 on random
+// operand bits (tools_dev/micro/mfma_power.hip, profiles/r04_micro_mfma_power.txt).  A: row = lane % 16, k = 8 (lane / 16) + 0..7;
+// B: column = lane % 16, same k; D: row = 4 (lane / 16) + reg, column = lane % 16.
+#define EXCEL_MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 #define EXCEL_SPLIT_NAME "bf16"
 #endif
 typedef split_t splitx8 __attribute__((ext_vector_type(8)));

@@ -36,11 +36,11 @@ typedef unsigned short u16;
 // Shared epilogue of the GEMM kernels: bias -> activation -> (+ residual) -> store, specialised per output mode so the
 // 64 accumulator elements of a thread see no per-element mode branches, integer divisions or 64-bit multiplies.
 template <int OUT_MODE, int TI>
-__device__ __forceinline__ void bf_epilogue(const GemmBfArgs& p, const f32x16 (&acc)[TI][2], int m0, int n0, int wm, int wn, int lane) {
-    const int r = lane & 31;
+__device__ __forceinline__ void bf_epilogue(const GemmBfArgs& p, const f32x4 (&acc)[2 * TI][4], int m0, int n0, int wm, int wn, int lane) {
+    const int r = lane & 15;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + r;
+    for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wn * 64 + j * 16 + r;
         if (col >= p.N) continue;
         const float bv = p.bias ? p.bias[col] : 0.f;
         long long qcol_off = 0;
@@ -53,13 +53,13 @@ __device__ __forceinline__ void bf_epilogue(const GemmBfArgs& p, const f32x16 (&
             qcol_off = ((long long)qt * p.heads + qh) * p.tokN * p.hd + qd;     // + (b*3*heads*tokN + n) * hd per row
         }
 #pragma unroll
-        for (int i = 0; i < TI; ++i) {
-            const int rbase = m0 + wm * (TI * 32) + i * 32 + 4 * (lane >> 5);
+        for (int i = 0; i < 2 * TI; ++i) {
+            const int rbase = m0 + wm * (TI * 32) + i * 16 + 4 * (lane >> 4);
             int qb = 0, qn = 0;
             if (OUT_MODE == GEMM_OUT_QKV_HEADMAJOR) { qb = rbase / p.tokN; qn = rbase - qb * p.tokN; }
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int dr = (e & 3) + 8 * (e >> 2);
+            for (int e = 0; e < 4; ++e) {
+                const int dr = e;
                 const int row = rbase + dr;
                 if (row >= p.M) continue;
                 float v = acc[i][j][e] + bv;
@@ -94,9 +94,9 @@ __device__ __forceinline__ void bf_epilogue(const GemmBfArgs& p, const f32x16 (&
 // 64x64 tile through 2 x (32 x 68-float) LDS rounds and stores row-contiguous 16-byte vectors: bias / residual become
 // float4 loads, fp32 rows are written as full 256-B segments, split-bf16 rows as 8-byte hi/lo groups.
 template <int OUT_MODE, int TI>
-__device__ __forceinline__ void bf_epilogue_lds(const GemmBfArgs& p, const f32x16 (&acc)[TI][2], int m0, int n0, int wm, int wn,
+__device__ __forceinline__ void bf_epilogue_lds(const GemmBfArgs& p, const f32x4 (&acc)[2 * TI][4], int m0, int n0, int wm, int wn,
                                                 int lane, float* scratch, int nti = TI) {
-    const int r = lane & 31;
+    const int r = lane & 15;
     const int c4 = (lane & 15) * 4;
     const int col = n0 + wn * 64 + c4;
     const bool col_ok = col < p.N;                       // N % 4 == 0: the whole float4 is inside or outside
@@ -113,10 +113,13 @@ __device__ __forceinline__ void bf_epilogue_lds(const GemmBfArgs& p, const f32x1
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
         if (i >= nti) break;                                  // (mixed-height tiles: a short tile has nti = TI - 1 row tiles per wave)
+        // accumulator tile (16-row tile t, 16-column tile j): register e = row 4 (lane / 16) + e, column lane % 16
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { if (EXCEL_DBG(p.dbg) & 32) break; scratch[c32_row(e, lane) * 68 + j * 32 + r] = acc[i][j][e]; }
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { if (EXCEL_DBG(p.dbg) & 32) break; scratch[(t * 16 + 4 * (lane >> 4) + e) * 68 + j * 16 + r] = acc[2 * i + t][j][e]; }
         __builtin_amdgcn_s_waitcnt(0xc07f);               // this wave's LDS writes landed (same-wave read back)
         // Batched by hand: 8 LDS reads, then (residual) 8 global loads, then the math, then the stores.  Written as one loop with the row
         // test in front, every iteration was its own chain of basic blocks - ds_read, lgkmcnt(0), residual load, vmcnt(0) (which also waits
@@ -128,7 +131,7 @@ __device__ __forceinline__ void bf_epilogue_lds(const GemmBfArgs& p, const f32x1
 #pragma unroll
         for (int it = 0; it < EB; ++it) {
             const int row_l = (h0 + it) * 4 + (lane >> 4);
-            if (EXCEL_DBG(p.dbg) & 32) { v[it][0] = acc[i][0][h0 + it]; v[it][1] = acc[i][0][h0 + it + 8]; v[it][2] = acc[i][1][h0 + it]; v[it][3] = acc[i][1][h0 + it + 8]; }   // dev arm: no LDS transpose (wrong values, same registers live)
+            if (EXCEL_DBG(p.dbg) & 32) { v[it][0] = acc[2 * i][it][0]; v[it][1] = acc[2 * i][it][1]; v[it][2] = acc[2 * i + 1][it][2]; v[it][3] = acc[2 * i + 1][it][3]; }   // dev arm: no LDS transpose (wrong values, same registers live)
             else v[it] = *reinterpret_cast<const f32x4*>(&scratch[row_l * 68 + c4]);
         }
         const int row0 = m0 + wm * (nti * 32) + i * 32 + (lane >> 4);
@@ -277,15 +280,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16x3_kernel(GemmBfArgs
         for (int j = 0; j < PER_WAVE; ++j) issue_piece(kt, stage, j);
     };
 
-    f32x16 acc[TI][2];
+    // accumulators: 2 TI x 4 tiles of 16 x 16 (v_mfma_f32_16x16x32: one instruction covers the whole 32-k stage)
+    f32x4 acc[2 * TI][4];
 #pragma unroll
-    for (int i = 0; i < TI; ++i)
+    for (int i = 0; i < 2 * TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int sw = (r >> 1) & 7;      // (row>>1)&7 of every fragment row this lane reads (tile rows are r + multiples of 32)
+    const int r16 = lane & 15, kg = lane >> 4;     // fragment row / column of a 16-wide tile, k group (8 k each)
+    const int sw = (r16 >> 1) & 7;    // (row>>1)&7 of every fragment row this lane reads (tile rows are r16 + multiples of 16)
     const int nk = p.K / TBK;
 
     // kt_next >= 0 (TI == 5 path): the next tile's LDS-DMA pieces are issued one per (k16 sub-step, row tile) pair INSIDE the MFMA
@@ -297,60 +300,39 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16x3_kernel(GemmBfArgs
     auto compute = [&](int stage, int kt_next) {
         const u16* as = smem + stage * STAGE;
         const u16* bs = as + BM * TROW;
+        const int ch = (kg ^ sw) * 8, cl = ((4 + kg) ^ sw) * 8;       // this lane's 16-byte chunk of the hi / lo half of a 128-byte row
+        splitx8 bh[4], bl[4];
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const int ch = ((s2 * 2 + kh) ^ sw) * 8, cl = ((4 + s2 * 2 + kh) ^ sw) * 8;
-            splitx8 bh[2], bl[2];
+        for (int j = 0; j < 4; ++j) {
+            const u16* rowp = bs + (wn * 64 + j * 16 + r16) * TROW;
+            bh[j] = *reinterpret_cast<const splitx8*>(rowp + ch);
+            bl[j] = *reinterpret_cast<const splitx8*>(rowp + cl);
+        }
+        // A fragments are streamed one 16-row tile ahead (the accumulators leave < 100 registers for everything else in the 320 x 256
+        // tile), and the scheduler may not hoist them
+        splitx8 ah[2], al[2];
+        {
+            const u16* rowp = as + (wm * wm_rows + r16) * TROW;
+            ah[0] = *reinterpret_cast<const splitx8*>(rowp + ch);
+            al[0] = *reinterpret_cast<const splitx8*>(rowp + cl);
+        }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const u16* rowp = bs + (wn * 64 + j * 32 + r) * TROW;
-                bh[j] = *reinterpret_cast<const splitx8*>(rowp + ch);
-                bl[j] = *reinterpret_cast<const splitx8*>(rowp + cl);
+        for (int i = 0; i < 2 * TI; ++i) {
+            if (kt_next >= 0 && i < PER_WAVE) issue_piece(kt_next, stage ^ 1, i);
+            if (MIX && i >= 2 * nti) continue;                  // short tile: this wave has 2 (TI - 1) row tiles (the DMA piece above still goes out)
+            if (i + 1 < 2 * TI && (!MIX || i + 1 < 2 * nti)) {
+                const u16* rowp = as + (wm * wm_rows + (i + 1) * 16 + r16) * TROW;
+                ah[(i + 1) & 1] = *reinterpret_cast<const splitx8*>(rowp + ch);
+                al[(i + 1) & 1] = *reinterpret_cast<const splitx8*>(rowp + cl);
             }
-            if (TI <= 4) {
-                splitx8 ah[TI], al[TI];
 #pragma unroll
-                for (int i = 0; i < TI; ++i) {
-                    const u16* rowp = as + (wm * (TI * 32) + i * 32 + r) * TROW;
-                    ah[i] = *reinterpret_cast<const splitx8*>(rowp + ch);
-                    al[i] = *reinterpret_cast<const splitx8*>(rowp + cl);
-                }
-#pragma unroll
-                for (int i = 0; i < TI; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        // small terms first, the dominant hi.hi product last
-                        acc[i][j] = EXCEL_MFMA16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = EXCEL_MFMA16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = EXCEL_MFMA16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                    }
-            } else {
-                // register-tight variant (TI*2*16 accumulator registers leave < 100 for everything else): A fragments
-                // are streamed one row tile ahead instead of all at once, and the scheduler may not hoist them
-                splitx8 ah[2], al[2];
-                {
-                    const u16* rowp = as + (wm * wm_rows + r) * TROW;
-                    ah[0] = *reinterpret_cast<const splitx8*>(rowp + ch);
-                    al[0] = *reinterpret_cast<const splitx8*>(rowp + cl);
-                }
-#pragma unroll
-                for (int i = 0; i < TI; ++i) {
-                    if (kt_next >= 0 && s2 * TI + i < PER_WAVE) issue_piece(kt_next, stage ^ 1, s2 * TI + i);
-                    if (MIX && i >= nti) continue;                  // short tile: this wave has TI - 1 row tiles (the DMA piece above still goes out)
-                    if (i + 1 < TI && (!MIX || i + 1 < nti)) {
-                        const u16* rowp = as + (wm * wm_rows + (i + 1) * 32 + r) * TROW;
-                        ah[(i + 1) & 1] = *reinterpret_cast<const splitx8*>(rowp + ch);
-                        al[(i + 1) & 1] = *reinterpret_cast<const splitx8*>(rowp + cl);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        acc[i][j] = EXCEL_MFMA16(al[i & 1], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = EXCEL_MFMA16(ah[i & 1], bl[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = EXCEL_MFMA16(ah[i & 1], bh[j], acc[i][j], 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+            for (int j = 0; j < 4; ++j) {
+                // small terms first, the dominant hi.hi product last
+                acc[i][j] = EXCEL_MFMA32(al[i & 1], bh[j], acc[i][j]);
+                acc[i][j] = EXCEL_MFMA32(ah[i & 1], bl[j], acc[i][j]);
+                acc[i][j] = EXCEL_MFMA32(ah[i & 1], bh[j], acc[i][j]);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -362,21 +344,19 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16x3_kernel(GemmBfArgs
         for (int q = 0; q < 8; ++q) { fa[q] = split_hi(0.001f * (float)(lane + q)); fb[q] = split_hi(0.002f * (float)(lane ^ q)); }
         for (int kt = 0; kt < nk; ++kt)
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
+            for (int i = 0; i < 2 * TI; ++i)
 #pragma unroll
-                for (int i = 0; i < TI; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        acc[i][j] = EXCEL_MFMA16(fb, fa, acc[i][j], 0, 0, 0);
-                        acc[i][j] = EXCEL_MFMA16(fa, fb, acc[i][j], 0, 0, 0);
-                        acc[i][j] = EXCEL_MFMA16(fa, fa, acc[i][j], 0, 0, 0);
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j] = EXCEL_MFMA32(fb, fa, acc[i][j]);
+                    acc[i][j] = EXCEL_MFMA32(fa, fb, acc[i][j]);
+                    acc[i][j] = EXCEL_MFMA32(fa, fa, acc[i][j]);
+                }
     } else if (NSTAGE == 2) {
         issue_tile(0, 0);
         __syncthreads();                  // drains the LDS-DMA (vmcnt(0)) and publishes the tile
         for (int kt = 0; kt < nk; ++kt) {
             const bool more = kt + 1 < nk && !(EXCEL_DBG(p.dbg) & 2);
-            if (TI > 4 && PER_WAVE <= 2 * TI && !(EXCEL_DBG(p.dbg) & 1)) {
+            if (TI > 4 && PER_WAVE <= 2 * TI && !(EXCEL_DBG(p.dbg) & 1)) {      // (one piece per 16-row tile: 2 TI slots per stage)
                 compute(kt & 1, more ? kt + 1 : -1);               // tile kt+1 streams in behind this step's MFMAs
             } else {
                 if (more) issue_tile(kt + 1, (kt + 1) & 1);        // in flight during this step's MFMAs
@@ -411,11 +391,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16x3_kernel(GemmBfArgs
         // dev arm "no epilogue": the k-loop alone (the accumulators stay live through a store that never happens)
         float sum = 0.f;
 #pragma unroll
-        for (int i = 0; i < TI; ++i)
+        for (int i = 0; i < 2 * TI; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) sum += acc[i][j][e];
+                for (int e = 0; e < 4; ++e) sum += acc[i][j][e];
         if (sum == 1.2345e-30f) p.C[0] = sum;
         return;
     }

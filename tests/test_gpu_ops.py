@@ -153,7 +153,10 @@ def test_vit_tiny_strip_three_tiles_per_wave_bf16x3(ops, S):
     got = host(r["attn"])
     for l in range(TINY.layers):
         assert maxabs(got[l], attn[l]) < 2e-4 * (TINY.heads if l >= TINY.layers - TINY.n_surgery else 1.0), f"attn layer {l}"
-    assert relmax(host(r["w_aff"]), attn[-6:, :, 1:, 1:].mean(0, dtype=np.float32)) < 2e-4
+    # 3e-4: bf16x3's accumulated rounding in this tiny net (width 128) lands at 1.8-2.3e-4 depending on the GEMM's accumulation order - with
+    # the K = 32 MFMA form 2.30e-4 / 2.19e-4, while the GEMM's own error against float64 is unchanged to three digits (rms 4.43e-6, max 2.7e-5 of
+    # the output's rms for both forms: tools_dev/gemm_accuracy.py)
+    assert relmax(host(r["w_aff"]), attn[-6:, :, 1:, 1:].mean(0, dtype=np.float32)) < 3e-4
     assert relmax(host(r["x_raw"]), x) < 5e-4
 
 
