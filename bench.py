@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 F32_MATRIX_PEAK_TF = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 BF16_MFMA_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak
-MFMA_SUSTAINED_RANDOM_TF = {"bf16x3": 1770.0, "f16x3": 1700.0}   # whole-chip MFMA-only stream on random operand bits (see the roofline block)
+MFMA_SUSTAINED_RANDOM_TF = {"bf16x3": 2130.0, "f16x3": 2040.0}   # whole-chip MFMA-only stream (16x16x32 form) on random operand bits (see the roofline block)
 # SURVEY.md 8 flop table @448^2 (per image, GFLOP): rows that run on the gemm_f32 kernel
 GEMM_GFLOP_PER_IMG = 0.925 + 12 * (2.778 + 0.926 + 7.408) + 5 * (0.926 + 0.947) + 0.617 + 0.036
 VIT_CAM_GFLOP_PER_IMG = 181.2  # the reference algorithm's ViT + CAM work
@@ -405,9 +405,9 @@ def main(argv=None, hooks=None):
                     traffic = par_traffic = traffic_source = None
             if mode in ("bf16x3", "f16x3"):
                 peak = BF16_MFMA_PEAK_TF
-                kname = ("gemm_bf16x3_kernel (fp32 operands as bf16 hi+lo planes, 3 x v_mfma_f32_32x32x16_bf16 per product; "
+                kname = ("gemm_bf16x3_kernel (fp32 operands as bf16 hi+lo planes, 3 x v_mfma_f32_16x16x32_bf16 per product; "
                          "all nn.Linear / patch-embed / proj GEMMs)") if mode == "bf16x3" else (
-                         "gemm_bf16x3_kernel, IEEE-half instance (fp32 operands as f16 hi+lo planes, 3 x v_mfma_f32_32x32x16_f16 per product)")
+                         "gemm_bf16x3_kernel, IEEE-half instance (fp32 operands as f16 hi+lo planes, 3 x v_mfma_f32_16x16x32_f16 per product)")
             else:
                 peak = F32_MATRIX_PEAK_TF
                 kname = "gemm_f32_kernel<NT> (fp32 MFMA 32x32x2; all nn.Linear / patch-embed / proj / sim GEMMs)"
@@ -425,8 +425,9 @@ def main(argv=None, hooks=None):
                 out["roofline"]["mfma_issue_frac"] = round(3 * achieved / peak, 4)
                 out["roofline"]["fp32_equivalent_peak"] = round(peak / 3, 1)
                 # what the whole chip sustains on THIS MFMA stream with random operand bits, operands in registers, no memory traffic
-                # (tools_dev/micro/mfma_power.hip, profiles/r04_micro_mfma_power.txt: 2 470 TFLOP/s with zero operands, 1 680-1 810 with
-                # random mantissas - the clock drops from 2.37 to 1.6-1.7 GHz between 128 and 256 busy CUs): the power-capped ceiling
+                # (tools_dev/micro/mfma_power.hip, profiles/r04_micro_mfma_power.txt: 2 470 TFLOP/s with zero operands; with random mantissas
+                # 1 680-1 810 for the 32x32x16 form and 2 130 for the 16x16x32 form the kernel uses - the clock drops from 2.37 to 1.7 /
+                # 2.04 GHz between 128 and 256 busy CUs): the power-capped ceiling
                 sustained = MFMA_SUSTAINED_RANDOM_TF[mode]
                 out["roofline"]["sustained_peak_random_operands"] = sustained
                 out["roofline"]["mfma_frac_of_sustained"] = round(3 * achieved / sustained, 4)

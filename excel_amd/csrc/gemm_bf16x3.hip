@@ -3,7 +3,8 @@
 // Every fp32 operand x is carried as two bf16 planes  x = hi + lo  (hi = bf16(x), lo = bf16(x - hi); 16 mantissa bits,
 // fp32 exponent range, so no scaling and no overflow concerns) and a product is evaluated as
 //     a.b ~= ah.bh + ah.bl + al.bh          (the al.bl term is 2^-16 relative and dropped)
-// with three v_mfma_f32_32x32x16_bf16 into ONE fp32 accumulator.  Products of bf16 values are exact in fp32, so the
+// with three matrix-core instructions into ONE fp32 accumulator - since round 4 v_mfma_f32_16x16x32_bf16 (K = 32 per instruction: half the
+// accumulator updates per flop of the 32x32x16 form; under the chip's power cap it sustains 2 130 instead of 1 800 TFLOP/s on random bits).  Products of bf16 values are exact in fp32, so the
 // only error is the dropped term and the lo truncation: ~2^-17 relative per product.  Measured through the whole
 // ViT-B/16 surgery forward at 448^2 the CAM moves by 8.8e-6 max-abs against exact fp32 (gate: 1e-3) -- see DESIGN.md 2.
 // The bf16 pipe issues 16x the MACs per cycle of the f32-input MFMA, so 3 MFMAs per product is a 5.3x higher ceiling
@@ -18,8 +19,8 @@
 //   C[M,N] (fp32 or split) = act(A_split[M,K] . W_split[N,K]^T + bias) + residual
 // Tiling: 128x128x32 block tile, 4 waves (2x2) x (2x2) MFMA tiles of 32x32, LDS double buffer,
 // direct-to-LDS staging
-// (global_load_lds_dwordx4, XOR-swizzled 128-B rows: conflict-free ds_read_b128), XCD-aware tile order; per k16 step a wave does 8 ds_read_b128 and
-// 12 MFMAs.
+// (global_load_lds_dwordx4, XOR-swizzled 128-B rows: conflict-free ds_read_b128), XCD-aware tile order; per 32-k stage a wave of the
+// 128 x 128 tile does 16 ds_read_b128 and 48 MFMAs (16 x 16 x 32).
 #include <stdlib.h>
 #include "common.h"
 #include "excel_internal.h"

@@ -48,7 +48,7 @@ int excel_split_bf16(const float* in, void* out, long long rows, int K, void* st
 int excel_gemm_bf16x3(const void* A_split, const void* W_split, float* C, const float* bias, const float* residual,
                       int M, int N, int K, int act, int split_out, void* stream);
 /* The same two building blocks with IEEE-half planes ("f16x3": hi = half(x), lo = half(x - hi); 11 + 11 mantissa bits where lo stays
- * a normal half, range 65 504; v_mfma_f32_32x32x16_f16, same layouts and rate). */
+ * a normal half, range 65 504; v_mfma_f32_16x16x32_f16 in the GEMM, same layouts and rate). */
 int excel_split_f16(const float* in, void* out, long long rows, int K, void* stream);
 int excel_gemm_f16x3(const void* A_split, const void* W_split, float* C, const float* bias, const float* residual,
                      int M, int N, int K, int act, int split_out, void* stream);

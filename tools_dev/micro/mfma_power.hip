@@ -50,6 +50,10 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, int data) {
                     a4[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, a4[i], 0, 0, 0);
                     a4[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, a4[i], 0, 0, 0);
                     a4[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, a4[i], 0, 0, 0);
+                } else {
+                    a4[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, a4[i], 0, 0, 0);
+                    a4[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, a4[i], 0, 0, 0);
+                    a4[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, a4[i], 0, 0, 0);
                 }
             }
         }
@@ -106,13 +110,14 @@ int main(int argc, char** argv) {
     const char* dn[3] = {"zeros ", "smooth", "random"};
     const int norder = argc > 2 ? 3 : 1;                      // any second argument: also the operand-reuse order and the 16x16x32 form (bf16, random data)
     for (int order = 0; order < norder; ++order)
-    for (int f16 = 0; f16 < (order ? 1 : 2); ++f16)
+    for (int f16 = 0; f16 < (order == 1 ? 1 : 2); ++f16)
         for (int data = (order ? 2 : 0); data < 3; ++data)
             for (int grid : {32, 64, 128, 192, 256}) {
                 float best = 1e30f, last = 0.f;
                 for (int rep = 0; rep < 6; ++rep) {              // back to back: the later repetitions see the steady-state clock
                     hipEventRecord(e0);
-                    if (order == 2) hipLaunchKernelGGL((k<0, 2>), dim3(grid), dim3(512), 0, 0, out, iters, data);
+                    if (order == 2 && f16) hipLaunchKernelGGL((k<1, 2>), dim3(grid), dim3(512), 0, 0, out, iters, data);
+                    else if (order == 2) hipLaunchKernelGGL((k<0, 2>), dim3(grid), dim3(512), 0, 0, out, iters, data);
                     else if (order) hipLaunchKernelGGL((k<0, 1>), dim3(grid), dim3(512), 0, 0, out, iters, data);
                     else if (f16) hipLaunchKernelGGL((k<1, 0>), dim3(grid), dim3(512), 0, 0, out, iters, data);
                     else hipLaunchKernelGGL((k<0, 0>), dim3(grid), dim3(512), 0, 0, out, iters, data);
