@@ -34,6 +34,27 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, int data) {
         else { bf16x8 x; __builtin_memcpy(&x, raw[f], 16); return x; }
     };
     auto ah0 = frag(0), al0 = frag(1), ah1 = frag(2), al1 = frag(3), bh0 = frag(4), bl0 = frag(5), bh1 = frag(6), bl1 = frag(7);
+    if constexpr (ORDER == 3) {
+        // 16x16x32 with the accumulators in AGPRs (inline asm, "+a"): does the accumulator file matter for power?
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        f32x4 a4[20];
+        for (int i = 0; i < 20; ++i) a4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 20; ++i) {
+                const auto& ah = (i & 1) ? ah1 : ah0;
+                const auto& al = (i & 1) ? al1 : al0;
+                const auto& bh = (i & 2) ? bh1 : bh0;
+                const auto& bl = (i & 2) ? bl1 : bl0;
+                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n v_mfma_f32_16x16x32_bf16 %0, %3, %4, %0\n v_mfma_f32_16x16x32_bf16 %0, %3, %2, %0"
+                             : "+a"(a4[i]) : "v"(al), "v"(bh), "v"(ah), "v"(bl));
+            }
+        }
+        float s4 = 0.f;
+        for (int i = 0; i < 20; ++i) s4 += a4[i][0] + a4[i][1] + a4[i][2] + a4[i][3];
+        if (s4 == 1.2345e-30f) out[0] = s4;
+        return;
+    }
     if constexpr (ORDER == 2) {
         // the same flops as 16x16x32 instructions (60 per block on 20 accumulators of 4 registers, three dependent per accumulator)
         typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -108,15 +129,16 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     const char* dn[3] = {"zeros ", "smooth", "random"};
-    const int norder = argc > 2 ? 3 : 1;                      // any second argument: also the operand-reuse order and the 16x16x32 form (bf16, random data)
+    const int norder = argc > 2 ? 4 : 1;                      // any second argument: also the operand-reuse order and the 16x16x32 form (bf16, random data)
     for (int order = 0; order < norder; ++order)
-    for (int f16 = 0; f16 < (order == 1 ? 1 : 2); ++f16)
+    for (int f16 = 0; f16 < ((order == 1 || order == 3) ? 1 : 2); ++f16)
         for (int data = (order ? 2 : 0); data < 3; ++data)
             for (int grid : {32, 64, 128, 192, 256}) {
                 float best = 1e30f, last = 0.f;
                 for (int rep = 0; rep < 6; ++rep) {              // back to back: the later repetitions see the steady-state clock
                     hipEventRecord(e0);
-                    if (order == 2 && f16) hipLaunchKernelGGL((k<1, 2>), dim3(grid), dim3(512), 0, 0, out, iters, data);
+                    if (order == 3) hipLaunchKernelGGL((k<0, 3>), dim3(grid), dim3(512), 0, 0, out, iters, data);
+                    else if (order == 2 && f16) hipLaunchKernelGGL((k<1, 2>), dim3(grid), dim3(512), 0, 0, out, iters, data);
                     else if (order == 2) hipLaunchKernelGGL((k<0, 2>), dim3(grid), dim3(512), 0, 0, out, iters, data);
                     else if (order) hipLaunchKernelGGL((k<0, 1>), dim3(grid), dim3(512), 0, 0, out, iters, data);
                     else if (f16) hipLaunchKernelGGL((k<1, 0>), dim3(grid), dim3(512), 0, 0, out, iters, data);
@@ -127,7 +149,7 @@ int main(int argc, char** argv) {
                     if (last < best) best = last;
                 }
                 const double cyc = 2.0 * iters * 30 * 32;
-                printf("%s%s %s grid %3d: best %8.1f us  last %8.1f us  -> %.2f GHz effective (last), %.0f TFLOP/s dense-equivalent\n", order == 2 ? "16x16x32 " : order ? "reuse-order " : "", f16 ? "f16 " : "bf16", dn[data], grid,
+                printf("%s%s %s grid %3d: best %8.1f us  last %8.1f us  -> %.2f GHz effective (last), %.0f TFLOP/s dense-equivalent\n", order == 3 ? "16x16x32-agpr " : order == 2 ? "16x16x32 " : order ? "reuse-order " : "", f16 ? "f16 " : "bf16", dn[data], grid,
                        best * 1e3, last * 1e3, cyc / (last * 1e-3) * 1e-9, grid * 8.0 * iters * 30 * 32768.0 / (last * 1e-3) * 1e-12);
             }
     return 0;
