@@ -497,6 +497,8 @@ def main(argv=None, hooks=None):
             # benchmark's images - CAM max-abs difference (gate 1e-3; infer_lam falls back to exact fp32 above 5e-4)
             out["numerics_check"] = model.check_numerics(batches[0][0][:4], fallback=False)
         if on_gpu and world == 1 and args.ragged_images > 0:
+            gc.collect()
+            gc.freeze()                                             # as infer_lam.validate does: later collections skip the start-up heap
             out["harness_ragged"] = harness_ragged(model, device, n_images=args.ragged_images, batch=B)
         print(json.dumps(out), flush=True)
         v = out.get("verify")
