@@ -123,6 +123,48 @@ def cpu_baseline(max_images, seed, budget_s=60.0):
                       f"ViT and PAR + numpy for the small stages, {threads} threads, {dt:.1f} s"}, preds
 
 
+def power_sideline(pipe, batch, seconds, B):
+    """Socket power while the SAME step runs in an untimed loop: `rocm-smi --showpower --showclocks` sampled from a side thread every
+    ~0.25 s (a subprocess: it does not hold the interpreter).  -> mean W / MHz of the samples behind the ramp, joules per image.
+    The step is energy-bound on this part (every stage sits at the socket power cap), so this is its other roofline."""
+    import re, shutil, subprocess, threading
+    import torch
+    if not shutil.which("rocm-smi"):
+        return None
+    stop, samples = threading.Event(), []
+
+    def sampler():
+        while not stop.is_set():
+            try:
+                t = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=5).stdout
+                w = re.findall(r"Package Power \(W\): (\d+\.\d+)", t)
+                c = re.findall(r"sclk clock level: \S+ \((\d+)Mhz\)", t)
+                if w and c:
+                    samples.append((float(w[0]), int(c[0])))
+            except Exception:
+                pass
+            time.sleep(0.2)
+
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(8):
+            pipe.run_batch(*batch)
+        torch.cuda.synchronize()
+        n += 8
+    dt = (time.perf_counter() - t0) / n
+    stop.set()
+    th.join()
+    mid = samples[2:-1] if len(samples) > 5 else samples            # drop the ramp at both ends
+    if not mid:
+        return None
+    w = sum(x[0] for x in mid) / len(mid)
+    return {"socket_power_w": round(w, 1), "shader_clock_mhz": round(sum(x[1] for x in mid) / len(mid)), "samples": len(mid),
+            "ms_per_step": round(dt * 1e3, 3), "joules_per_step": round(w * dt, 2), "joules_per_image": round(w * dt / B, 3),
+            "source": "rocm-smi socket power sampled during an untimed loop of the same step"}
+
+
 def csrc_sha16():
     """Id of the kernel sources in the tree (excel_amd/build.py:source_id): stamps profiles so the line can say whether `traffic` was
     measured on this code, and is compared with the id compiled into the loaded library (`excel_build_id`)."""
@@ -245,6 +287,7 @@ def main(argv=None, hooks=None):
     ap.add_argument("--cpu-images", type=int, default=64, help="upper bound of the CPU-baseline sample (stops after ~60 s of CPU work; 0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--ragged-images", type=int, default=256, help="images of the harness_ragged side-line (0 = skip)")
+    ap.add_argument("--power-seconds", type=float, default=3.0, help="untimed loop of the step with rocm-smi power sampling (0 = skip)")
     ap.add_argument("--overlap", type=int, default=int(os.environ.get("EXCEL_BENCH_OVERLAP", "0")),
                     help="1: two-stream software pipeline (PAR of batch i overlaps the ViT of batch i+1)")
     ap.add_argument("--split", type=int, default=int(os.environ.get("EXCEL_BENCH_SPLIT", "1")),
@@ -496,6 +539,8 @@ def main(argv=None, hooks=None):
             # the guard a user runs on his own weights (ExCEL_model.check_numerics): the default bf16x3 mode against exact fp32 on four of the
             # benchmark's images - CAM max-abs difference (gate 1e-3; infer_lam falls back to exact fp32 above 5e-4)
             out["numerics_check"] = model.check_numerics(batches[0][0][:4], fallback=False)
+        if on_gpu and world == 1 and args.power_seconds > 0:
+            out["power"] = power_sideline(pipe, batches[0], args.power_seconds, B)
         if on_gpu and world == 1 and args.ragged_images > 0:
             gc.collect()
             gc.freeze()                                             # as infer_lam.validate does: later collections skip the start-up heap
