@@ -696,3 +696,11 @@ def test_clip_text_prompt_lists():
     voc, coco = clip_text.text_prompts(21), clip_text.text_prompts(81)
     assert len(voc) == 45 and len(coco) == 103 and voc[0] == "aeroplane" and voc[14].startswith("person with clothes")
     assert voc[20:] == clip_text.BACKGROUND_CATEGORY and coco[80:] == clip_text.BACKGROUND_CATEGORY_COCO
+
+
+def test_bench_power_sideline_without_rocm_smi(monkeypatch):
+    """bench.py's power side-line is optional: without `rocm-smi` on the PATH it reports nothing and never touches the pipeline."""
+    import shutil
+    import bench
+    monkeypatch.setattr(shutil, "which", lambda name: None)
+    assert bench.power_sideline(pipe=None, batch=None, seconds=0.1, B=32) is None
