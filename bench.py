@@ -67,7 +67,8 @@ def cpu_baseline(max_images, seed, budget_s=60.0):
     ncpu = os.cpu_count() or 1
     cfg = VitConfig(width=768, layers=12, heads=12, patch=16, out_dim=512, input_resolution=224, n_surgery=5)
     w = oracle.vit.reload_self_attn(synthetic.make_vit_state_dict(seed=0), cfg, 28, "train")
-    bank = np.load(os.path.join(ROOT, "tests", "golden", "attr_bank_pascal_voc.npz"))["bank"]
+    from excel_amd.model.load_attr import BANK_DIR
+    bank = np.load(os.path.join(BANK_DIR, "attr_bank_pascal_voc.npz"))["bank"]
     text_attr = oracle.attr.attr_aggregate(synthetic.make_text_features(45), bank, 20)
     ds = synthetic.SyntheticSegDataset(max_images, (448, 448), seed=seed)
     # thread count: "all threads" is not the fastest setting on a 256-thread host (measured on the GPU box: 16 threads 1.7 s/image,

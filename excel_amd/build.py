@@ -50,6 +50,21 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _object_sig(src, cmd_flags):
+    """Content signature of ONE object: its source, every header / .inc under csrc (any .hip may include any of them: a superset is
+    cheap and never stale), the public header and the exact command-line flags.  Objects are rebuilt when this changes, whatever the
+    time stamps say - so the library's build id (source_id over the same files) really describes every object linked into it."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(" ".join(cmd_flags).encode())
+    h.update(open(src, "rb").read())
+    for f in sorted(f for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))):
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(CSRC, "..", "..", "include", "excel_hip.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build(force=False, verbose=True):
     """EXCEL_DEV=1 in the environment adds -DEXCEL_DEV: ablation / experiment switches read from environment variables are compiled
     in (development only; the shipped library has none)."""
@@ -63,32 +78,36 @@ def build(force=False, verbose=True):
     sig = " ".join([hipcc] + flags)
     if not force and (not os.path.exists(stamp) or open(stamp).read() != sig):
         force = os.path.exists(LIB) or any(os.path.exists(os.path.join(CSRC, s.replace(".hip", ".o"))) for s in SOURCES)
-    objs, jobs = [], []
+    import json
+    sigfile = os.path.join(CSRC, ".build_objs")
+    try:
+        sigs = json.load(open(sigfile))
+    except Exception:
+        sigs = {}
+    objs, jobs = [], []           # jobs: (command, object name, signature)
     for s in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(CSRC, s.replace(".hip", ".o"))
-        objs.append(obj)
-        extra = []
-        stale = force or _stale(obj, [src] + hdrs)
-        if s == "abi.hip":
-            # abi.hip carries the id of ALL sources (excel_build_id): it is rebuilt whenever any of them changed
-            extra = ['-DEXCEL_BUILD_ID="%s"' % sid]
-            idstamp = os.path.join(CSRC, ".build_id")
-            stale = stale or not os.path.exists(idstamp) or open(idstamp).read() != sid
-        if stale:
-            jobs.append([hipcc] + flags + extra + ["-c", src, "-o", obj])
-        if s in SPLIT_SOURCES:
-            obj16 = os.path.join(CSRC, s.replace(".hip", "_f16.o"))
-            objs.append(obj16)
-            if force or _stale(obj16, [src] + hdrs):
-                jobs.append([hipcc] + flags + ["-DEXCEL_SPLIT_F16", "-c", src, "-o", obj16])
+        variants = [("", [])] + ([("_f16", ["-DEXCEL_SPLIT_F16"])] if s in SPLIT_SOURCES else [])
+        for suffix, vflags in variants:
+            obj = os.path.join(CSRC, s.replace(".hip", suffix + ".o"))
+            objs.append(obj)
+            # abi.hip carries the id of ALL sources (excel_build_id): its flags change whenever any of them changed
+            extra = ['-DEXCEL_BUILD_ID="%s"' % sid] if s == "abi.hip" else []
+            sig_o = _object_sig(src, [hipcc] + flags + vflags + extra)
+            name = os.path.basename(obj)
+            if force or not os.path.exists(obj) or sigs.get(name) != sig_o:
+                jobs.append(([hipcc] + flags + vflags + extra + ["-c", src, "-o", obj], name, sig_o))
     if jobs:
         with cf.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
-            for cmd, res in zip(jobs, ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs)):
+            for (cmd, name, sig_o), res in zip(jobs, ex.map(lambda j: subprocess.run(j[0], capture_output=True, text=True), jobs)):
                 if res.returncode != 0:
+                    sigs.pop(name, None)
+                    json.dump(sigs, open(sigfile, "w"))
                     raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), res.stderr))
+                sigs[name] = sig_o
                 if verbose:
-                    print("[excel_amd.build] compiled", os.path.basename(cmd[-1]))
+                    print("[excel_amd.build] compiled", name)
+        json.dump(sigs, open(sigfile, "w"), indent=0, sort_keys=True)
     if force or jobs or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         res = subprocess.run(cmd, capture_output=True, text=True)

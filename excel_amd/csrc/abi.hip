@@ -228,12 +228,14 @@ static int vit_prepare_split_weights(excel_vit* h, int type) {
         return EXCEL_ERR_LAUNCH;
     }
     h->split_arena = (unsigned short*)arena;
-    h->split_type = type;
+    h->split_type = 0;               // the arena holds nothing usable until every split kernel has finished (set below, after the sync)
     float* cur = arena;
+    int put_rc = EXCEL_OK;
     auto put = [&](const float* src, size_t rows, size_t K) -> unsigned short* {
         unsigned short* dst = (unsigned short*)cur;
-        if (type == 2) excel_f16::excel_launch_split_bf16(src, dst, (long long)rows, (int)K, 0);
-        else excel_bf16::excel_launch_split_bf16(src, dst, (long long)rows, (int)K, 0);
+        const int rc = type == 2 ? excel_f16::excel_launch_split_bf16(src, dst, (long long)rows, (int)K, 0)
+                                 : excel_bf16::excel_launch_split_bf16(src, dst, (long long)rows, (int)K, 0);
+        if (rc != EXCEL_OK && put_rc == EXCEL_OK) put_rc = rc;
         cur += rows * K;
         return dst;
     };
@@ -247,10 +249,14 @@ static int vit_prepare_split_weights(excel_vit* h, int type) {
     }
     h->s_conv1 = put(h->w.conv1_w, D, Kc);
     h->s_projT = put(h->projT, c.out_dim, D);
+    // (one-time set-up on the legacy stream 0, which every blocking stream orders against; the device-wide sync above / this one make it
+    // safe for callers on non-blocking streams too)
+    if (put_rc != EXCEL_OK) return put_rc;
     if (hipStreamSynchronize(0) != hipSuccess) {
         excel_set_error("excel_vit: splitting weights failed: %s", hipGetErrorString(hipGetLastError()));
         return EXCEL_ERR_LAUNCH;
     }
+    h->split_type = type;            // only now: a failed re-split leaves split_type 0, so the next set_gemm_mode splits again
     return EXCEL_OK;
 }
 

@@ -189,10 +189,12 @@ typedef split_t splitx8 __attribute__((ext_vector_type(8)));
 typedef split_t splitx4 __attribute__((ext_vector_type(4)));
 // fp32 -> one 16-bit plane (hi = split_hi(x), lo = split_hi(x - hi)).  IEEE half saturates at +-65 504 instead of becoming inf: lo then
 // carries the next 65 504, so values up to 131 008 keep 11+ bits and anything beyond is clamped - a finite, visibly wrong product that
-// check_numerics catches, not a NaN; bf16 has the fp32 range.
+// check_numerics catches, not an inf; a NaN input stays NaN in both planes; bf16 has the fp32 range.
 __device__ __forceinline__ split_t split_hi(float x) {
 #ifdef EXCEL_SPLIT_F16
-    return (split_t)__builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
+    // v_med3_f32 with IEEE mode on returns a FINITE +-65 504 for a NaN input: keep the NaN (check_numerics and the GEMM self-check rely on
+    // a NaN of the fast path failing the comparison, not passing as a finite difference)
+    return (split_t)(x != x ? x : __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f));
 #else
     return (split_t)x;
 #endif

@@ -37,7 +37,7 @@ typedef unsigned short u16;
 // Shared epilogue of the GEMM kernels: bias -> activation -> (+ residual) -> store, specialised per output mode so the
 // 64 accumulator elements of a thread see no per-element mode branches, integer divisions or 64-bit multiplies.
 template <int OUT_MODE, int TI>
-__device__ __forceinline__ void bf_epilogue(const GemmBfArgs& p, const f32x4 (&acc)[2 * TI][4], int m0, int n0, int wm, int wn, int lane) {
+__device__ __forceinline__ void bf_epilogue(const GemmBfArgs& p, const f32x4 (&acc)[2 * TI][4], int m0, int n0, int wm, int wn, int lane, int nti = TI) {
     const int r = lane & 15;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -55,7 +55,8 @@ __device__ __forceinline__ void bf_epilogue(const GemmBfArgs& p, const f32x4 (&a
         }
 #pragma unroll
         for (int i = 0; i < 2 * TI; ++i) {
-            const int rbase = m0 + wm * (TI * 32) + i * 16 + 4 * (lane >> 4);
+            if (i >= 2 * nti) break;                              // (mixed-height tiles: a short tile's waves own nti = TI - 1 row tiles, and their rows start at wm * nti * 32)
+            const int rbase = m0 + wm * (nti * 32) + i * 16 + 4 * (lane >> 4);
             int qb = 0, qn = 0;
             if (OUT_MODE == GEMM_OUT_QKV_HEADMAJOR) { qb = rbase / p.tokN; qn = rbase - qb * p.tokN; }
 #pragma unroll
@@ -408,9 +409,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16x3_kernel(GemmBfArgs
         else if (p.out_mode == GEMM_OUT_QKV_HEADMAJOR) bf_epilogue_lds<GEMM_OUT_QKV_HEADMAJOR, TI>(p, acc, m0, n0, wm, wn, lane, scratch, nti);
         else bf_epilogue_lds<GEMM_OUT_PLAIN, TI>(p, acc, m0, n0, wm, wn, lane, scratch, nti);
     } else {
-        if (p.out_mode == GEMM_OUT_SPLIT_BF16) bf_epilogue<GEMM_OUT_SPLIT_BF16, TI>(p, acc, m0, n0, wm, wn, lane);
-        else if (p.out_mode == GEMM_OUT_QKV_HEADMAJOR) bf_epilogue<GEMM_OUT_QKV_HEADMAJOR, TI>(p, acc, m0, n0, wm, wn, lane);
-        else bf_epilogue<GEMM_OUT_PLAIN, TI>(p, acc, m0, n0, wm, wn, lane);
+        if (p.out_mode == GEMM_OUT_SPLIT_BF16) bf_epilogue<GEMM_OUT_SPLIT_BF16, TI>(p, acc, m0, n0, wm, wn, lane, nti);
+        else if (p.out_mode == GEMM_OUT_QKV_HEADMAJOR) bf_epilogue<GEMM_OUT_QKV_HEADMAJOR, TI>(p, acc, m0, n0, wm, wn, lane, nti);
+        else bf_epilogue<GEMM_OUT_PLAIN, TI>(p, acc, m0, n0, wm, wn, lane, nti);
     }
 }
 

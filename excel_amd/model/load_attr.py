@@ -1,6 +1,7 @@
 """attr_aggregate (TSE): fuse class text embeddings with the cached k-means attribute bank.
 Mirror of model/load_attr.py:86-119; the bank file is the reference's shipped data
-(attributes_text/*_embedding_bank.pth, or the .npz copy under tests/golden/)."""
+(attributes_text/*_embedding_bank.pth, or the .npz copy of those two tables shipped inside the package:
+excel_amd/attributes_text/attr_bank_<dataset>.npz).  Nothing here reads from tests/."""
 import os
 
 import numpy as np
@@ -9,12 +10,13 @@ import torch
 from .. import ops
 
 
+BANK_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "attributes_text")
+
+
 def load_bank(dataset_name="pascal_voc", num_atrr_clusters=112, search_dirs=None):
     """-> (bank [512,K] f32 tensor, flag [F,K]).  Looks for the reference's .pth next to the cwd (as the reference
-    does, load_attr.py:88) and for the .npz fixture shipped with this repo."""
-    here = os.path.dirname(os.path.abspath(__file__))
-    root = os.path.dirname(os.path.dirname(here))
-    dirs = list(search_dirs or []) + ["./attributes_text", os.path.join(root, "tests", "golden")]
+    does, load_attr.py:88) and for the .npz copy shipped inside the package (excel_amd/attributes_text/)."""
+    dirs = list(search_dirs or []) + ["./attributes_text", BANK_DIR]
     for d in dirs:
         p = os.path.join(d, f"{dataset_name}_desc_clip_ViT-B-16_gpt4.0_cluster_{num_atrr_clusters}_embedding_bank.pth")
         if os.path.exists(p):

@@ -117,7 +117,7 @@ class ExCEL_model:
 
     __call__ = forward
 
-    def check_numerics(self, img, tol=5e-4, fallback=True):
+    def check_numerics(self, img, tol=5e-4, fallback=True, reduce=None):
         """Guard of the fast matrix-core modes on the caller's OWN weights and images.  "bf16x3" carries 16 mantissa bits per operand:
         measured against a float64 run of the oracle its CAM error is ~12x that of fp32 arithmetic - 1e-5 on well-conditioned networks
         (gate 1e-3), but on an ill-conditioned one (massive-activation channels + near-one-hot attention rows:
@@ -126,20 +126,29 @@ class ExCEL_model:
         [b,3,S,S] in the current mode and in exact fp32 ("f32") and compares the attr maps - the quantity the gate is stated on.
         With `fallback`, a difference above `tol` (half the gate by default) moves this model one step down the ladder
         bf16x3 -> f16x3 -> f32 (re-checked at every step) for everything that follows.
+        `reduce(diff) -> diff` shares a rung's verdict between the ranks of a job (infer_lam: all-reduce MAX, a NaN counts as +inf);
+        it is called exactly once per rung on EVERY rank, also on a rank whose shard is empty (`img=None`: contributes 0), so the
+        collective sequence is identical everywhere.  This is the one implementation of the ladder.
         -> {"max_abs_diff" (of the mode it started in), "tol", "mode_before", "mode_after", "ladder": [(mode, diff), ...]}"""
         h = self.encoder.visual.handle()
         before = h.gemm_mode()
         if before == "f32":
             return {"max_abs_diff": 0.0, "tol": tol, "mode_before": before, "mode_after": before, "ladder": []}
-        h.set_gemm_mode("f32")
-        try:
-            exact = self.forward(img)[2].clone()
-        finally:
-            h.set_gemm_mode(before)
+        exact = None
+        if img is not None:
+            h.set_gemm_mode("f32")
+            try:
+                exact = self.forward(img)[2].clone()
+            finally:
+                h.set_gemm_mode(before)
         ladder, after = [], before
         for mode in (["bf16x3", "f16x3"] if before == "bf16x3" else [before]):
-            h.set_gemm_mode(mode)
-            diff = float((self.forward(img)[2] - exact).abs().max())
+            diff = 0.0
+            if img is not None:
+                h.set_gemm_mode(mode)
+                diff = float((self.forward(img)[2] - exact).abs().max())
+            if reduce is not None:
+                diff = float(reduce(diff if diff == diff else float("inf")))
             ladder.append((mode, diff))
             after = mode
             if diff <= tol or not fallback:              # (NaN compares false: moves on)

@@ -346,47 +346,42 @@ def crf_proc(args, rank=0, world=1, device="cuda"):
 
 
 def _gemm_self_check(model, dataset, idx, args, device, world):
-    """ExCEL_model.check_numerics on the first (up to 4) samples of this rank's shard, resized like the loop resizes them (:74).  With
-    several ranks the verdict is shared (max over ranks of the difference): every rank runs the same mode."""
+    """ExCEL_model.check_numerics (the one implementation of the bf16x3 -> f16x3 -> f32 ladder) on the first (up to 4) samples of this
+    rank's shard, resized like the loop resizes them (:74).  With several ranks every rung's verdict is shared (all-reduce MAX of the
+    difference): every rank runs the same mode, and a rank whose shard is EMPTY (fewer images than ranks) still joins every collective
+    with a difference of 0 instead of leaving the others waiting."""
     from .. import ops
     S = args.resize_size
     take = [int(i) for i in idx[:4]]
-    first = dataset[take[0]][1]
-    if first.dtype == np.uint8:                                                             # decoded images of their own sizes
-        from ..datasets.loader import pack_samples
-        rb = pack_samples([dataset[i] for i in take])
-        inputs = ops.normalize_resize_u8_ragged(rb.images.to(device), ops.RaggedPlan(rb.hw, device), S)
-    else:
-        _, imgs, _, _ = dataset.batch(take)
-        inputs = torch.from_numpy(imgs).to(device)
-        if inputs.shape[-2:] != (S, S):
-            inputs = ops.bilinear_resize(inputs, S, S, align_corners=False)
-    # ExCEL_model.check_numerics' ladder (bf16x3 -> f16x3 -> f32) with every verdict shared by the ranks (max of the difference)
-    h = model.encoder.visual.handle()
-    before, tol = h.gemm_mode(), float(getattr(args, "gemm_check_tol", 5e-4))
-    if before == "f32":
-        return {"max_abs_diff": 0.0, "tol": tol, "mode_before": before, "mode_after": before, "ladder": []}
-    h.set_gemm_mode("f32")
-    exact = model(inputs)[2].clone()
-    ladder, after = [], "f32"
-    for mode in (["bf16x3", "f16x3"] if before == "bf16x3" else [before]):
-        h.set_gemm_mode(mode)
-        diff = float((model(inputs)[2] - exact).abs().max())
+    inputs = None
+    if take:
+        first = dataset[take[0]][1]
+        if first.dtype == np.uint8:                                                         # decoded images of their own sizes
+            from ..datasets.loader import pack_samples
+            rb = pack_samples([dataset[i] for i in take])
+            inputs = ops.normalize_resize_u8_ragged(rb.images.to(device), ops.RaggedPlan(rb.hw, device), S)
+        else:
+            _, imgs, _, _ = dataset.batch(take)
+            inputs = torch.from_numpy(imgs).to(device)
+            if inputs.shape[-2:] != (S, S):
+                inputs = ops.bilinear_resize(inputs, S, S, align_corners=False)
+
+    def share(diff):
         if world > 1 and dist.is_initialized():
-            t = torch.tensor([diff if diff == diff else float("inf")], dtype=torch.float64, device=device)
+            t = torch.tensor([diff], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            diff = float(t.item())
-        ladder.append((mode, diff))
-        if diff <= tol:
-            after = mode
-            break
-    h.set_gemm_mode(after)
+            return float(t.item())
+        return diff
+
+    tol = float(getattr(args, "gemm_check_tol", 5e-4))
+    out = model.check_numerics(inputs, tol=tol, fallback=True, reduce=share)
+    before, after, ladder = out["mode_before"], out["mode_after"], out["ladder"]
     if after != before:
         logging.warning(f"gemm self-check: CAMs of the {before} mode differ from exact fp32 by {ladder[0][1]:.2e} (> {tol:.1e}) on these weights: "
                         f"the run continues in {after} ({', '.join(f'{m} {d:.2e}' for m, d in ladder)})")
-    else:
+    elif ladder:
         logging.info(f"gemm self-check: {before} vs exact fp32 CAM max-abs difference {ladder[0][1]:.2e} (tolerance {tol:.1e})")
-    return {"max_abs_diff": ladder[0][1], "tol": tol, "mode_before": before, "mode_after": after, "ladder": ladder}
+    return out
 
 
 def validate(args=None, dataset=None, pipe=None):
@@ -445,7 +440,7 @@ def validate(args=None, dataset=None, pipe=None):
     gc.freeze()
     par = PAR(num_iter=20, dilations=[1, 2, 4, 8, 12, 24])                                  # :168
     idx = shard_indices(len(dataset), rank, world)                                          # :166
-    if model is not None and getattr(args, "gemm_check", True) and len(idx) > 0:
+    if model is not None and getattr(args, "gemm_check", True):              # every rank joins, also one with an empty shard
         validate.last_gemm_check = _gemm_self_check(model, dataset, idx, args, device, world)
     hist, nimg, secs = build_validation(model, par, dataset, idx, device, args, pipe=pipe)
     validate.last_model = model                                                             # handle for callers / tests

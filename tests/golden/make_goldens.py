@@ -214,9 +214,9 @@ def gold_attr():
         agg, _ = ref_attr_aggregate(torch.from_numpy(tf), ds, F_, K, "unused.json")
         out[f"{ds}_text"] = tf
         out[f"{ds}_agg"] = agg
-        # the shipped bank itself is reference DATA (not source): kept as a fixture so the GPU box,
-        # which has no /root/reference, can build the same text bank.
-        np.savez_compressed(os.path.join(HERE, f"attr_bank_{ds}.npz"), bank=bank.numpy(), flag=flag.numpy())
+        # the shipped bank itself is reference DATA (not source): the product keeps a copy inside the package
+        # (excel_amd/attributes_text/), so the GPU box, which has no /root/reference, builds the same text bank.
+        np.savez_compressed(os.path.join(HERE, "..", "..", "excel_amd", "attributes_text", f"attr_bank_{ds}.npz"), bank=bank.numpy(), flag=flag.numpy())
     save("attr_aggregate.npz", **out)
 
 

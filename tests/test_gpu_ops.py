@@ -786,6 +786,27 @@ def test_gemm_bf16x3_bench_shapes(ops, M, N, K):
     assert np.array_equal(hi, _bf16_round(out)) and np.array_equal(lo, _bf16_round(out - hi))
 
 
+@pytest.mark.parametrize("M,N,K", [(25120, 1001, 64), (12560, 2302, 64), (25120, 770, 96)])
+def test_gemm_bf16x3_scalar_epilogue_big_tiles(ops, M, N, K):
+    """N not a multiple of 4 sends the big tiles (256 / 320 rows, mixed-height row tiles included) through the scalar epilogue
+    (round-4 advisor finding: a short 256-row tile of the mixed-height launch stored wave row 1 thirty-two rows too low and wrote
+    bias-only values into the next row tile).  Plain and bias + QuickGELU + residual, against a float64 product."""
+    rs = np.random.RandomState(N)
+    A = rs.standard_normal((M, K)).astype(np.float32)
+    W = (rs.standard_normal((N, K)) * 0.05).astype(np.float32)
+    bias = rs.standard_normal(N).astype(np.float32)
+    res = rs.standard_normal((M, N)).astype(np.float32)
+    ref = A.astype(np.float64) @ W.T.astype(np.float64)
+    As, Ws = ops.split_bf16(dev(A)), ops.split_bf16(dev(W))
+    scale = np.sqrt(K) * 0.05
+    out = host(ops.gemm_bf16x3(As, Ws))
+    assert out.shape == (M, N) and maxabs(out, ref) < 3e-5 * scale
+    y = ref + bias
+    y = y * (1.0 / (1.0 + np.exp(-1.702 * y))) + res
+    out2 = host(ops.gemm_bf16x3(As, Ws, bias=dev(bias), residual=dev(res), act=1))
+    assert maxabs(out2, y) < 3e-5 * scale + 2e-6
+
+
 @pytest.mark.parametrize("sharp", [1.6, 2.0])
 def test_vit_b16_448_clip_like_outlier_net(ops, sharp):
     """Full-size ViT-B/16 @448 on a CLIP-LIKE STRESS NET (oracle.vit.make_vit_weights(outliers=True): 3-6 massive-activation channels at
