@@ -287,6 +287,7 @@ def main(argv=None, hooks=None):
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step (BASELINE configs[2]: 32)")
     ap.add_argument("--cpu-images", type=int, default=64, help="upper bound of the CPU-baseline sample (stops after ~60 s of CPU work; 0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--no-rccl", action="store_true", help="bare N=1 launch: do not bring up the one-rank RCCL group (the matrix is then not gathered)")
     ap.add_argument("--ragged-images", type=int, default=256, help="images of the harness_ragged side-line (0 = skip)")
     ap.add_argument("--power-seconds", type=float, default=3.0, help="untimed loop of the step with rocm-smi power sampling (0 = skip)")
     ap.add_argument("--overlap", type=int, default=int(os.environ.get("EXCEL_BENCH_OVERLAP", "0")),
@@ -309,6 +310,14 @@ def main(argv=None, hooks=None):
             print("bench.py: self-launching", " ".join(cmd), file=sys.stderr, flush=True)
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             os.execv(cmd[0], cmd)
+    json_out = sys.stdout
+    if on_gpu:
+        # stdout carries ONE JSON line (the driver's contract).  librccl prints a version banner to file descriptor 1 when its first
+        # communicator comes up: everything that is not the line goes to stderr from here on.
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        json_out = os.fdopen(keep, "w")
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -319,21 +328,47 @@ def main(argv=None, hooks=None):
         device = torch.device("cuda", local_rank)
     else:
         device = torch.device(hooks["device"])
-    if world > 1:
+    rccl_note = None
+    if world > 1 or ("MASTER_PORT" in os.environ and "RANK" in os.environ):
+        # under torch.distributed.run (any N, also --nproc-per-node 1): the launcher's rendezvous
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=hooks.get("backend", "nccl"))      # "nccl" is RCCL on ROCm
         assert dist.get_world_size() == args.gpus
+    elif on_gpu and not args.no_rccl:
+        # launched bare at N = 1: a one-rank RCCL group over a private TCP store, so that the path's one collective (the all-gather
+        # of the confusion matrix) goes through RCCL on this hardware exactly as it does for N > 1.  A failure to bring RCCL up is
+        # reported in the JSON line (`rccl`), it does not stop the single-GPU measurement.
+        try:
+            import socket
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+            sk.close()
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+        except Exception as e:       # noqa: BLE001
+            rccl_note = f"unavailable: {type(e).__name__}: {e}"[:200]
 
     from excel_amd.tools.infer_lam import gather_hists
     from excel_amd.utils import evaluate
     B, S, NC = args.batch, 448, 21
+    if dist.is_initialized() and rccl_note is None:
+        # RCCL builds its communicator (and, per collective kind, its channels) on first use: pay that here, not in the timed region
+        try:
+            gather_hists(torch.zeros((NC, NC), dtype=torch.int64, device=device))
+            dist.barrier()
+        except Exception as e:       # noqa: BLE001
+            if world > 1:
+                raise
+            rccl_note = f"unavailable: {type(e).__name__}: {e}"[:200]
+            dist.destroy_process_group()
     n_batches = 2
     pipe, batches, ks, model = hooks.get("make_workload", make_workload)(args, rank, world, device)
     if on_gpu:
         from excel_amd import _lib, ops
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         if on_gpu:
             torch.cuda.synchronize()
@@ -372,7 +407,13 @@ def main(argv=None, hooks=None):
         step_fn(*batches[i % n_batches])
         host_marks.append(time.perf_counter() - th)                      # host time to ENQUEUE step i: a host-side self-check
     pipe.drain()
+    if on_gpu:
+        torch.cuda.synchronize()                                    # (so that gather_ms below is the collective, not the queued steps)
+    tg = time.perf_counter()
     per_rank, total = gather_hists(pipe.hist)                       # the one collective (RCCL all-gather)
+    if on_gpu:
+        torch.cuda.synchronize()
+    gather_ms = (time.perf_counter() - tg) * 1e3
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
@@ -422,7 +463,9 @@ def main(argv=None, hooks=None):
             "host_enqueue_ms_per_step": round(sum(host_steps) / max(len(host_steps), 1) * 1e3, 3),
             "host_enqueue_ms_max_step": round(max(host_steps) * 1e3, 3) if host_steps else None,
             "host_enqueue_ms_steps": [round(x * 1e3, 2) for x in host_steps],
-            "rccl_ranks": int(dist.get_world_size()) if world > 1 else 1,
+            # ranks the all-gather really spanned (from the process group; 0 = no RCCL group, the matrix was not gathered) and its time
+            "rccl_ranks": int(dist.get_world_size()) if dist.is_initialized() else 0,
+            "rccl": rccl_note or ("all_gather of [21,21] int64 over %d rank(s), %.3f ms" % (dist.get_world_size(), gather_ms) if dist.is_initialized() else "no process group"),
             "per_rank_hist_mass": [int(x) for x in per_rank.reshape(per_rank.shape[0], -1).sum(1).tolist()],
         }
         if prof:
@@ -546,13 +589,13 @@ def main(argv=None, hooks=None):
             gc.collect()
             gc.freeze()                                             # as infer_lam.validate does: later collections skip the start-up heap
             out["harness_ragged"] = harness_ragged(model, device, n_images=args.ragged_images, batch=B)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
         v = out.get("verify")
         if v and v["label_agreement_mean"] < 0.999:
             # what was timed must be what was checked: a line whose labels disagree with the CPU port is not a measurement
             print(f"bench.py: label agreement {v['label_agreement_mean']} < 0.999 against the CPU port", file=sys.stderr)
             sys.exit(3)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

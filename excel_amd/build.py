@@ -12,6 +12,10 @@ SOURCES = ["gemm.hip", "gemm_bf16x3.hip", "norm.hip", "attn.hip", "attn_strip.hi
 # with -DEXCEL_SPLIT_F16, IEEE half (namespace excel_f16, objects *_f16.o) - the "f16x3" matrix-core mode (common.h, excel_internal.h)
 SPLIT_SOURCES = ["gemm.hip", "gemm_bf16x3.hip", "norm.hip", "attn.hip", "attn_strip.hip", "cam.hip"]
 HEADERS = ["common.h", "excel_internal.h", "excel_split_api.inc", "decoder_internal.h", os.path.join("..", "..", "include", "excel_hip.h")]
+# kernels that must never touch scratch memory: a spill or a dynamically indexed accumulator array inside these turns a matrix-core loop
+# into a memory loop (round 5: one `break` in an unrolled epilogue loop sent the 320x256 GEMM's accumulators to scratch, 3.5x slower,
+# all tests green).  build() reads hipcc's kernel-resource-usage remarks and refuses to link a library that violates this.
+NO_SCRATCH = ("gemm_bf16x3_kernel", "gemm_w4_kernel", "attn_strip_kernel", "par_iterate_guide_kernel", "par_stats_tile_kernel")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
          # fully unroll the big register-tile epilogues (a partially unrolled loop indexes the accumulator array
          # dynamically and sends it to scratch)
@@ -50,6 +54,30 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _parse_resources(stderr):
+    """hipcc -Rpass-analysis=kernel-resource-usage remarks -> {mangled kernel name: {"vgprs", "agprs", "sgprs", "scratch", "occupancy", "lds"}}"""
+    import re
+    out, cur = {}, None
+    keys = {"VGPRs": "vgprs", "AGPRs": "agprs", "SGPRs": "sgprs", "ScratchSize [bytes/lane]": "scratch", "Occupancy [waves/SIMD]": "occupancy",
+            "LDS Size [bytes/block]": "lds", "VGPRs Spill": "vgpr_spill", "SGPRs Spill": "sgpr_spill"}
+    for line in stderr.splitlines():
+        m = re.search(r"remark:\s+(.*?)\s*\[-Rpass-analysis", line)
+        if not m:
+            continue
+        body = m.group(1)
+        if body.startswith("Function Name:"):
+            cur = body.split(":", 1)[1].strip()
+            out[cur] = {}
+        elif cur and ":" in body:
+            k, v = body.rsplit(":", 1)
+            if k.strip() in keys:
+                try:
+                    out[cur][keys[k.strip()]] = int(v)
+                except ValueError:
+                    pass
+    return out
+
+
 def _object_sig(src, cmd_flags):
     """Content signature of ONE object: its source, every header / .inc under csrc (any .hip may include any of them: a superset is
     cheap and never stale), the public header and the exact command-line flags.  Objects are rebuilt when this changes, whatever the
@@ -84,6 +112,11 @@ def build(force=False, verbose=True):
         sigs = json.load(open(sigfile))
     except Exception:
         sigs = {}
+    resfile = os.path.join(CSRC, ".build_resources.json")      # per object: hipcc's register / scratch / occupancy figures of every kernel
+    try:
+        resources = json.load(open(resfile))
+    except Exception:
+        resources = {}
     objs, jobs = [], []           # jobs: (command, object name, signature)
     for s in SOURCES:
         src = os.path.join(CSRC, s)
@@ -96,7 +129,7 @@ def build(force=False, verbose=True):
             sig_o = _object_sig(src, [hipcc] + flags + vflags + extra)
             name = os.path.basename(obj)
             if force or not os.path.exists(obj) or sigs.get(name) != sig_o:
-                jobs.append(([hipcc] + flags + vflags + extra + ["-c", src, "-o", obj], name, sig_o))
+                jobs.append(([hipcc] + flags + vflags + extra + ["-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", obj], name, sig_o))
     if jobs:
         with cf.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             for (cmd, name, sig_o), res in zip(jobs, ex.map(lambda j: subprocess.run(j[0], capture_output=True, text=True), jobs)):
@@ -104,10 +137,17 @@ def build(force=False, verbose=True):
                     sigs.pop(name, None)
                     json.dump(sigs, open(sigfile, "w"))
                     raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), res.stderr))
+                resources[name] = _parse_resources(res.stderr)
+                bad = {k: v for k, v in resources[name].items() if any(n in k for n in NO_SCRATCH) and (v.get("scratch", 0) or v.get("vgpr_spill", 0))}
+                if bad:
+                    sigs.pop(name, None)
+                    json.dump(sigs, open(sigfile, "w"))
+                    raise RuntimeError("%s: hot kernels use scratch memory (spill / dynamically indexed register array): %s" % (name, bad))
                 sigs[name] = sig_o
                 if verbose:
                     print("[excel_amd.build] compiled", name)
         json.dump(sigs, open(sigfile, "w"), indent=0, sort_keys=True)
+        json.dump(resources, open(resfile, "w"), indent=0, sort_keys=True)
     if force or jobs or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         res = subprocess.run(cmd, capture_output=True, text=True)

@@ -55,7 +55,7 @@ __device__ __forceinline__ void bf_epilogue(const GemmBfArgs& p, const f32x4 (&a
         }
 #pragma unroll
         for (int i = 0; i < 2 * TI; ++i) {
-            if (i >= 2 * nti) break;                              // (mixed-height tiles: a short tile's waves own nti = TI - 1 row tiles, and their rows start at wm * nti * 32)
+            if (i >= 2 * nti) continue;                           // (mixed-height tiles: a short tile's waves own nti = TI - 1 row tiles, and their rows start at wm * nti * 32)
             const int rbase = m0 + wm * (nti * 32) + i * 16 + 4 * (lane >> 4);
             int qb = 0, qn = 0;
             if (OUT_MODE == GEMM_OUT_QKV_HEADMAJOR) { qb = rbase / p.tokN; qn = rbase - qb * p.tokN; }

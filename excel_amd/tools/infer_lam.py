@@ -126,8 +126,10 @@ def pin_rank_to_cores(local_rank, local_world):
 
 def gather_hists(hist, group=None):
     """all_gather of the per-rank [nc,nc] int64 confusion matrices -> ([R,nc,nc], summed [nc,nc]).
-    One small message per rank (3.5 KB VOC / 52 KB COCO): latency-bound, issued once per evaluation."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    One small message per rank (3.5 KB VOC / 52 KB COCO): latency-bound, issued once per evaluation.
+    With a process group the collective always runs - also over a single rank (RCCL on one GPU: the same call path as N > 1, which is
+    what the 1-GPU hardware tests and `bench.py --gpus 1` exercise); without one the matrix is returned as it is."""
+    if not (dist.is_available() and dist.is_initialized()):
         return hist[None], hist
     world = dist.get_world_size(group)
     parts = [torch.empty_like(hist) for _ in range(world)]
