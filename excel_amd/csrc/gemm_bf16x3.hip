@@ -522,6 +522,13 @@ int excel_launch_gemm_bf16x3(const GemmBfArgs& p_in, hipStream_t stream) {
         }
     }
     const int nb = p.batch > 1 ? p.batch : 1;
+#ifdef EXCEL_DEV
+    static const bool no_w4 = getenv("EXCEL_BF_W4") && atoi(getenv("EXCEL_BF_W4")) == 0;       // dev knob: the 8-wave kernel for A/B runs
+#else
+    const bool no_w4 = false;
+#endif
+    // the 320 x 256 tile runs on the four-wave kernel with the hand-placed k-loop (gemm_w4.hip) whenever its preconditions hold
+    if (kind == 3 && !no_w4 && excel_gemm_w4_supported(p)) return excel_launch_gemm_w4(p, stream);
     if (kind == 3 && nb == 1 && !force_uniform) {
         // mixed-height row tiles (kernel header): R = rounds of the uniform 320-row tiling; nt = the row tiles that fit into R rounds;
         // `tall` of them must be 320 rows high to cover M, the rest can be 256.  Worth it when the tall tiles leave room in the last round

@@ -798,13 +798,13 @@ def test_gemm_bf16x3_scalar_epilogue_big_tiles(ops, M, N, K):
     res = rs.standard_normal((M, N)).astype(np.float32)
     ref = A.astype(np.float64) @ W.T.astype(np.float64)
     As, Ws = ops.split_bf16(dev(A)), ops.split_bf16(dev(W))
-    scale = np.sqrt(K) * 0.05
+    tol = 4e-5                                           # outputs ~N(0, 0.4^2), 2^-17 per product; max over 25 M entries measured 1.5e-5
     out = host(ops.gemm_bf16x3(As, Ws))
-    assert out.shape == (M, N) and maxabs(out, ref) < 3e-5 * scale
+    assert out.shape == (M, N) and maxabs(out, ref) < tol
     y = ref + bias
     y = y * (1.0 / (1.0 + np.exp(-1.702 * y))) + res
     out2 = host(ops.gemm_bf16x3(As, Ws, bias=dev(bias), residual=dev(res), act=1))
-    assert maxabs(out2, y) < 3e-5 * scale + 2e-6
+    assert maxabs(out2, y) < tol
 
 
 @pytest.mark.parametrize("sharp", [1.6, 2.0])
