@@ -44,7 +44,6 @@ constexpr int ROWB = 128;                           // bytes per staged row
 constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;   // 40 960 + 32 768 = 73 728
 constexpr int NT_M = WTM / 16, NT_N = WTN / 16;      // 10 x 8 accumulator tiles of 16 x 16 per wave
 constexpr int A_PIECES = BM / 8 / 4, B_PIECES = BN / 8 / 4, PIECES = A_PIECES + B_PIECES;   // 1-KB DMA pieces per wave and stage: 10 + 8
-constexpr int EPI_PITCH = 132;                       // floats per row of the epilogue's transpose scratch (32 rows x 128 columns per wave)
 
 template <int I> using IC = std::integral_constant<int, I>;
 template <int B, int E, class F>
@@ -55,12 +54,18 @@ __device__ __forceinline__ void sfor(F&& f) {
     }
 }
 
-// accumulate-in-place MFMA with the accumulator in the AGPR file (row tiles 0-7) or the VGPR file (row tiles 8, 9)
+// accumulate-in-place MFMA with the accumulator in the AGPR file (row tiles 0-7) or the VGPR file (row tiles 8, 9).  `a` = activation
+// fragment, `b` = weight fragment; the instruction gets them SWAPPED (srcA = weights): the tile comes out transposed, a lane then holds
+// consecutive COLUMNS of one row (epilogue)
+template <bool ON = true>
 __device__ __forceinline__ void mfma_agpr(f32x4& c, const splitx8& a, const splitx8& b) {
-    asm volatile(W4_MFMA_OP " %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    if constexpr (!ON) { asm volatile("" : "+a"(c) : "v"(a), "v"(b)); return; }
+    asm volatile(W4_MFMA_OP " %0, %2, %1, %0" : "+a"(c) : "v"(a), "v"(b));
 }
+template <bool ON = true>
 __device__ __forceinline__ void mfma_vgpr(f32x4& c, const splitx8& a, const splitx8& b) {
-    asm volatile(W4_MFMA_OP " %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    if constexpr (!ON) { asm volatile("" : "+v"(c) : "v"(a), "v"(b)); return; }
+    asm volatile(W4_MFMA_OP " %0, %2, %1, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 template <int OFF>
 __device__ __forceinline__ void lds_rd(splitx8& dst, unsigned addr) {
@@ -78,6 +83,9 @@ __device__ __forceinline__ void wait_lgkm() {
 
 // One launch = cdiv(M,320) x cdiv(N,256) workgroups of 256 threads.  Preconditions (checked by the launcher): K % 64 == 0 (an even number of 32-k steps),
 // N, ldc, ldr, hd multiples of 4 (vector epilogue), operand extents below 2^31 bytes (32-bit buffer offsets), batch == 1.
+// DBG (development builds only; the shipped library instantiates DBG = 0): timing-only ablation arms, results are wrong -
+//   1 no LDS-DMA after the prologue, 2 no fragment reads after the prologue, 4 no barrier in the k-loop, 8 no epilogue, 16 no MFMAs
+template <int DBG>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmBfArgs p) {
     using namespace w4;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE_BYTES];
@@ -101,7 +109,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmBfArgs p) {
         constexpr bool isB = q >= A_PIECES;
         const int seg = wave + 4 * (isB ? q - A_PIECES : q);
         const int row_l = seg * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((row_l >> 1) & 7);
+        // A rows: slot = chunk ^ ((row >> 1) & 7); B rows: slot = chunk ^ swz_b(row) - the weight fragments are read with a permuted
+        // row <-> lane map (epilogue), and this is the swizzle that keeps THOSE reads conflict-free
+        const int c = (lane & 7) ^ (isB ? (((row_l >> 1) & 1) + 2 * ((row_l >> 3) & 3)) : ((row_l >> 1) & 7));
         const int grow = isB ? min(n0 + row_l, p.N - 1) : min(m0 + row_l, p.M - 1);     // rows past the edge re-read the last row (never stored)
         voff[q] = grow * (isB ? p.ldb : p.lda) * 2 + c * 16;
     });
@@ -125,8 +135,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmBfArgs p) {
     const int r16 = lane & 15, kg = lane >> 4, sw = (r16 >> 1) & 7;
     const unsigned a_hi = smem_base + (wm * WTM + r16) * ROWB + ((kg ^ sw) * 16);
     const unsigned a_lo = smem_base + (wm * WTM + r16) * ROWB + (((4 + kg) ^ sw) * 16);
-    const unsigned b_hi = smem_base + A_BYTES + (wn * WTN + r16) * ROWB + ((kg ^ sw) * 16);
-    const unsigned b_lo = smem_base + A_BYTES + (wn * WTN + r16) * ROWB + (((4 + kg) ^ sw) * 16);
+    // weight fragment of column tile j = 2 jp + t: lane r reads staged row 32 jp + 4 t + brow, brow = 8 (r / 4) + (r % 4); swz_b(brow) does
+    // not depend on jp, t
+    const int brow = 8 * (r16 >> 2) + (r16 & 3), swb = ((brow >> 1) & 1) + 2 * ((brow >> 3) & 3);
+    const unsigned b_hi = smem_base + A_BYTES + (wn * WTN + brow) * ROWB + ((kg ^ swb) * 16);
+    const unsigned b_lo = smem_base + A_BYTES + (wn * WTN + brow) * ROWB + (((4 + kg) ^ swb) * 16);
     const unsigned a_hi1 = a_hi + STAGE_BYTES, a_lo1 = a_lo + STAGE_BYTES, b_hi1 = b_hi + STAGE_BYTES, b_lo1 = b_lo + STAGE_BYTES;
 
     f32x4 accA[8][NT_N];      // AGPR file
@@ -142,13 +155,15 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmBfArgs p) {
     // reads of the head of a step from the stage at `S` (compile-time 0 / 1): A tiles 0 and 1, then (tail only) the B column pairs
     auto read_a = [&](auto Sc, auto Ic, auto SLOTc) {
         constexpr int S = decltype(Sc)::value, i = decltype(Ic)::value, slot = decltype(SLOTc)::value;
+        if constexpr (DBG & 2) return;
         lds_rd<i * 2048>(Ah[slot], S ? a_hi1 : a_hi);
         lds_rd<i * 2048>(Al[slot], S ? a_lo1 : a_lo);
     };
     auto read_b = [&](auto Sc, auto Jc) {
         constexpr int S = decltype(Sc)::value, j = decltype(Jc)::value;
-        lds_rd<j * 2048>(Bh[j], S ? b_hi1 : b_hi);
-        lds_rd<j * 2048>(Bl[j], S ? b_lo1 : b_lo);
+        if constexpr (DBG & 2) return;
+        lds_rd<(32 * (j >> 1) + 4 * (j & 1)) * ROWB>(Bh[j], S ? b_hi1 : b_hi);
+        lds_rd<(32 * (j >> 1) + 4 * (j & 1)) * ROWB>(Bl[j], S ? b_lo1 : b_lo);
     };
 
     // ---- one 32-k step.  P = step parity: data in stage P, A-ring phase 2 P.  The stage of the NEXT step (k offset `soff_next` bytes) is
@@ -166,21 +181,21 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmBfArgs p) {
                 constexpr int n = decltype(Nc)::value, pass = n / NT_N, j = n % NT_N;
                 if constexpr (i == 0 && pass == 0) wait_lgkm<15 - 2 * j>();        // tail read order: A0, A1, then (Bh, Bl) per column tile
                 if constexpr (i == 0 && pass == 1 && j == 0) wait_lgkm<0>();
-                if constexpr (pass == 0) mfma_agpr(accA[i][j], Al[slot], Bh[j]);
-                else if constexpr (pass == 1) mfma_agpr(accA[i][j], Ah[slot], Bl[j]);
-                else mfma_agpr(accA[i][j], Ah[slot], Bh[j]);
+                if constexpr (pass == 0) mfma_agpr<!(DBG & 16)>(accA[i][j], Al[slot], Bh[j]);
+                else if constexpr (pass == 1) mfma_agpr<!(DBG & 16)>(accA[i][j], Ah[slot], Bl[j]);
+                else mfma_agpr<!(DBG & 16)>(accA[i][j], Ah[slot], Bh[j]);
                 // A fragments two row tiles ahead (ring slot of tile i - 2, retired), behind the first pass
                 if constexpr (n == NT_N) read_a(IC<P>{}, IC<i + 2>{}, IC<(2 * P + i + 2) & 3>{});
                 // the next stage's DMA pieces: 4,4,4,3,3 over row tiles 0..4, one piece between MFMAs
                 if constexpr (i <= 4 && (n == 2 || n == 10 || n == 14 || (n == 20 && i <= 2))) {
                     constexpr int q = (i <= 2 ? 4 * i : 12 + 3 * (i - 3)) + (n == 2 ? 0 : n == 10 ? 1 : n == 14 ? 2 : 3);
-                    dma(IC<q>{}, IC<q + 1>{}, (1 - P) * STAGE_BYTES, soff_next);
+                    if constexpr (!(DBG & 1)) dma(IC<q>{}, IC<q + 1>{}, (1 - P) * STAGE_BYTES, soff_next);
                 }
             });
         });
         // every read of stage P has been issued; this wave's pieces of stage 1 - P have landed -> one barrier publishes and frees
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!(DBG & 4)) __builtin_amdgcn_s_barrier();
         // tail: row tiles 8, 9 (VGPR accumulators) column-pair-major; the next step's A tiles 0, 1 first, then each pair's B fragments
         // as soon as its 12 MFMAs have been issued
         read_a(IC<1 - P>{}, IC<0>{}, IC<(2 * (1 - P) + 0) & 3>{});
@@ -188,12 +203,12 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmBfArgs p) {
         constexpr int s8 = (2 * P + 8) & 3, s9 = (2 * P + 9) & 3;
         sfor<0, NT_N / 2>([&](auto JPc) {
             constexpr int j0 = 2 * decltype(JPc)::value, j1 = j0 + 1;
-            mfma_vgpr(accV[0][j0], Al[s8], Bh[j0]); mfma_vgpr(accV[0][j1], Al[s8], Bh[j1]);
-            mfma_vgpr(accV[1][j0], Al[s9], Bh[j0]); mfma_vgpr(accV[1][j1], Al[s9], Bh[j1]);
-            mfma_vgpr(accV[0][j0], Ah[s8], Bl[j0]); mfma_vgpr(accV[0][j1], Ah[s8], Bl[j1]);
-            mfma_vgpr(accV[1][j0], Ah[s9], Bl[j0]); mfma_vgpr(accV[1][j1], Ah[s9], Bl[j1]);
-            mfma_vgpr(accV[0][j0], Ah[s8], Bh[j0]); mfma_vgpr(accV[0][j1], Ah[s8], Bh[j1]);
-            mfma_vgpr(accV[1][j0], Ah[s9], Bh[j0]); mfma_vgpr(accV[1][j1], Ah[s9], Bh[j1]);
+            mfma_vgpr<!(DBG & 16)>(accV[0][j0], Al[s8], Bh[j0]); mfma_vgpr<!(DBG & 16)>(accV[0][j1], Al[s8], Bh[j1]);
+            mfma_vgpr<!(DBG & 16)>(accV[1][j0], Al[s9], Bh[j0]); mfma_vgpr<!(DBG & 16)>(accV[1][j1], Al[s9], Bh[j1]);
+            mfma_vgpr<!(DBG & 16)>(accV[0][j0], Ah[s8], Bl[j0]); mfma_vgpr<!(DBG & 16)>(accV[0][j1], Ah[s8], Bl[j1]);
+            mfma_vgpr<!(DBG & 16)>(accV[1][j0], Ah[s9], Bl[j0]); mfma_vgpr<!(DBG & 16)>(accV[1][j1], Ah[s9], Bl[j1]);
+            mfma_vgpr<!(DBG & 16)>(accV[0][j0], Ah[s8], Bh[j0]); mfma_vgpr<!(DBG & 16)>(accV[0][j1], Ah[s8], Bh[j1]);
+            mfma_vgpr<!(DBG & 16)>(accV[1][j0], Ah[s9], Bh[j0]); mfma_vgpr<!(DBG & 16)>(accV[1][j1], Ah[s9], Bh[j1]);
             read_b(IC<1 - P>{}, IC<j0>{});
             read_b(IC<1 - P>{}, IC<j1>{});
         });
@@ -214,113 +229,179 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmBfArgs p) {
     }
     // the tail of the last step read (stale) fragments that nobody uses; retire them and let the matrix pipe drain before the
     // compiler's own accumulator reads (it cannot see that the asm statements above are MFMAs)
+    // (the vmcnt(0) also retires the last step's spare fetch: no LDS-DMA may land after this workgroup has ended.  No barrier: the
+    // epilogue does not touch LDS)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_nop 15\n s_nop 15" ::: "memory");
-    __syncthreads();
 
-    // ---- epilogue: per 32-row group g (row tiles 2 g, 2 g + 1) the wave transposes 32 x 128 outputs through LDS and stores row-contiguous
-    // 16-byte vectors: bias / residual as float4, fp32 rows as 512-byte segments, split rows as 8-byte hi / lo groups (gemm_bf16x3.hip)
-    float* scratch = reinterpret_cast<float*>(smem) + wave * (32 * EPI_PITCH);
-    const int c4 = (lane & 31) * 4;
-    const int col = n0 + wn * WTN + c4;
-    const bool col_ok = col < p.N;
-    const int colc = col_ok ? col : 0;
-    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias && col_ok) bias4 = *reinterpret_cast<const f32x4*>(p.bias + col);
-    int qt = 0, qh = 0, qd = 0;
-    if (p.out_mode == GEMM_OUT_QKV_HEADMAJOR) {
-        const int D = p.heads * p.hd;
-        qt = col / D;
-        const int rem = col - qt * D;
-        qh = rem / p.hd;
-        qd = rem - qh * p.hd;
+    if constexpr (DBG & 8) {        // the accumulators stay live through a store that never happens
+        float sum = 0.f;
+        sfor<0, 8>([&](auto I) { sfor<0, NT_N>([&](auto J) { const f32x4 v = accA[decltype(I)::value][decltype(J)::value]; sum += v[0] + v[1] + v[2] + v[3]; }); });
+        sfor<0, 2>([&](auto I) { sfor<0, NT_N>([&](auto J) { const f32x4 v = accV[decltype(I)::value][decltype(J)::value]; sum += v[0] + v[1] + v[2] + v[3]; }); });
+        if (sum == 1.2345e-30f) p.C[0] = sum;
+        return;
     }
-    sfor<0, NT_M / 2>([&](auto Gc) {
-        constexpr int g = decltype(Gc)::value;
-        sfor<0, 2>([&](auto Tc) {
-            constexpr int t = decltype(Tc)::value, ti = 2 * g + t;
+    // ---- epilogue, straight from the registers (no LDS transpose).  The MFMAs were issued with the operand roles swapped
+    // (srcA = weight fragment, srcB = activation fragment), so an accumulator tile holds C TRANSPOSED: lane (r = lane % 16, g = lane / 16),
+    // register e = C[row 16 i + r][column c(j, g, e)].  The weight fragment of column tile j = 2 jp + t reads the staged weight rows
+    // 32 jp + 8 (r / 4) + 4 t + (r % 4), which makes c = 32 jp + 8 g + 4 t + e: a lane owns EIGHT consecutive columns per tile pair -
+    // fp32 rows go out as 2 x 16 B per lane (128 contiguous bytes per row and instruction pair), split rows as one 16-byte hi and one
+    // 16-byte lo store (a whole 64-byte hi / lo segment per row), bias and residual come in the same shape.  (The transposing epilogue
+    // of the 8-wave kernel, on one wave per SIMD with nothing to hide its LDS round trips, was 25 % of this kernel: 43 k of 174 k cycles
+    // per tile, profiles/r05_w4_arms.txt.)
+    int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // re-derived behind the loop: values computed from
+    asm volatile("" : "+v"(lane_e));                                                    // `lane` up front would be carried through it (spills)
+    const int g4 = lane_e >> 4, r16e = lane_e & 15;
+    const int colw = n0 + wn * WTN + 8 * g4;                    // + 32 jp: first of this lane's 8 columns in pair jp
+    f32x4 bias4[NT_N];
+    sfor<0, NT_N>([&](auto Jc) {
+        constexpr int j = decltype(Jc)::value;
+        const int c = colw + 32 * (j >> 1) + 4 * (j & 1);
+        bias4[j] = (p.bias && c < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    });
+    // one specialised copy per output mode (a run-time mode inside the row loop keeps the store addresses of all three modes live at once
+    // and spills)
+    auto epilogue = [&](auto MODEc) {
+        constexpr int MODE = decltype(MODEc)::value;
+        // head-major q|k|v scatter: the 8 columns of a pair stay inside one head (hd % 8 == 0): per pair the offset of (type, head, d)
+        int qoff[NT_N / 2];                                          // (row indices of the [B,3,H,tokN] planes: < 2^31 rows)
+        int qdd[NT_N / 2];
+        if constexpr (MODE == GEMM_OUT_QKV_HEADMAJOR) {
+            const int D = p.heads * p.hd;
+            sfor<0, NT_N / 2>([&](auto JPc) {
+                constexpr int jp = decltype(JPc)::value;
+                const int c = min(colw + 32 * jp, p.N - 8);
+                const int qt = c / D, rem = c - qt * D, qh = rem / p.hd;
+                qdd[jp] = rem - qh * p.hd;
+                qoff[jp] = (qt * p.heads + qh) * p.tokN;      // + b * 3 * heads * tokN + n  -> row index of the [.., tokN, hd] planes
+            });
+        }
+        sfor<0, NT_M>([&](auto Ic) {
+            constexpr int i = (decltype(Ic)::value + 8) % NT_M;          // row tiles 8, 9 first: their accumulators occupy 64 VGPRs
+            const int row = m0 + wm * WTM + 16 * i + r16e;
+            const bool row_ok = row < p.M;
+            const int rowc = row_ok ? row : p.M - 1;
+            f32x4 v[NT_N];
             sfor<0, NT_N>([&](auto Jc) {
                 constexpr int j = decltype(Jc)::value;
-                f32x4 v;
-                if constexpr (ti < 8) v = accA[ti][j]; else v = accV[ti - 8][j];
-                // accumulator tile: register e = row 4 (lane / 16) + e, column lane % 16
-#pragma unroll
-                for (int e = 0; e < 4; ++e) scratch[(t * 16 + 4 * kg + e) * EPI_PITCH + j * 16 + r16] = v[e];
+                if constexpr (i < 8) v[j] = accA[i][j]; else v[j] = accV[i - 8][j];
+                asm volatile("" : "+v"(v[j]));        // a clean AGPR -> VGPR copy point (left alone, the allocator splits the tiles into
+                                                      // 64-bit halves for packed adds and permutes 200 AGPRs at the loop exit)
             });
-        });
-        __builtin_amdgcn_s_waitcnt(0xc07f);               // this wave's LDS writes landed (same-wave read back)
-        const int row0 = m0 + wm * WTM + g * 32 + (lane >> 5);
-        int qb0 = 0, qn0 = 0;
-        if (p.out_mode == GEMM_OUT_QKV_HEADMAJOR) { qb0 = row0 / p.tokN; qn0 = row0 - qb0 * p.tokN; }
-        constexpr int EB = 4;                              // rows per batch: LDS reads, then residual loads, then math, then stores
-#pragma unroll
-        for (int h0 = 0; h0 < 16; h0 += EB) {
-            f32x4 v[EB];
-#pragma unroll
-            for (int it = 0; it < EB; ++it) v[it] = *reinterpret_cast<const f32x4*>(&scratch[((h0 + it) * 2 + (lane >> 5)) * EPI_PITCH + c4]);
             if (p.res) {
-                f32x4 rs[EB];
-#pragma unroll
-                for (int it = 0; it < EB; ++it) rs[it] = *reinterpret_cast<const f32x4*>(p.res + (long long)min(row0 + (h0 + it) * 2, p.M - 1) * p.ldr + colc);
-#pragma unroll
-                for (int it = 0; it < EB; ++it) v[it] += bias4;
-                if (p.act == GEMM_ACT_QUICKGELU) {
-#pragma unroll
-                    for (int it = 0; it < EB; ++it)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) v[it][q] = v[it][q] * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v[it][q]));
-                }
-#pragma unroll
-                for (int it = 0; it < EB; ++it) v[it] += rs[it];
+                f32x4 rs[NT_N];
+                sfor<0, NT_N>([&](auto Jc) {
+                    constexpr int j = decltype(Jc)::value;
+                    const int c = min(colw + 32 * (j >> 1) + 4 * (j & 1), p.N - 4);
+                    rs[j] = *reinterpret_cast<const f32x4*>(p.res + (long long)rowc * p.ldr + c);
+                });
+                sfor<0, NT_N>([&](auto Jc) { constexpr int j = decltype(Jc)::value; v[j] += bias4[j]; });
+                if (p.act == GEMM_ACT_QUICKGELU)
+                    sfor<0, NT_N>([&](auto Jc) {
+                        constexpr int j = decltype(Jc)::value;
+    #pragma unroll
+                        for (int q = 0; q < 4; ++q) v[j][q] = v[j][q] * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v[j][q]));
+                    });
+                sfor<0, NT_N>([&](auto Jc) { constexpr int j = decltype(Jc)::value; v[j] += rs[j]; });
             } else {
-#pragma unroll
-                for (int it = 0; it < EB; ++it) v[it] += bias4;
-                if (p.act == GEMM_ACT_QUICKGELU) {
-#pragma unroll
-                    for (int it = 0; it < EB; ++it)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) v[it][q] = v[it][q] * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v[it][q]));
-                }
+                sfor<0, NT_N>([&](auto Jc) { constexpr int j = decltype(Jc)::value; v[j] += bias4[j]; });
+                if (p.act == GEMM_ACT_QUICKGELU)
+                    sfor<0, NT_N>([&](auto Jc) {
+                        constexpr int j = decltype(Jc)::value;
+    #pragma unroll
+                        for (int q = 0; q < 4; ++q) v[j][q] = v[j][q] * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v[j][q]));
+                    });
             }
-#pragma unroll
-            for (int it = 0; it < EB; ++it) {
-                const int row = row0 + (h0 + it) * 2;
-                if (row >= p.M || !col_ok) continue;
-                if (p.out_mode == GEMM_OUT_PLAIN) {
-                    *reinterpret_cast<f32x4*>(p.C + (long long)row * p.ldc + col) = v[it];
-                } else {
-                    split_t hi[4], lo[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { hi[q] = split_hi(v[it][q]); lo[q] = split_hi(v[it][q] - (float)hi[q]); }
-                    if (p.out_mode == GEMM_OUT_SPLIT_BF16) {
-                        split_t* o = reinterpret_cast<split_t*>(p.Cs) + (long long)row * 2 * p.N + split_off(col, 0);
-                        *reinterpret_cast<uint2*>(o) = *reinterpret_cast<const uint2*>(hi);
-                        *reinterpret_cast<uint2*>(o + 32) = *reinterpret_cast<const uint2*>(lo);
-                    } else {   // q|k|v head-major: fp32 (exact-mode consumers) or [hi hd | lo hd] planes for the bf16x3 attention
-                        int b = qb0, n = qn0 + (h0 + it) * 2;
-                        while (n >= p.tokN) { n -= p.tokN; ++b; }
-                        const long long rowidx = (((long long)b * 3 + qt) * p.heads + qh) * p.tokN + n;
-                        if (!p.qkv_split) *reinterpret_cast<f32x4*>(p.C + rowidx * p.hd + qd) = v[it];
-                        if (p.qkv_split) {
-                            split_t* o = reinterpret_cast<split_t*>(p.qkv_split) + rowidx * 2 * p.hd + qd;
+            if constexpr (MODE == GEMM_OUT_PLAIN) {
+                sfor<0, NT_N>([&](auto Jc) {
+                    constexpr int j = decltype(Jc)::value;
+                    const int c = colw + 32 * (j >> 1) + 4 * (j & 1);
+                    if (row_ok && c < p.N) *reinterpret_cast<f32x4*>(p.C + (long long)row * p.ldc + c) = v[j];
+                });
+            } else {
+                int qrow = 0;
+                if constexpr (MODE == GEMM_OUT_QKV_HEADMAJOR) {
+                    const int b = rowc / p.tokN, n = rowc - b * p.tokN;
+                    qrow = b * 3 * p.heads * p.tokN + n;
+                }
+                sfor<0, NT_N / 2>([&](auto JPc) {
+                    constexpr int jp = decltype(JPc)::value;
+                    const int c = colw + 32 * jp;
+                    const bool ok0 = row_ok && c < p.N && !(DBG & 64), ok1 = row_ok && c + 4 < p.N && !(DBG & 64);   // (64: timing arm without stores)
+                    unsigned hi[4], lo[4];          // 8 columns: packed pairs, already in store order
+    #pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        split_pair(v[2 * jp][2 * q], v[2 * jp][2 * q + 1], hi[q], lo[q]);
+                        split_pair(v[2 * jp + 1][2 * q], v[2 * jp + 1][2 * q + 1], hi[2 + q], lo[2 + q]);
+                    }
+                    if constexpr (DBG & 32) {       // timing arm: no split arithmetic (the raw bits of four of the values)
+                        *reinterpret_cast<f32x4*>(hi) = v[2 * jp];
+                        *reinterpret_cast<f32x4*>(lo) = v[2 * jp + 1];
+                    }
+                    if constexpr (MODE == GEMM_OUT_SPLIT_BF16) {
+                        split_t* o = reinterpret_cast<split_t*>(p.Cs) + (long long)row * 2 * p.N + split_off(c, 0);
+                        if (ok1) {
+                            *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(hi);
+                            *reinterpret_cast<uint4*>(o + 32) = *reinterpret_cast<const uint4*>(lo);
+                        } else if (ok0) {
                             *reinterpret_cast<uint2*>(o) = *reinterpret_cast<const uint2*>(hi);
-                            *reinterpret_cast<uint2*>(o + p.hd) = *reinterpret_cast<const uint2*>(lo);
+                            *reinterpret_cast<uint2*>(o + 32) = *reinterpret_cast<const uint2*>(lo);
+                        }
+                    } else {   // q|k|v head-major: fp32 (exact-mode consumers) or [hi hd | lo hd] planes for the bf16x3 attention
+                        const long long rowidx = (long long)(qoff[jp] + qrow);
+                        if (!p.qkv_split) {
+                            float* o = p.C + rowidx * p.hd + qdd[jp];
+                            if (ok0) *reinterpret_cast<f32x4*>(o) = v[2 * jp];
+                            if (ok1) *reinterpret_cast<f32x4*>(o + 4) = v[2 * jp + 1];
+                        } else {
+                            split_t* o = reinterpret_cast<split_t*>(p.qkv_split) + rowidx * 2 * p.hd + qdd[jp];
+                            if (ok1) {
+                                *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(hi);
+                                *reinterpret_cast<uint4*>(o + p.hd) = *reinterpret_cast<const uint4*>(lo);
+                            } else if (ok0) {
+                                *reinterpret_cast<uint2*>(o) = *reinterpret_cast<const uint2*>(hi);
+                                *reinterpret_cast<uint2*>(o + p.hd) = *reinterpret_cast<const uint2*>(lo);
+                            }
                         }
                     }
-                }
+                });
             }
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);               // read-backs done before the next group overwrites the scratch
-    });
+            __builtin_amdgcn_sched_barrier(0);      // one row tile at a time: hoisting the next tiles' accumulator reads and residual loads spills
+        });
+    };
+    if (p.out_mode == GEMM_OUT_SPLIT_BF16) epilogue(IC<GEMM_OUT_SPLIT_BF16>{});
+    else if (p.out_mode == GEMM_OUT_QKV_HEADMAJOR) epilogue(IC<GEMM_OUT_QKV_HEADMAJOR>{});
+    else epilogue(IC<GEMM_OUT_PLAIN>{});
 }
 
 bool excel_gemm_w4_supported(const GemmBfArgs& p) {
-    const bool vec = (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 && (p.hd & 3) == 0;
+    const bool vec = (p.N & 3) == 0 && p.N >= 8 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 && (p.hd & 7) == 0;
     return vec && p.batch <= 1 && p.K >= 64 && (p.K % 64) == 0 && (long long)p.M * p.lda * 2 < 0x7fffffffLL && (long long)p.N * p.ldb * 2 < 0x7fffffffLL;
 }
 
 int excel_launch_gemm_w4(const GemmBfArgs& p, hipStream_t stream) {
     EXCEL_CHECK_ARG(excel_gemm_w4_supported(p), "gemm_w4: unsupported problem (vector epilogue, batch 1, K %% 64 == 0, operands below 2 GB)");
-    hipLaunchKernelGGL(gemm_w4_kernel, dim3(cdiv(p.M, w4::BM) * cdiv(p.N, w4::BN)), dim3(256), 0, stream, p);
+    const dim3 grid(cdiv(p.M, w4::BM) * cdiv(p.N, w4::BN));
+#ifdef EXCEL_DEV
+    static const int dbg = getenv("EXCEL_W4_DBG") ? atoi(getenv("EXCEL_W4_DBG")) : 0;
+    switch (dbg) {
+        case 1: hipLaunchKernelGGL(gemm_w4_kernel<1>, grid, dim3(256), 0, stream, p); break;
+        case 2: hipLaunchKernelGGL(gemm_w4_kernel<2>, grid, dim3(256), 0, stream, p); break;
+        case 3: hipLaunchKernelGGL(gemm_w4_kernel<3>, grid, dim3(256), 0, stream, p); break;
+        case 4: hipLaunchKernelGGL(gemm_w4_kernel<4>, grid, dim3(256), 0, stream, p); break;
+        case 7: hipLaunchKernelGGL(gemm_w4_kernel<7>, grid, dim3(256), 0, stream, p); break;
+        case 8: hipLaunchKernelGGL(gemm_w4_kernel<8>, grid, dim3(256), 0, stream, p); break;
+        case 9: hipLaunchKernelGGL(gemm_w4_kernel<9>, grid, dim3(256), 0, stream, p); break;
+        case 10: hipLaunchKernelGGL(gemm_w4_kernel<10>, grid, dim3(256), 0, stream, p); break;
+        case 15: hipLaunchKernelGGL(gemm_w4_kernel<15>, grid, dim3(256), 0, stream, p); break;
+        case 24: hipLaunchKernelGGL(gemm_w4_kernel<24>, grid, dim3(256), 0, stream, p); break;
+        case 32: hipLaunchKernelGGL(gemm_w4_kernel<32>, grid, dim3(256), 0, stream, p); break;
+        case 64: hipLaunchKernelGGL(gemm_w4_kernel<64>, grid, dim3(256), 0, stream, p); break;
+        case 96: hipLaunchKernelGGL(gemm_w4_kernel<96>, grid, dim3(256), 0, stream, p); break;
+        default: hipLaunchKernelGGL(gemm_w4_kernel<0>, grid, dim3(256), 0, stream, p);
+    }
+#else
+    hipLaunchKernelGGL(gemm_w4_kernel<0>, grid, dim3(256), 0, stream, p);
+#endif
     EXCEL_CHECK_LAUNCH("gemm_w4");
     return EXCEL_OK;
 }
