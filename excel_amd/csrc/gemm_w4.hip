@@ -151,6 +151,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmBfArgs p) {
     splitx8 Bh[NT_N], Bl[NT_N];
 
     const int nk = p.K / 32;
+    int stamp_idx = 0;            // (DBG & 128 only)
 
     // reads of the head of a step from the stage at `S` (compile-time 0 / 1): A tiles 0 and 1, then (tail only) the B column pairs
     auto read_a = [&](auto Sc, auto Ic, auto SLOTc) {
@@ -195,7 +196,25 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmBfArgs p) {
         });
         // every read of stage P has been issued; this wave's pieces of stage 1 - P have landed -> one barrier publishes and frees
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if constexpr (DBG & 128) {        // cycle stamps (development): s_memtime before / after the barrier, wave 0 of workgroup 0 -> the `bias` buffer
+            if (blockIdx.x == 0 && wave == 0) {
+                unsigned long long t0 = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                unsigned long long rt = __builtin_amdgcn_s_memrealtime();      // constant 100 MHz: shader clock = d(memtime) / d(memrealtime) x 100 MHz
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) reinterpret_cast<unsigned long long*>(const_cast<float*>(p.bias))[2 * stamp_idx] = t0;
+                if (lane == 0) reinterpret_cast<unsigned long long*>(const_cast<float*>(p.bias))[256 + stamp_idx] = rt;
+            }
+        }
         if constexpr (!(DBG & 4)) __builtin_amdgcn_s_barrier();
+        if constexpr (DBG & 128) {
+            if (blockIdx.x == 0 && wave == 0) {
+                unsigned long long t1 = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) reinterpret_cast<unsigned long long*>(const_cast<float*>(p.bias))[2 * stamp_idx + 1] = t1;
+                ++stamp_idx;
+            }
+        }
         // tail: row tiles 8, 9 (VGPR accumulators) column-pair-major; the next step's A tiles 0, 1 first, then each pair's B fragments
         // as soon as its 12 MFMAs have been issued
         read_a(IC<1 - P>{}, IC<0>{}, IC<(2 * (1 - P) + 0) & 3>{});
@@ -396,6 +415,8 @@ int excel_launch_gemm_w4(const GemmBfArgs& p, hipStream_t stream) {
         case 24: hipLaunchKernelGGL(gemm_w4_kernel<24>, grid, dim3(256), 0, stream, p); break;
         case 32: hipLaunchKernelGGL(gemm_w4_kernel<32>, grid, dim3(256), 0, stream, p); break;
         case 64: hipLaunchKernelGGL(gemm_w4_kernel<64>, grid, dim3(256), 0, stream, p); break;
+        case 136: hipLaunchKernelGGL(gemm_w4_kernel<136>, grid, dim3(256), 0, stream, p); break;
+        case 143: hipLaunchKernelGGL(gemm_w4_kernel<143>, grid, dim3(256), 0, stream, p); break;
         case 96: hipLaunchKernelGGL(gemm_w4_kernel<96>, grid, dim3(256), 0, stream, p); break;
         default: hipLaunchKernelGGL(gemm_w4_kernel<0>, grid, dim3(256), 0, stream, p);
     }

@@ -1,0 +1,32 @@
+"""CI run of tests/parity_real_weights.py (the operator's real-weights parity command) on a tiny on-disk CLIP checkpoint + BPE file and a
+synthetic on-disk VOC tree: the command line, the checkpoint / tokenizer / data-set plumbing, the CPU restatement and the HIP path it
+compares, and its JSON record."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def test_parity_script_on_tiny_checkpoint(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _clip_files import write_tiny_clip
+    import parity_real_weights
+    from excel_amd.tools import synthetic
+    root, lists = str(tmp_path / "VOC2012"), str(tmp_path / "lists")
+    synthetic.write_voc_tree(root, lists, 5, seed=21)
+    ckpt, bpe_path, _ = write_tiny_clip(tmp_path)
+    out = parity_real_weights.main(["--model", ckpt, "--bpe_path", bpe_path, "--data_folder", root, "--list_folder", lists,
+                                    "--infer_set", "train", "--resize_size", "224", "--batch_size", "3", "--n_images", "5",
+                                    "--label_gate", "0.995"])
+    print(out)
+    assert out["images"] == 5 and out["scored_pixels"] > 0
+    assert out["cam_max_abs"] < 1e-3                                   # the north-star gate, on this checkpoint
+    assert out["label_agreement_mean"] >= 0.995 and out["ok"]
+    assert out["gemm_rung"]["started_in"] == "bf16x3" and out["gemm_rung"]["settled_on"] in ("bf16x3", "f16x3", "f32")
+    assert 0.0 <= out["miou_hip"] <= 1.0 and abs(out["miou_hip"] - out["miou_cpu"]) < 0.02

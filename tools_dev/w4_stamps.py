@@ -1,0 +1,26 @@
+"""Dev (EXCEL_DEV library, EXCEL_W4_DBG=136 or 143): cycle stamps of the four-wave GEMM's k-loop - s_memtime before / after every step's
+barrier on wave 0 of workgroup 0 -> cycles per 32-k step and cycles spent in the barrier."""
+import os, sys, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+if os.environ.get("EXCEL_AB_LIB"):
+    import excel_amd._lib as _L
+    _L.LIB_PATH = os.path.abspath(os.environ["EXCEL_AB_LIB"])
+from excel_amd import ops
+from excel_amd._lib import lib
+M, N, K = (int(x) for x in sys.argv[1:4]) if len(sys.argv) > 3 else (25120, 2304, 768)
+g = torch.Generator(device="cuda").manual_seed(0)
+A = torch.randn(M, K, device="cuda", generator=g); W = torch.randn(N, K, device="cuda", generator=g) * 0.05
+As, Ws = ops.split_bf16(A), ops.split_bf16(W)
+out = torch.empty((M, 2 * N), dtype=torch.float32, device="cuda")
+stamps = torch.zeros(max(N, 4096), dtype=torch.float32, device="cuda")
+st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+for _ in range(3):
+    lib().excel_gemm_bf16x3(As.data_ptr(), Ws.data_ptr(), out.data_ptr(), stamps.data_ptr(), None, M, N, K, 0, 1, st)
+torch.cuda.synchronize()
+t = stamps.view(torch.int64)[: 2 * (K // 32)].cpu().numpy().reshape(-1, 2)
+rt = stamps.view(torch.int64)[256: 256 + K // 32].cpu().numpy()
+step = t[1:, 0] - t[:-1, 0]
+print("  shader clock over the k-loop: %d cycles in %d ticks of the 100 MHz real-time counter -> %.2f GHz" % (t[-1, 0] - t[0, 0], rt[-1] - rt[0], (t[-1, 0] - t[0, 0]) / max(rt[-1] - rt[0], 1) * 0.1))
+print("dbg", os.environ.get("EXCEL_W4_DBG"), "shape", M, N, K, "| cycles per step (barrier arrival to next barrier arrival):", step.tolist())
+print("  mean step %.0f (240 MFMAs x 16 = 3840), barrier wait per step mean %.0f, max %.0f; s_memtime ticks are at 100 MHz x? check: total %.0f ticks" % (step.mean(), (t[:, 1] - t[:, 0]).mean(), (t[:, 1] - t[:, 0]).max(), t[-1, 0] - t[0, 0]))
