@@ -492,9 +492,10 @@ def main(argv=None, hooks=None):
                     traffic = par_traffic = traffic_source = None
             if mode in ("bf16x3", "f16x3"):
                 peak = BF16_MFMA_PEAK_TF
-                kname = ("gemm_bf16x3_kernel (fp32 operands as bf16 hi+lo planes, 3 x v_mfma_f32_16x16x32_bf16 per product; "
-                         "all nn.Linear / patch-embed / proj GEMMs)") if mode == "bf16x3" else (
-                         "gemm_bf16x3_kernel, IEEE-half instance (fp32 operands as f16 hi+lo planes, 3 x v_mfma_f32_16x16x32_f16 per product)")
+                kname = ("gemm_w4_kernel + gemm_bf16x3_kernel (fp32 operands as bf16 hi+lo planes, 3 x v_mfma_f32_16x16x32_bf16 per product; all "
+                         "nn.Linear / patch-embed / proj GEMMs: the 320x256-tile launches - 51 of 59 per step, 94 % of the time - run on the "
+                         "four-wave hand-scheduled kernel gemm_w4.hip)") if mode == "bf16x3" else (
+                         "gemm_w4_kernel + gemm_bf16x3_kernel, IEEE-half instances (fp32 operands as f16 hi+lo planes, 3 x v_mfma_f32_16x16x32_f16 per product)")
             else:
                 peak = F32_MATRIX_PEAK_TF
                 kname = "gemm_f32_kernel<NT> (fp32 MFMA 32x32x2; all nn.Linear / patch-embed / proj / sim GEMMs)"
@@ -519,6 +520,12 @@ def main(argv=None, hooks=None):
                 out["roofline"]["sustained_peak_random_operands"] = sustained
                 out["roofline"]["mfma_frac_of_sustained"] = round(3 * achieved / sustained, 4)
                 out["roofline"]["sustained_source"] = "profiles/r04_micro_mfma_power.txt (measured constant, not re-measured by this run)"
+                # where the rest goes, from in-kernel s_memtime / s_memrealtime stamps of the four-wave kernel (profiles/r05_w4_cycle_stamps.txt,
+                # measured constants): a 32-k step of 240 MFMAs takes 4 300 shader cycles (3 840 of matrix-pipe time: 0.89 busy INSIDE the
+                # k-loop; the bare one-wave MFMA stream takes 4 080) at a power-capped 1.86-1.94 GHz; the launch-level fraction above adds
+                # the epilogue (~21 % of a tile), prologue / dispatch (~8 %) and the tile quantisation of the grid (92.6 % at 711 tiles)
+                out["roofline"]["k_loop"] = {"cycles_per_32k_step": 4300, "mfma_cycles_per_step": 3840, "busy_in_k_loop": 0.89,
+                                             "shader_clock_ghz_in_k_loop": 1.9, "source": "profiles/r05_w4_cycle_stamps.txt"}
             # secondary rooflines (same event-timing source): PAR propagation (HBM) and the whole ViT (MFMA)
             par_it = prof["par_iterate"]
             if par_it["ms"] > 0:
@@ -560,6 +567,16 @@ def main(argv=None, hooks=None):
                     "mfma_issue_frac": round((3 if mode != "f32" else 1) * tf / vpeak, 4),
                     "algorithmic_gflop_per_image": round(cam_flops / steps / B / 1e9, 4), "survey_gflop_per_image": 0.653,
                     "ms_per_step": round(cam_ms / steps, 4),
+                    # the same launches priced as what they are bound by - bytes: the projection reads the ln_post tokens once (split planes =
+                    # 4 B per value) and writes x_raw, the norm pass and the similarity pass each read x_raw, the CAM goes out; the floor is
+                    # tokens in + CAM out (a fused projection -> similarity would never write x_raw)
+                    "bytes_view": (lambda moved, floor, t: {
+                        "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "moved_bytes_per_step": moved, "achieved": round(moved / t / 1e9, 1), "frac": round(moved / t / 1e9 / HBM_PEAK_GBS, 4),
+                        "floor_bytes_per_step": floor, "achieved_on_floor": round(floor / t / 1e9, 1), "frac_on_floor": round(floor / t / 1e9 / HBM_PEAK_GBS, 4),
+                        "reading": "four whole-chip launches of 15-65 us each: launch / latency bound, neither the matrix core nor HBM is near its peak; "
+                                   "0.5 % of the step"})(
+                        B * 785 * (768 * 4 + 3 * 512 * 4) + B * 784 * 20 * 4, B * 785 * 768 * 4 + B * 784 * 20 * 4, cam_ms / steps * 1e-3),
                     "note": "bound: 97 % of these flops are the projection GEMM (198 tiles on 256 CUs: 77 % of one round); the similarity part is HBM / "
                             "latency-bound (arithmetic intensity ~45 flop/B, SURVEY 8d; x_raw is read twice: norm pass + similarity pass); ln_post is timed under 'layernorm'"}
             out["kernel_ms_per_step"] = {k: round(v, 4) for k, v in sorted(ms.items(), key=lambda kv: -kv[1])}
