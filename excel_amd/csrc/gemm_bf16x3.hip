@@ -527,8 +527,36 @@ int excel_launch_gemm_bf16x3(const GemmBfArgs& p_in, hipStream_t stream) {
 #else
     const bool no_w4 = false;
 #endif
-    // the 320 x 256 tile runs on the four-wave kernel with the hand-placed k-loop (gemm_w4.hip) whenever its preconditions hold
-    if (kind == 3 && !no_w4 && excel_gemm_w4_supported(p)) return excel_launch_gemm_w4(p, stream);
+    // The four-wave kernel with the hand-placed k-loop (gemm_w4.hip) in its 320- / 256- / 160-row instance, whenever its preconditions
+    // hold and its modelled launch time beats the best 8-wave tile's.  8-wave model: algorithmic flops over (tile fill x intrinsic
+    // efficiency) x the 320 x 256 tile's measured rate at full fill (345 TFLOP/s fp32-equivalent at K = 768, 400 at K = 3072).
+    if (!no_w4 && nb == 1 && p.M >= 2048) {
+        static int n_cu3 = 0;
+        if (!n_cu3) {
+            int dev = 0; hipDeviceProp_t prop;
+            n_cu3 = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+        }
+        int force_ntm = 0;
+#ifdef EXCEL_DEV
+        { static const char* e = getenv("EXCEL_W4_NTM"); if (e) force_ntm = atoi(e); }       // dev knob: 10 / 8 / 5, -1 = model only
+        if (force && !strcmp(force, "320")) force_ntm = 10;
+#endif
+        const int bm8[4] = {128, 256, 256, 320}, bn8[4] = {128, 128, 256, 256}, wg8[4] = {2, 1, 1, 1};
+        const double in8[4] = {0.80, 0.88, 0.97, 1.0};
+        const long long tiles8 = (long long)cdiv(p.M, bm8[kind]) * cdiv(p.N, bn8[kind]), slots8 = (long long)n_cu3 * wg8[kind];
+        const double busy8 = ((double)p.M * p.N) / ((double)((tiles8 + slots8 - 1) / slots8) * slots8 * bm8[kind] * bn8[kind]);
+        const double kfac = p.K <= 768 ? 0.0 : (p.K >= 3072 ? 1.0 : (p.K - 768) / 2304.0);
+        double best_us = force ? 1e30 : 2.0 * p.M * (double)p.N * p.K / (busy8 * in8[kind] * (345.0 + 55.0 * kfac) * 1e6);
+        int best_ntm = 0;
+        const int cand[3] = {10, 8, 5};
+        for (int c = 0; c < 3; ++c) {
+            if (!excel_gemm_w4_supported(p, cand[c])) continue;
+            if (force_ntm > 0) { if (cand[c] == force_ntm) { best_ntm = force_ntm; } continue; }
+            const double us = excel_gemm_w4_model_us(p, cand[c], n_cu3);
+            if (us < best_us) { best_us = us; best_ntm = cand[c]; }
+        }
+        if (best_ntm) return excel_launch_gemm_w4(p, best_ntm, stream);
+    }
     if (kind == 3 && nb == 1 && !force_uniform) {
         // mixed-height row tiles (kernel header): R = rounds of the uniform 320-row tiling; nt = the row tiles that fit into R rounds;
         // `tall` of them must be 320 rows high to cover M, the rest can be 256.  Worth it when the tall tiles leave room in the last round

@@ -39,11 +39,35 @@ typedef unsigned short u16;
 #endif
 
 namespace w4 {
-constexpr int BM = 320, BN = 256, WTM = 160, WTN = 128;
+constexpr int BN = 256, WTN = 128;
 constexpr int ROWB = 128;                           // bytes per staged row
-constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;   // 40 960 + 32 768 = 73 728
-constexpr int NT_M = WTM / 16, NT_N = WTN / 16;      // 10 x 8 accumulator tiles of 16 x 16 per wave
-constexpr int A_PIECES = BM / 8 / 4, B_PIECES = BN / 8 / 4, PIECES = A_PIECES + B_PIECES;   // 1-KB DMA pieces per wave and stage: 10 + 8
+constexpr int B_BYTES = BN * ROWB;                  // 32 768
+constexpr int NT_N = WTN / 16;                      // 8 column tiles of 16 per wave
+constexpr int B_PIECES = BN / 8 / 4;                // 1-KB DMA pieces of the weight rows per wave and stage: 8
+// Geometry of an instance: a wave owns NT_M x 8 accumulator tiles (16 NT_M rows x 128 columns), the workgroup 32 NT_M x 256.
+//   NT_M = 10: 320 x 256 (the B = 32 layer shapes: 237 / 711 / 948 tiles), 8: 256 x 256, 5: 160 x 256 (B = 16: 237 tiles for N = 768)
+template <int NT_M>
+struct Geo {
+    static constexpr int BM = 32 * NT_M, WTM = 16 * NT_M;
+    static constexpr int A_BYTES = BM * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
+    static constexpr int A_PIECES = NT_M, PIECES = A_PIECES + B_PIECES;      // BM / 8 rows per piece / 4 waves = NT_M
+    static constexpr int MAIN = NT_M - 2;                 // row tiles in front of the barrier (AGPR accumulators); the last two form the tail (VGPR)
+    static constexpr int UNROLL = (NT_M & 1) ? 4 : 2;     // steps until (step * NT_M) % 4 (A-ring phase) and the stage parity repeat
+    // DMA pieces of the stage after next that already go out in the TAIL of a step (into the stage its barrier has just freed): only the
+    // short instance needs them - its three main row tiles are too few to both issue 13 pieces and cover their latency
+    static constexpr int TAILQ = NT_M == 5 ? 8 : 0;
+    // pieces per main row tile, at MFMA positions pos(count, k)
+    static constexpr int cnt(int i) { return NT_M == 10 ? (i <= 2 ? 4 : i <= 4 ? 3 : 0) : NT_M == 8 ? (i <= 1 ? 5 : i <= 3 ? 3 : 0) : (i == 0 ? 5 : 0); }
+    static constexpr int pos(int c, int k) { return c == 5 ? (k == 0 ? 2 : k == 1 ? 6 : k == 2 ? 10 : k == 3 ? 14 : 20) : c == 4 ? (k == 0 ? 2 : k == 1 ? 10 : k == 2 ? 14 : 20) : (k == 0 ? 2 : k == 1 ? 10 : 14); }
+    // piece issued behind MFMA n of main row tile i, or -1
+    static constexpr int piece_at(int i, int n) {
+        int q = TAILQ;
+        for (int t = 0; t < i; ++t) q += cnt(t);
+        for (int k = 0; k < cnt(i); ++k) if (pos(cnt(i), k) == n) return q + k;
+        return -1;
+    }
+    static_assert(TAILQ + cnt(0) + cnt(1) + cnt(2) + cnt(3) + cnt(4) == PIECES, "every piece has a slot");
+};
 
 template <int I> using IC = std::integral_constant<int, I>;
 template <int B, int E, class F>
@@ -81,13 +105,16 @@ __device__ __forceinline__ void wait_lgkm() {
 }
 }  // namespace w4
 
-// One launch = cdiv(M,320) x cdiv(N,256) workgroups of 256 threads.  Preconditions (checked by the launcher): K % 64 == 0 (an even number of 32-k steps),
+// One launch = cdiv(M, 32 NT_M) x cdiv(N,256) workgroups of 256 threads.  Preconditions (checked by the launcher): K % 64 == 0 (K % 128 for the odd NT_M = 5: the k-loop is unrolled until ring phase and stage parity repeat),
 // N, ldc, ldr, hd multiples of 4 (vector epilogue), operand extents below 2^31 bytes (32-bit buffer offsets), batch == 1.
 // DBG (development builds only; the shipped library instantiates DBG = 0): timing-only ablation arms, results are wrong -
 //   1 no LDS-DMA after the prologue, 2 no fragment reads after the prologue, 4 no barrier in the k-loop, 8 no epilogue, 16 no MFMAs
-template <int DBG>
-__global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmBfArgs p) {
+template <int NT_M, int DBG>
+__device__ __forceinline__ void gemm_w4_body(GemmBfArgs p) {
     using namespace w4;
+    using G = Geo<NT_M>;
+    constexpr int BM = G::BM, WTM = G::WTM, A_BYTES = G::A_BYTES, STAGE_BYTES = G::STAGE_BYTES, A_PIECES = G::A_PIECES, PIECES = G::PIECES;
+    constexpr int MAIN = G::MAIN, UNROLL = G::UNROLL, TAILQ = G::TAILQ;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -142,12 +169,12 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmBfArgs p) {
     const unsigned b_lo = smem_base + A_BYTES + (wn * WTN + brow) * ROWB + (((4 + kg) ^ swb) * 16);
     const unsigned a_hi1 = a_hi + STAGE_BYTES, a_lo1 = a_lo + STAGE_BYTES, b_hi1 = b_hi + STAGE_BYTES, b_lo1 = b_lo + STAGE_BYTES;
 
-    f32x4 accA[8][NT_N];      // AGPR file
-    f32x4 accV[2][NT_N];      // VGPR file
-    sfor<0, 8>([&](auto I) { sfor<0, NT_N>([&](auto J) { accA[decltype(I)::value][decltype(J)::value] = f32x4{0.f, 0.f, 0.f, 0.f}; }); });
+    f32x4 accA[MAIN][NT_N];   // AGPR file: row tiles 0 .. MAIN-1
+    f32x4 accV[2][NT_N];      // VGPR file: the two tail row tiles
+    sfor<0, MAIN>([&](auto I) { sfor<0, NT_N>([&](auto J) { accA[decltype(I)::value][decltype(J)::value] = f32x4{0.f, 0.f, 0.f, 0.f}; }); });
     sfor<0, 2>([&](auto I) { sfor<0, NT_N>([&](auto J) { accV[decltype(I)::value][decltype(J)::value] = f32x4{0.f, 0.f, 0.f, 0.f}; }); });
 
-    splitx8 Ah[4], Al[4];     // ring of A fragments: row tile i of a step with parity P sits in slot (2 P + i) & 3
+    splitx8 Ah[4], Al[4];     // ring of A fragments: row tile i of step P (mod UNROLL) sits in slot (P NT_M + i) & 3
     splitx8 Bh[NT_N], Bl[NT_N];
 
     const int nk = p.K / 32;
@@ -167,16 +194,17 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmBfArgs p) {
         lds_rd<(32 * (j >> 1) + 4 * (j & 1)) * ROWB>(Bl[j], S ? b_lo1 : b_lo);
     };
 
-    // ---- one 32-k step.  P = step parity: data in stage P, A-ring phase 2 P.  The stage of the NEXT step (k offset `soff_next` bytes) is
-    // fetched during this one.  The last step fetches its own k-block once more into the other stage (nobody reads it; +1/nk of the
-    // L2 -> LDS traffic): the stream then has no end-of-loop variant - one copy of each parity, no per-piece branches, and no join of
-    // differently allocated accumulator sets (a peeled last pair made the compiler permute 256 AGPRs and spill 24 VGPRs at the seam).
-    auto step = [&](auto Pc, int soff_next) {
-        constexpr int P = decltype(Pc)::value;
-        // row tiles 0..7, pass-major: lo.hi over the 8 column tiles, then hi.lo, then hi.hi (small terms first)
-        sfor<0, 8>([&](auto Ic) {
+    // ---- one 32-k step.  P = step index mod UNROLL: data in stage P & 1, A-ring phase P NT_M.  The stage of the NEXT step (k offset
+    // `soff_next` bytes) is fetched during this one (and, short instance, its first TAILQ pieces already in the previous step's tail: this
+    // step's tail issues those of the step after next, k offset `soff_next2`, into the stage its barrier has just freed).  Past the end of
+    // K the offsets are clamped to the last k-block (fetched once more, never read; +1/nk of the L2 -> LDS traffic): the stream has no
+    // end-of-loop variant - one copy per step phase, no per-piece branches, no join of differently allocated accumulator sets.
+    auto step = [&](auto Pc, int soff_next, int soff_next2) {
+        constexpr int P = decltype(Pc)::value, S = P & 1, R = (P * NT_M) & 3, Rn = ((P + 1) * NT_M) & 3;
+        // main row tiles, pass-major: lo.hi over the 8 column tiles, then hi.lo, then hi.hi (small terms first)
+        sfor<0, MAIN>([&](auto Ic) {
             constexpr int i = decltype(Ic)::value;
-            constexpr int slot = (2 * P + i) & 3;
+            constexpr int slot = (R + i) & 3;
             if constexpr (i > 0) wait_lgkm<2>();              // tile i landed; only tile i + 1's two reads may still be in flight
             sfor<0, 3 * NT_N>([&](auto Nc) {
                 constexpr int n = decltype(Nc)::value, pass = n / NT_N, j = n % NT_N;
@@ -186,12 +214,10 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmBfArgs p) {
                 else if constexpr (pass == 1) mfma_agpr<!(DBG & 16)>(accA[i][j], Ah[slot], Bl[j]);
                 else mfma_agpr<!(DBG & 16)>(accA[i][j], Ah[slot], Bh[j]);
                 // A fragments two row tiles ahead (ring slot of tile i - 2, retired), behind the first pass
-                if constexpr (n == NT_N) read_a(IC<P>{}, IC<i + 2>{}, IC<(2 * P + i + 2) & 3>{});
-                // the next stage's DMA pieces: 4,4,4,3,3 over row tiles 0..4, one piece between MFMAs
-                if constexpr (i <= 4 && (n == 2 || n == 10 || n == 14 || (n == 20 && i <= 2))) {
-                    constexpr int q = (i <= 2 ? 4 * i : 12 + 3 * (i - 3)) + (n == 2 ? 0 : n == 10 ? 1 : n == 14 ? 2 : 3);
-                    if constexpr (!(DBG & 1)) dma(IC<q>{}, IC<q + 1>{}, (1 - P) * STAGE_BYTES, soff_next);
-                }
+                if constexpr (n == NT_N) read_a(IC<S>{}, IC<i + 2>{}, IC<(R + i + 2) & 3>{});
+                // the next stage's DMA pieces, one at a time between MFMAs (Geo::piece_at)
+                constexpr int q = G::piece_at(i, n);
+                if constexpr (q >= 0 && !(DBG & 1)) dma(IC<q>{}, IC<q + 1>{}, (1 - S) * STAGE_BYTES, soff_next);
             });
         });
         // every read of stage P has been issued; this wave's pieces of stage 1 - P have landed -> one barrier publishes and frees
@@ -215,36 +241,42 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmBfArgs p) {
                 ++stamp_idx;
             }
         }
-        // tail: row tiles 8, 9 (VGPR accumulators) column-pair-major; the next step's A tiles 0, 1 first, then each pair's B fragments
-        // as soon as its 12 MFMAs have been issued
-        read_a(IC<1 - P>{}, IC<0>{}, IC<(2 * (1 - P) + 0) & 3>{});
-        read_a(IC<1 - P>{}, IC<1>{}, IC<(2 * (1 - P) + 1) & 3>{});
-        constexpr int s8 = (2 * P + 8) & 3, s9 = (2 * P + 9) & 3;
+        // tail: the last two row tiles (VGPR accumulators) column-pair-major; the next step's A tiles 0, 1 first, then each pair's B
+        // fragments as soon as its 12 MFMAs have been issued
+        read_a(IC<1 - S>{}, IC<0>{}, IC<(Rn + 0) & 3>{});
+        read_a(IC<1 - S>{}, IC<1>{}, IC<(Rn + 1) & 3>{});
+        constexpr int s8 = (R + NT_M - 2) & 3, s9 = (R + NT_M - 1) & 3;
         sfor<0, NT_N / 2>([&](auto JPc) {
-            constexpr int j0 = 2 * decltype(JPc)::value, j1 = j0 + 1;
+            constexpr int jp = decltype(JPc)::value, j0 = 2 * jp, j1 = j0 + 1;
             mfma_vgpr<!(DBG & 16)>(accV[0][j0], Al[s8], Bh[j0]); mfma_vgpr<!(DBG & 16)>(accV[0][j1], Al[s8], Bh[j1]);
             mfma_vgpr<!(DBG & 16)>(accV[1][j0], Al[s9], Bh[j0]); mfma_vgpr<!(DBG & 16)>(accV[1][j1], Al[s9], Bh[j1]);
             mfma_vgpr<!(DBG & 16)>(accV[0][j0], Ah[s8], Bl[j0]); mfma_vgpr<!(DBG & 16)>(accV[0][j1], Ah[s8], Bl[j1]);
             mfma_vgpr<!(DBG & 16)>(accV[1][j0], Ah[s9], Bl[j0]); mfma_vgpr<!(DBG & 16)>(accV[1][j1], Ah[s9], Bl[j1]);
             mfma_vgpr<!(DBG & 16)>(accV[0][j0], Ah[s8], Bh[j0]); mfma_vgpr<!(DBG & 16)>(accV[0][j1], Ah[s8], Bh[j1]);
             mfma_vgpr<!(DBG & 16)>(accV[1][j0], Ah[s9], Bh[j0]); mfma_vgpr<!(DBG & 16)>(accV[1][j1], Ah[s9], Bh[j1]);
-            read_b(IC<1 - P>{}, IC<j0>{});
-            read_b(IC<1 - P>{}, IC<j1>{});
+            read_b(IC<1 - S>{}, IC<j0>{});
+            read_b(IC<1 - S>{}, IC<j1>{});
+            // short instance: two pieces of the step after next, into the stage this step's barrier has freed
+            if constexpr (2 * jp + 1 < TAILQ && !(DBG & 1)) dma(IC<2 * jp>{}, IC<2 * jp + 2>{}, S * STAGE_BYTES, soff_next2);
         });
     };
 
-    // ---- prologue: stage 0 <- k-block 0, published; head reads of step 0 in the order the tail issues them
+    // ---- prologue: stage 0 <- k-block 0 (and the pieces of k-block 1 a tail would have issued), published; head reads of step 0 in the
+    // order the tail issues them
+    const int soff_last = (nk - 1) * 128;
     dma(IC<0>{}, IC<PIECES>{}, 0u, 0);
+    if constexpr (TAILQ > 0) dma(IC<0>{}, IC<TAILQ>{}, (unsigned)STAGE_BYTES, min(128, soff_last));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     read_a(IC<0>{}, IC<0>{}, IC<0>{});
     read_a(IC<0>{}, IC<1>{}, IC<1>{});
     sfor<0, NT_N>([&](auto J) { read_b(IC<0>{}, J); });
 
-    const int soff_last = (nk - 1) * 128;
-    for (int kt = 0; kt < nk; kt += 2) {                 // nk is even (K % 64 == 0 is a precondition)
-        step(IC<0>{}, (kt + 1) * 128);
-        step(IC<1>{}, min((kt + 2) * 128, soff_last));
+    for (int kt = 0; kt < nk; kt += UNROLL) {            // nk is a multiple of UNROLL (a precondition)
+        sfor<0, UNROLL>([&](auto Pc) {
+            constexpr int P = decltype(Pc)::value;
+            step(Pc, min((kt + P + 1) * 128, soff_last), min((kt + P + 2) * 128, soff_last));
+        });
     }
     // the tail of the last step read (stale) fragments that nobody uses; retire them and let the matrix pipe drain before the
     // compiler's own accumulator reads (it cannot see that the asm statements above are MFMAs)
@@ -254,7 +286,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmBfArgs p) {
 
     if constexpr (DBG & 8) {        // the accumulators stay live through a store that never happens
         float sum = 0.f;
-        sfor<0, 8>([&](auto I) { sfor<0, NT_N>([&](auto J) { const f32x4 v = accA[decltype(I)::value][decltype(J)::value]; sum += v[0] + v[1] + v[2] + v[3]; }); });
+        sfor<0, MAIN>([&](auto I) { sfor<0, NT_N>([&](auto J) { const f32x4 v = accA[decltype(I)::value][decltype(J)::value]; sum += v[0] + v[1] + v[2] + v[3]; }); });
         sfor<0, 2>([&](auto I) { sfor<0, NT_N>([&](auto J) { const f32x4 v = accV[decltype(I)::value][decltype(J)::value]; sum += v[0] + v[1] + v[2] + v[3]; }); });
         if (sum == 1.2345e-30f) p.C[0] = sum;
         return;
@@ -295,14 +327,14 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmBfArgs p) {
             });
         }
         sfor<0, NT_M>([&](auto Ic) {
-            constexpr int i = (decltype(Ic)::value + 8) % NT_M;          // row tiles 8, 9 first: their accumulators occupy 64 VGPRs
+            constexpr int i = (decltype(Ic)::value + MAIN) % NT_M;       // the tail row tiles first: their accumulators occupy 64 VGPRs
             const int row = m0 + wm * WTM + 16 * i + r16e;
             const bool row_ok = row < p.M;
             const int rowc = row_ok ? row : p.M - 1;
             f32x4 v[NT_N];
             sfor<0, NT_N>([&](auto Jc) {
                 constexpr int j = decltype(Jc)::value;
-                if constexpr (i < 8) v[j] = accA[i][j]; else v[j] = accV[i - 8][j];
+                if constexpr (i < MAIN) v[j] = accA[i][j]; else v[j] = accV[i - MAIN][j];
                 asm volatile("" : "+v"(v[j]));        // a clean AGPR -> VGPR copy point (left alone, the allocator splits the tiles into
                                                       // 64-bit halves for packed adds and permutes 200 AGPRs at the loop exit)
             });
@@ -392,37 +424,65 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmBfArgs p) {
     else epilogue(IC<GEMM_OUT_PLAIN>{});
 }
 
-bool excel_gemm_w4_supported(const GemmBfArgs& p) {
+// nt_m: 10 (320-row tiles), 8 (256) or 5 (160)
+bool excel_gemm_w4_supported(const GemmBfArgs& p, int nt_m) {
     const bool vec = (p.N & 3) == 0 && p.N >= 8 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 && (p.hd & 7) == 0;
-    return vec && p.batch <= 1 && p.K >= 64 && (p.K % 64) == 0 && (long long)p.M * p.lda * 2 < 0x7fffffffLL && (long long)p.N * p.ldb * 2 < 0x7fffffffLL;
+    const int kq = 32 * ((nt_m & 1) ? 4 : 2);          // the k-loop is unrolled over 2 (4) steps of 32
+    return (nt_m == 10 || nt_m == 8 || nt_m == 5) && vec && p.batch <= 1 && p.K >= kq && (p.K % kq) == 0 &&
+           (long long)p.M * p.lda * 2 < 0x7fffffffLL && (long long)p.N * p.ldb * 2 < 0x7fffffffLL;
 }
 
-int excel_launch_gemm_w4(const GemmBfArgs& p, hipStream_t stream) {
-    EXCEL_CHECK_ARG(excel_gemm_w4_supported(p), "gemm_w4: unsupported problem (vector epilogue, batch 1, K %% 64 == 0, operands below 2 GB)");
-    const dim3 grid(cdiv(p.M, w4::BM) * cdiv(p.N, w4::BN));
+// Modelled time (us) of one launch of the nt_m instance on n_cu CUs: rounds of tiles x (prologue + row tiles x (k-steps x 0.233 + epilogue
+// 1.8)); calibrated on the B = 32 layer shapes (profiles/r05_w4_arms.txt: a 320-row tile of K = 768 is 56 us of k-loop + 18 of epilogue + 7),
+// the short instance pays ~8 % more per row tile for its fragment reads (26 instead of 36 per 240 MFMAs-equivalent).  The launcher compares
+// this against the 8-wave tiles' model (gemm_bf16x3.hip).
+double excel_gemm_w4_model_us(const GemmBfArgs& p, int nt_m, int n_cu) {
+    const long long tiles = (long long)cdiv(p.M, 32 * nt_m) * cdiv(p.N, w4::BN);
+    const long long rounds = (tiles + n_cu - 1) / n_cu;
+    const double per_row_tile = (p.K / 32) * 0.233 * (nt_m == 5 ? 1.08 : nt_m == 8 ? 1.02 : 1.0) + 1.8;
+    return rounds * (7.0 + nt_m * per_row_tile);
+}
+
+// one plain __global__ function per instance (a kernel TEMPLATE launched from inside a function template lost its host-side stub)
+#define W4_KERNEL(NT, DBG) __global__ __launch_bounds__(256, 1) void gemm_w4_kernel_##NT##_##DBG(GemmBfArgs p) { gemm_w4_body<NT, DBG>(p); }
+W4_KERNEL(10, 0) W4_KERNEL(8, 0) W4_KERNEL(5, 0)
+#ifdef EXCEL_DEV
+W4_KERNEL(10, 1) W4_KERNEL(10, 2) W4_KERNEL(10, 4) W4_KERNEL(10, 8) W4_KERNEL(8, 8) W4_KERNEL(5, 8) W4_KERNEL(10, 9) W4_KERNEL(10, 10)
+W4_KERNEL(10, 15) W4_KERNEL(10, 24) W4_KERNEL(10, 32) W4_KERNEL(10, 136) W4_KERNEL(10, 143)
+#endif
+#define W4_LAUNCH(NT, DBG) hipLaunchKernelGGL(gemm_w4_kernel_##NT##_##DBG, grid, dim3(256), 0, stream, p)
+
+static void launch_w4(const GemmBfArgs& p, int nt_m, hipStream_t stream) {
+    const dim3 grid(cdiv(p.M, 32 * nt_m) * cdiv(p.N, w4::BN));
 #ifdef EXCEL_DEV
     static const int dbg = getenv("EXCEL_W4_DBG") ? atoi(getenv("EXCEL_W4_DBG")) : 0;
-    switch (dbg) {
-        case 1: hipLaunchKernelGGL(gemm_w4_kernel<1>, grid, dim3(256), 0, stream, p); break;
-        case 2: hipLaunchKernelGGL(gemm_w4_kernel<2>, grid, dim3(256), 0, stream, p); break;
-        case 3: hipLaunchKernelGGL(gemm_w4_kernel<3>, grid, dim3(256), 0, stream, p); break;
-        case 4: hipLaunchKernelGGL(gemm_w4_kernel<4>, grid, dim3(256), 0, stream, p); break;
-        case 7: hipLaunchKernelGGL(gemm_w4_kernel<7>, grid, dim3(256), 0, stream, p); break;
-        case 8: hipLaunchKernelGGL(gemm_w4_kernel<8>, grid, dim3(256), 0, stream, p); break;
-        case 9: hipLaunchKernelGGL(gemm_w4_kernel<9>, grid, dim3(256), 0, stream, p); break;
-        case 10: hipLaunchKernelGGL(gemm_w4_kernel<10>, grid, dim3(256), 0, stream, p); break;
-        case 15: hipLaunchKernelGGL(gemm_w4_kernel<15>, grid, dim3(256), 0, stream, p); break;
-        case 24: hipLaunchKernelGGL(gemm_w4_kernel<24>, grid, dim3(256), 0, stream, p); break;
-        case 32: hipLaunchKernelGGL(gemm_w4_kernel<32>, grid, dim3(256), 0, stream, p); break;
-        case 64: hipLaunchKernelGGL(gemm_w4_kernel<64>, grid, dim3(256), 0, stream, p); break;
-        case 136: hipLaunchKernelGGL(gemm_w4_kernel<136>, grid, dim3(256), 0, stream, p); break;
-        case 143: hipLaunchKernelGGL(gemm_w4_kernel<143>, grid, dim3(256), 0, stream, p); break;
-        case 96: hipLaunchKernelGGL(gemm_w4_kernel<96>, grid, dim3(256), 0, stream, p); break;
-        default: hipLaunchKernelGGL(gemm_w4_kernel<0>, grid, dim3(256), 0, stream, p);
+    if (nt_m == 10) {
+        switch (dbg) {
+            case 1: W4_LAUNCH(10, 1); return;
+            case 2: W4_LAUNCH(10, 2); return;
+            case 4: W4_LAUNCH(10, 4); return;
+            case 8: W4_LAUNCH(10, 8); return;
+            case 9: W4_LAUNCH(10, 9); return;
+            case 10: W4_LAUNCH(10, 10); return;
+            case 15: W4_LAUNCH(10, 15); return;
+            case 24: W4_LAUNCH(10, 24); return;
+            case 32: W4_LAUNCH(10, 32); return;
+            case 136: W4_LAUNCH(10, 136); return;
+            case 143: W4_LAUNCH(10, 143); return;
+            default: break;
+        }
     }
-#else
-    hipLaunchKernelGGL(gemm_w4_kernel<0>, grid, dim3(256), 0, stream, p);
+    if (dbg == 8 && nt_m == 8) { W4_LAUNCH(8, 8); return; }
+    if (dbg == 8 && nt_m == 5) { W4_LAUNCH(5, 8); return; }
 #endif
+    if (nt_m == 10) W4_LAUNCH(10, 0);
+    else if (nt_m == 8) W4_LAUNCH(8, 0);
+    else W4_LAUNCH(5, 0);
+}
+
+int excel_launch_gemm_w4(const GemmBfArgs& p, int nt_m, hipStream_t stream) {
+    EXCEL_CHECK_ARG(excel_gemm_w4_supported(p, nt_m), "gemm_w4: unsupported problem (vector epilogue, batch 1, K %% 64 (128) == 0, operands below 2 GB)");
+    launch_w4(p, nt_m, stream);
     EXCEL_CHECK_LAUNCH("gemm_w4");
     return EXCEL_OK;
 }
