@@ -121,6 +121,23 @@ __device__ __forceinline__ void gemm_w4_body(GemmBfArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    // (DBG & 128) phase stamps of workgroups 0 / 100 / 200, wave 0: s_memrealtime (100 MHz) at entry, after the prologue's barrier, behind the
+    // k-loop and at the end -> `bias` buffer, u64 slots 400 + 8 (blockIdx / 100) + phase
+    auto phase_stamp = [&](int ph) {
+        if constexpr (DBG & 128) {
+            if (wave == 0 && (ph == 0 || ph == 3) && blockIdx.x < 700) {          // every workgroup: entry and end -> slots 500 + 2 b
+                const unsigned long long rt = __builtin_amdgcn_s_memrealtime();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) reinterpret_cast<unsigned long long*>(const_cast<float*>(p.bias))[500 + 2 * blockIdx.x + (ph ? 1 : 0)] = rt;
+            }
+            if (wave == 0 && (blockIdx.x % 100) == 0 && blockIdx.x < 300) {
+                const unsigned long long rt = __builtin_amdgcn_s_memrealtime();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) reinterpret_cast<unsigned long long*>(const_cast<float*>(p.bias))[400 + 8 * (blockIdx.x / 100) + ph] = rt;
+            }
+        }
+    };
+    phase_stamp(0);
     const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     const int tm = id / tiles_n, tn = id - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
@@ -268,6 +285,7 @@ __device__ __forceinline__ void gemm_w4_body(GemmBfArgs p) {
     if constexpr (TAILQ > 0) dma(IC<0>{}, IC<TAILQ>{}, (unsigned)STAGE_BYTES, min(128, soff_last));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    phase_stamp(1);
     read_a(IC<0>{}, IC<0>{}, IC<0>{});
     read_a(IC<0>{}, IC<1>{}, IC<1>{});
     sfor<0, NT_N>([&](auto J) { read_b(IC<0>{}, J); });
@@ -283,6 +301,7 @@ __device__ __forceinline__ void gemm_w4_body(GemmBfArgs p) {
     // (the vmcnt(0) also retires the last step's spare fetch: no LDS-DMA may land after this workgroup has ended.  No barrier: the
     // epilogue does not touch LDS)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_nop 15\n s_nop 15" ::: "memory");
+    phase_stamp(2);
 
     if constexpr (DBG & 8) {        // the accumulators stay live through a store that never happens
         float sum = 0.f;
@@ -422,6 +441,7 @@ __device__ __forceinline__ void gemm_w4_body(GemmBfArgs p) {
     if (p.out_mode == GEMM_OUT_SPLIT_BF16) epilogue(IC<GEMM_OUT_SPLIT_BF16>{});
     else if (p.out_mode == GEMM_OUT_QKV_HEADMAJOR) epilogue(IC<GEMM_OUT_QKV_HEADMAJOR>{});
     else epilogue(IC<GEMM_OUT_PLAIN>{});
+    if constexpr (DBG & 128) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); phase_stamp(3); }
 }
 
 // nt_m: 10 (320-row tiles), 8 (256) or 5 (160)
@@ -448,7 +468,7 @@ double excel_gemm_w4_model_us(const GemmBfArgs& p, int nt_m, int n_cu) {
 W4_KERNEL(10, 0) W4_KERNEL(8, 0) W4_KERNEL(5, 0)
 #ifdef EXCEL_DEV
 W4_KERNEL(10, 1) W4_KERNEL(10, 2) W4_KERNEL(10, 4) W4_KERNEL(10, 8) W4_KERNEL(8, 8) W4_KERNEL(5, 8) W4_KERNEL(10, 9) W4_KERNEL(10, 10)
-W4_KERNEL(10, 15) W4_KERNEL(10, 24) W4_KERNEL(10, 32) W4_KERNEL(10, 136) W4_KERNEL(10, 143)
+W4_KERNEL(10, 15) W4_KERNEL(10, 24) W4_KERNEL(10, 32) W4_KERNEL(10, 136) W4_KERNEL(10, 143) W4_KERNEL(10, 128)
 #endif
 #define W4_LAUNCH(NT, DBG) hipLaunchKernelGGL(gemm_w4_kernel_##NT##_##DBG, grid, dim3(256), 0, stream, p)
 
@@ -467,6 +487,7 @@ static void launch_w4(const GemmBfArgs& p, int nt_m, hipStream_t stream) {
             case 15: W4_LAUNCH(10, 15); return;
             case 24: W4_LAUNCH(10, 24); return;
             case 32: W4_LAUNCH(10, 32); return;
+            case 128: W4_LAUNCH(10, 128); return;
             case 136: W4_LAUNCH(10, 136); return;
             case 143: W4_LAUNCH(10, 143); return;
             default: break;
