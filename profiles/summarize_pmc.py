@@ -49,9 +49,10 @@ def main(fetch_csv, write_csv, head=None):
         out[k] = dict(launches=n, fetch_size_kb_avg=round(f_kb, 1), write_size_kb_avg=round(w_kb, 1),
                       bytes_per_launch=int((2 * f_kb + w_kb) * 1024))
     top = {}
-    for cat, prefix in (("gemm_bf16x3", "gemm_bf16x3_kernel"), ("par_iterate", "par_iterate"), ("attn_rowpass", "attn_rowpass"),
-                        ("attn_accum", "attn_accum"), ("attn_strip", "attn_strip"), ("par_iterate_guide", "par_iterate_guide")):
-        ks = [v for k, v in out.items() if k.startswith(prefix)]
+    # (the bf16x3 GEMM category of bench.py = the four-wave kernel gemm_w4_kernel_* + the 8-wave gemm_bf16x3_kernel instances)
+    for cat, prefix in (("gemm_bf16x3", ("gemm_bf16x3_kernel", "gemm_w4_kernel")), ("par_iterate", ("par_iterate",)), ("attn_rowpass", ("attn_rowpass",)),
+                        ("attn_accum", ("attn_accum",)), ("attn_strip", ("attn_strip",)), ("par_iterate_guide", ("par_iterate_guide",))):
+        ks = [v for k, v in out.items() if any(px in k for px in prefix)]
         n = sum(v["launches"] for v in ks)
         if n:        # launch-weighted mean over the template instances of one bench category
             top[cat + "_bytes_per_launch"] = int(sum(v["bytes_per_launch"] * v["launches"] for v in ks) / n)
