@@ -1,28 +1,34 @@
-// "w4" bf16x3 GEMM: the 320 x 256 tile of gemm_bf16x3.hip on FOUR waves, one per SIMD, with a hand-placed instruction stream.
+// "w4" bf16x3 GEMM: the big tiles of gemm_bf16x3.hip on FOUR waves, one per SIMD, with a hand-placed instruction stream.
 //
-//   C[M,N] (fp32 or split) = act(A_split[M,K] . W_split[N,K]^T + bias) + residual          (same operands, layouts and epilogues)
+//   C[M,N] (fp32 or split) = act(A_split[M,K] . W_split[N,K]^T + bias) + residual          (same operands, layouts and epilogue semantics)
 //
-// Why a second kernel (rounds 3 and 4 measured this): the 8-wave kernel's k-loop takes 1.49x its own MFMA stream.  Its
+// Why a second kernel (rounds 3 and 4 measured this, EXPERIMENTS.md): the 8-wave kernel's k-loop takes 1.49x its own MFMA stream.  Its
 // waves own 160 x 64 outputs - 28 fragment reads per 120 MFMAs - and all eight of them stop at a __syncthreads() every 32 k, read
-// their B fragments and only then restart the matrix pipe.  Here a wave owns 160 x 128:
+// their B fragments and only then restart the matrix pipe.  Here a wave owns 16 NT_M x 128 outputs (NT_M = 10: 160 x 128):
 //   * 36 ds_read_b128 per 240 MFMAs (0.15 instead of 0.23 LDS fragment bytes per MFMA: under the socket power cap every LDS byte
-//     is clock), 320 accumulator registers = 256 AGPRs (row tiles 0-7) + 64 VGPRs (row tiles 8, 9) of the 512-register budget of a
-//     one-wave-per-SIMD kernel;
+//     is clock), 320 accumulator registers = 256 AGPRs (row tiles 0-7) + 64 VGPRs (the two tail row tiles) of the 512-register budget
+//     of a one-wave-per-SIMD kernel;
 //   * the compiler only allocates registers: every instruction of the k-loop is an `asm volatile` statement (MFMA with an explicit
 //     accumulator register class, ds_read_b128 with immediate offsets, counted s_waitcnt) or an LDS-DMA builtin between them, in
 //     program order - hipcc would otherwise shuttle accumulator tiles between the two register files (340 v_accvgpr moves per
 //     k-step, round 3) and drain the DMA queue in front of every LDS read it can see;
-//   * ONE barrier per 32-k step, placed after row tile 7 of 10, and nothing waits behind it: by then every A fragment of the step
-//     has been read (tiles 8 and 9 are fetched two tiles ahead into a 4-deep register ring), so the barrier both publishes the next
-//     stage (each wave waited for its own DMA pieces) and frees the current one.  The last two row tiles run column-pair-major, so
-//     the B fragments of a column pair are dead after 12 MFMAs and are re-loaded from the NEXT stage right there; the next step's
-//     first two A tiles are fetched at the head of this tail.  The matrix pipe never waits for an LDS round trip behind a barrier;
+//   * ONE barrier per 32-k step, placed in front of the last two row tiles, and nothing waits behind it: by then every A fragment of
+//     the step has been read (two tiles ahead, into a 4-deep register ring), so the barrier both publishes the next stage (each wave
+//     waited for its own DMA pieces) and frees the current one.  The last two row tiles run column-pair-major, so the B fragments of a
+//     column pair are dead after 12 MFMAs and are re-loaded from the NEXT stage right there; the next step's first two A tiles are
+//     fetched at the head of this tail.  The matrix pipe never waits for an LDS round trip behind a barrier: by in-kernel stamps a step
+//     of 240 MFMAs takes 4 300 cycles for 3 840 of matrix-pipe work (the bare one-wave MFMA stream: 4 080);
 //   * MFMAs on one accumulator are 8 apart (pass-major over the 8 column tiles of a row tile; 4 apart in the tail): a single wave
 //     has no partner to fill a dependent-accumulator wait (the first attempt, round 3: +44 % on the bare MFMA stream);
-//   * the 18 LDS-DMA pieces of the next stage go out during row tiles 0-4 (4,4,4,3,3), one between MFMAs, through a buffer
-//     descriptor: 18 loop-invariant 32-bit lane offsets + one scalar k offset (64-bit lane pointers spilled in round 3).
-// Stage layout, swizzle and fragment addressing are the 8-wave kernel's: row = [hi 32 | lo 32] bf16 = 128 B = 8 chunks of 16 B,
-// chunk c stored at slot c ^ ((row >> 1) & 7); A rows 0..319, then B rows 0..255; two stages = 147 456 B.
+//   * the LDS-DMA pieces of the next stage (NT_M + 8 per wave) go out one at a time between MFMAs of the early row tiles, through a
+//     buffer descriptor: loop-invariant 32-bit lane offsets + one scalar k offset (64-bit lane pointers spilled in round 3);
+//   * the epilogue stores straight from the registers: the MFMA gets the weight fragment as srcA (the tile comes out transposed: a lane
+//     holds columns of ONE row) and the weight rows are read in a permuted order with a swizzle of their own, so a lane owns 8
+//     consecutive columns per tile pair (no LDS transpose, no barrier; see the epilogue).
+// Instances: NT_M = 10 (320 x 256 tiles: the B = 32 layer shapes), 8 (256 x 256), 5 (160 x 256: N = 768 launches of the B = 16 shapes);
+// excel_launch_gemm_bf16x3 picks instance vs 8-wave tile by modelled time.
+// Stage layout: row = [hi 32 | lo 32] bf16 = 128 B = 8 chunks of 16 B; A rows (chunk c at slot c ^ ((row >> 1) & 7)), then the 256 B
+// rows (slot c ^ swz_b(row)); two stages.
 #include <stdlib.h>
 #include <type_traits>
 #include "common.h"
