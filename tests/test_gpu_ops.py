@@ -924,7 +924,7 @@ def _unsplit_f16(t):
     return f[:, :, 0, :].reshape(R, K), f[:, :, 1, :].reshape(R, K)
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 64, 512), (785, 2304, 768), (25120, 768, 768), (12560, 3072, 768)])
+@pytest.mark.parametrize("M,N,K", [(300, 64, 512), (785, 2304, 768), (25120, 768, 768), (12560, 3072, 768), (12560, 768, 768), (16400, 768, 768)])
 def test_gemm_f16x3(ops, M, N, K):
     """The split-plane building blocks with IEEE-half planes ("f16x3"): hi = half(x), lo = half(x - hi) exactly as numpy rounds them, and
     the three-MFMA product against float64 - 22 mantissa bits instead of bf16x3's 16: the bound is 16x tighter."""
@@ -946,7 +946,8 @@ def test_gemm_f16x3(ops, M, N, K):
     out2 = host(ops.gemm_bf16x3(As, Ws, bias=dev(bias), residual=dev(res), act=1, f16=True))
     assert maxabs(out2, y) < 5e-6 * scale + 4e-6
     hi2, lo2 = _unsplit_f16(host(ops.gemm_bf16x3(As, Ws, split_out=True, f16=True)))
-    assert np.array_equal(hi2, out.astype(np.float16).astype(np.float32))
+    h16 = out.astype(np.float16).astype(np.float32)
+    assert np.array_equal(hi2, h16) and np.array_equal(lo2, (out - h16).astype(np.float16).astype(np.float32))      # (four-wave kernel: split_pair)
 
 
 def test_split_f16_saturates_instead_of_overflowing(ops):
