@@ -207,6 +207,32 @@ def test_baseline_batch32_properties(gpu, b16_model):
         assert torch.equal(l1[0], labels[b])
 
 
+@pytest.mark.parametrize("B", [8, 16])
+def test_mid_batches_hit_every_gemm_instance_cam_vs_cpu_port(gpu, b16_model, golden, B):
+    """B = 8 / 16 @448x448 (M = 6 280 / 12 560 token rows: BASELINE configs[1]'s batch): the launcher runs these layers on the 160- and
+    256-row instances of the four-wave GEMM and on 8-wave tiles (B = 32 runs the 320-row instance, B = 1 the 128 x 128 tile) - every
+    epilogue mode of every instance inside the real ViT (head-major q|k|v scatter, split + QuickGELU, fp32 + residual).  The CAMs of the
+    first and the last image against the CPU port of the reference (torch-CPU ViT + numpy CAM, fp32), and BIT-identical to the same
+    image run alone: every instance accumulates an output element in the same k order."""
+    from oracle import torch_cpu
+    from excel_amd.tools import synthetic
+    model, sd, text = b16_model
+    cfg = VitConfig(width=768, layers=12, heads=12, patch=16, out_dim=512, input_resolution=224, n_surgery=5)
+    wo = oracle.vit.reload_self_attn({k: np.asarray(v) for k, v in sd.items()}, cfg, 28, "train")
+    text_attr = oracle.attr.attr_aggregate(text, golden("attr_bank_pascal_voc.npz")["bank"], 20)
+    ds = synthetic.SyntheticSegDataset(B, (448, 448), seed=4000 + B)
+    _, imgs, _, _ = ds.batch(range(B))
+    attr = model(dev(imgs))[2]
+    vit = torch_cpu.TorchVit(wo, cfg, 28)
+    for b in (0, B - 1):
+        x, _ = vit.forward(imgs[b])
+        f = x[None] / np.sqrt((x[None] * x[None]).sum(axis=1, keepdims=True, dtype=np.float32))
+        ref = oracle.cam.clip_feature_surgery(f.astype(np.float32), text_attr.T)[:, 1:, :20]
+        assert maxabs(host(attr[b]), ref[0]) < 1e-3                     # north-star gate (measured ~2e-5)
+        alone = model(dev(imgs[b:b + 1]))[2]
+        assert torch.equal(alone[0], attr[b])
+
+
 def test_ragged_batch32_full_size_properties(gpu, b16_model):
     """BASELINE configs[3]'s shape of work: ONE ragged batch of 32 images with VOC-like sizes (375x500, 500x375, 333x500 ... every image
     refined and scored at its own size, tools/infer_lam.py:74,94), ViT-B/16 at 448x448.  The oracle cannot finish this in seconds, so
