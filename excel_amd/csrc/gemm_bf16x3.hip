@@ -530,7 +530,12 @@ int excel_launch_gemm_bf16x3(const GemmBfArgs& p_in, hipStream_t stream) {
     // The four-wave kernel with the hand-placed k-loop (gemm_w4.hip) in its 320- / 256- / 160-row instance, whenever its preconditions
     // hold and its modelled launch time beats the best 8-wave tile's.  8-wave model: algorithmic flops over (tile fill x intrinsic
     // efficiency) x the 320 x 256 tile's measured rate at full fill (345 TFLOP/s fp32-equivalent at K = 768, 400 at K = 3072).
-    if (!no_w4 && nb == 1 && p.M >= 2048) {
+    bool w4_mode_ok = true;
+#ifdef EXCEL_DEV
+    { static const char* e = getenv("EXCEL_W4_MODES"); if (e) w4_mode_ok = (atoi(e) >> p.out_mode) & 1; }     // dev knob: bit per output mode (plain 1, qkv 2, split 4)
+    { static const char* e = getenv("EXCEL_W4_RES"); if (e && atoi(e) == 0 && p.res) w4_mode_ok = false; }      // dev knob: 0 = residual launches stay on the 8-wave kernel
+#endif
+    if (!no_w4 && w4_mode_ok && nb == 1 && p.M >= 2048) {
         static int n_cu3 = 0;
         if (!n_cu3) {
             int dev = 0; hipDeviceProp_t prop;

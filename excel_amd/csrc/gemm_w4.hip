@@ -306,7 +306,15 @@ __device__ __forceinline__ void gemm_w4_body(GemmBfArgs p) {
     // compiler's own accumulator reads (it cannot see that the asm statements above are MFMAs)
     // (the vmcnt(0) also retires the last step's spare fetch: no LDS-DMA may land after this workgroup has ended.  No barrier: the
     // epilogue does not touch LDS)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_nop 15\n s_nop 15" ::: "memory");
+    // The fragment registers are OPERANDS of this wait: the last step's tail issued ds_reads into them, and the compiler does not know that
+    // an asm ds_read completes asynchronously - with the registers dead behind the loop it handed one of them to the epilogue's lane-id
+    // computation ABOVE the wait, and the read landed on top of it (a garbage lane id -> wild bias / store addresses; timing dependent:
+    // it showed only when another kernel's waves shared the CU, i.e. with the 160- / 256-row instances on two streams).
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_nop 15\n s_nop 15"
+                 : "+v"(Ah[0]), "+v"(Ah[1]), "+v"(Ah[2]), "+v"(Ah[3]), "+v"(Al[0]), "+v"(Al[1]), "+v"(Al[2]), "+v"(Al[3]),
+                   "+v"(Bh[0]), "+v"(Bh[1]), "+v"(Bh[2]), "+v"(Bh[3]), "+v"(Bh[4]), "+v"(Bh[5]), "+v"(Bh[6]), "+v"(Bh[7]),
+                   "+v"(Bl[0]), "+v"(Bl[1]), "+v"(Bl[2]), "+v"(Bl[3]), "+v"(Bl[4]), "+v"(Bl[5]), "+v"(Bl[6]), "+v"(Bl[7])
+                 :: "memory");
     phase_stamp(2);
 
     if constexpr (DBG & 8) {        // the accumulators stay live through a store that never happens

@@ -13,6 +13,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "timeout: per-test limit in seconds (pytest-timeout when installed; a no-op marker otherwise)")
 
 
 def load_golden(name):

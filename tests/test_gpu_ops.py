@@ -811,6 +811,41 @@ def test_gemm_bf16x3_scalar_epilogue_big_tiles(ops, M, N, K):
     assert maxabs(out2, y) < tol
 
 
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("M,N,K", [(12560, 768, 768), (16400, 768, 768), (25120, 768, 768)])
+def test_gemm_bf16x3_with_neighbours_on_other_streams(ops, M, N, K):
+    """The four-wave GEMM instances (160- / 256- / 320-row tiles for these shapes) while ANOTHER kernel's waves share their CUs: the 160- and
+    256-row instances leave registers and LDS for a neighbour, and with one the timing of their LDS reads changes.  Round 5 found the
+    kernel's post-loop wait scheduled BEHIND the epilogue's lane-id computation - whose register was still the destination of an in-flight
+    ds_read: a garbage lane id and wild addresses, only under such a neighbour (memory fault in `bench.py --split 2`).  Two GEMM streams + a
+    LayerNorm stream, every result bit-identical to the serial launch."""
+    g = torch.Generator(device="cuda").manual_seed(M)
+    As = [ops.split_bf16(torch.randn(M, K, device="cuda", generator=g)) for _ in range(2)]
+    W = ops.split_bf16(torch.randn(N, K, device="cuda", generator=g) * 0.05)
+    bias = torch.randn(N, device="cuda", generator=g)
+    res = torch.randn(M, N, device="cuda", generator=g)
+    ref = [ops.gemm_bf16x3(a, W, bias=bias, residual=res, act=1) for a in As]
+    refs = [ops.gemm_bf16x3(a, W, bias=bias, split_out=True).clone() for a in As]
+    x = torch.randn(25120, 768, device="cuda", generator=g)
+    lw, lb = torch.ones(768, device="cuda"), torch.zeros(768, device="cuda")
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    for rep in range(3):
+        outs = [[], []]
+        for i in (0, 1):
+            with torch.cuda.stream(streams[i]):
+                for _ in range(6):
+                    outs[i].append(ops.gemm_bf16x3(As[i], W, bias=bias, residual=res, act=1))
+                    outs[i].append(ops.gemm_bf16x3(As[i], W, bias=bias, split_out=True))
+        with torch.cuda.stream(streams[2]):
+            for _ in range(16):
+                ops.layernorm(x, lw, lb)
+        torch.cuda.synchronize()
+        for i in (0, 1):
+            for j, o in enumerate(outs[i]):
+                assert torch.equal(o, refs[i] if j % 2 else ref[i]), (rep, i, j)
+
+
 @pytest.mark.parametrize("sharp", [1.6, 2.0])
 def test_vit_b16_448_clip_like_outlier_net(ops, sharp):
     """Full-size ViT-B/16 @448 on a CLIP-LIKE STRESS NET (oracle.vit.make_vit_weights(outliers=True): 3-6 massive-activation channels at

@@ -434,6 +434,26 @@ def test_split_batch_matches_single_stream(gpu, b16_model):
         assert np.array_equal(host(p2.hist), 2 * host(p1.hist))
 
 
+@pytest.mark.timeout(600)
+def test_split_batch32_two_streams_bit_identical(gpu, b16_model):
+    """`bench.py --split 2`: B = 32 as two concurrent B = 16 sub-batches on two streams - the sub-batches' GEMMs run on the 160- / 256-row
+    four-wave instances, which (unlike the 320-row one) share their CUs with the other stream's kernels.  Labels and histogram bit-identical
+    to the single-stream run (round 5: this faulted before the four-wave kernel's post-loop wait took its fragment registers as operands)."""
+    from excel_amd.pipeline import TrainingFreePipeline
+    from excel_amd.tools import synthetic
+    model = b16_model[0]
+    ds = synthetic.SyntheticSegDataset(32, (448, 448), num_classes=21, seed=555)
+    _, imgs, gts, cls = ds.batch(list(range(32)))
+    p1 = TrainingFreePipeline(model, num_classes=21, smax=ds.max_k())
+    ref = p1.run_batch(dev(imgs), dev(cls), dev(gts))
+    p2 = TrainingFreePipeline(model, num_classes=21, smax=ds.max_k())
+    for _ in range(3):
+        got = p2.run_batch_split(dev(imgs), dev(cls), dev(gts), nsplit=2)
+    p2.drain()
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref) and np.array_equal(host(p2.hist), 3 * host(p1.hist))
+
+
 # ------------------------------------------------------------------ SURVEY 8(f) rank 1: LVC branch (ex_feats, attn_pred, seg_attn)
 def test_feature_affinity_vs_golden_and_oracle(gpu, golden):
     from excel_amd import ops
