@@ -144,6 +144,15 @@ __device__ __forceinline__ void gemm_w4_body(GemmBfArgs p) {
         }
     };
     phase_stamp(0);
+#ifdef EXCEL_DEV
+    // dev experiment (EXCEL_W4_STAGGER = D us): the first round's workgroups start up to D us apart (8 phases per XCD), so that the
+    // epilogue store bursts of the 256 CUs no longer fall on top of each other for the rest of the launch
+    if (p.dbg > 0 && blockIdx.x < 256) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();                                  // 100 MHz
+        const unsigned long long ticks = (unsigned long long)((blockIdx.x >> 3) & 7) * (unsigned)p.dbg * 100ull / 8ull;
+        while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+    }
+#endif
     const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     const int tm = id / tiles_n, tn = id - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
@@ -486,9 +495,12 @@ W4_KERNEL(10, 15) W4_KERNEL(10, 24) W4_KERNEL(10, 32) W4_KERNEL(10, 136) W4_KERN
 #endif
 #define W4_LAUNCH(NT, DBG) hipLaunchKernelGGL(gemm_w4_kernel_##NT##_##DBG, grid, dim3(256), 0, stream, p)
 
-static void launch_w4(const GemmBfArgs& p, int nt_m, hipStream_t stream) {
+static void launch_w4(const GemmBfArgs& p_in, int nt_m, hipStream_t stream) {
+    GemmBfArgs p = p_in;
     const dim3 grid(cdiv(p.M, 32 * nt_m) * cdiv(p.N, w4::BN));
 #ifdef EXCEL_DEV
+    static const int stagger = getenv("EXCEL_W4_STAGGER") ? atoi(getenv("EXCEL_W4_STAGGER")) : 0;
+    p.dbg = (stagger > 0 && (int)grid.x > 320) ? stagger : 0;      // multi-round launches only
     static const int dbg = getenv("EXCEL_W4_DBG") ? atoi(getenv("EXCEL_W4_DBG")) : 0;
     if (nt_m == 10) {
         switch (dbg) {

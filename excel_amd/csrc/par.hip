@@ -27,6 +27,9 @@ struct ParDil {
 };
 
 #define PAR_LOG2E_3 0.48089834696298783f      // log2(e) / 3
+#ifndef PAR_MASK_DEPTH
+#define PAR_MASK_DEPTH 1                       // tap rows in flight in the mask phase of par_iterate_guide_kernel
+#endif
 
 // COMPACT: instead of the 48 affinity planes write the 5 per-pixel statistics they are a function of,
 //   stats[0..2] = k2_c = log2(e)/3 / ((std_c + 1e-8) w1)^2,   stats[3] = m (max of the 48 base-2 exponents),   stats[4] = 1 / sum 2^(z - m)
@@ -274,29 +277,32 @@ __global__ __launch_bounds__(512, 4) void par_iterate_guide_kernel(const float* 
     // 3 (2 for the centre row) ds_read_b64 from `base` = the thread's tile origin in the plane's buffer; row g+1 is issued before
     // row g is consumed.  d = 1 reads the aligned pairs around the pixel pair and shifts.
     const unsigned org = tile_b + (ty * TP + 2 * tx) * 4;
-    auto taps = [&](int buf, auto&& fn, auto&& pin) {
+    // DEPTH = tap rows in flight behind the one being consumed.  The guide phase (24 VALU per row) runs at 1; the mask phase has 3 fused
+    // multiply-adds per row against an LDS round trip per row, so it keeps DEPTH rows ahead (a ring of DEPTH + 1 register rows)
+    auto taps = [&](auto depth_c, int buf, auto&& fn, auto&& pin) {
+        constexpr int DEPTH = decltype(depth_c)::value, NS = DEPTH + 1;
         unsigned base = org + buf * (TR * TP * 4);
         asm volatile("" : "+v"(base));
-        f32x2 sl[2][3];
+        f32x2 sl[NS][3];
+        auto nreads = [](int G) constexpr { return (G % 3 != 1 || G / 3 == 0) ? 3 : 2; };          // the centre row of a dilation > 1 has no middle read
         auto issue = [&](auto g) {
-            constexpr int G = decltype(g)::value, r = G % 3, d = ParD<G / 3>::v, s = G & 1;
+            constexpr int G = decltype(g)::value, r = G % 3, d = ParD<G / 3>::v, s = G % NS;
             constexpr int row = (HALO + (r - 1) * d) * TP * 4, cl = (d == 1) ? HALO - 2 : HALO - d, cr = (d == 1) ? HALO + 2 : HALO + d;
             sl[s][0] = lds_read8_imm<row + cl * 4>(base);
             if constexpr (r != 1 || d == 1) sl[s][1] = lds_read8_imm<row + HALO * 4>(base);
             sl[s][2] = lds_read8_imm<row + cr * 4>(base);
         };
-        issue(std::integral_constant<int, 0>{});
+        static_for<DEPTH>([&](auto g) { issue(g); });
         static_for<NG>([&](auto g) {
-            constexpr int G = decltype(g)::value, di = G / 3, r = G % 3, d = ParD<di>::v, s = G & 1;
+            constexpr int G = decltype(g)::value, di = G / 3, r = G % 3, d = ParD<di>::v, s = G % NS;
             constexpr bool mid = (r != 1 || d == 1);
-            if constexpr (G + 1 < NG) {
-                issue(std::integral_constant<int, G + 1>{});
-                constexpr int nxt = ((G + 1) % 3 != 1 || ParD<(G + 1) / 3>::v == 1) ? 3 : 2;      // reads of row g+1 may stay in flight
-                if constexpr (mid) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(sl[s][0]), "+v"(sl[s][1]), "+v"(sl[s][2]) : "n"(nxt) : "memory");
-                else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(sl[s][0]), "+v"(sl[s][2]) : "n"(nxt) : "memory");
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sl[s][0]), "+v"(sl[s][1]), "+v"(sl[s][2])::"memory");
-            }
+            if constexpr (G + DEPTH < NG) issue(std::integral_constant<int, G + DEPTH>{});
+            // reads issued behind row G's: rows G+1 .. min(G + DEPTH, NG - 1) may stay in flight
+            constexpr int last = (G + DEPTH < NG) ? G + DEPTH : NG - 1;
+            constexpr int nxt = [&]() constexpr { int n = 0; for (int q = G + 1; q <= last; ++q) n += nreads(q); return n; }();
+            static_assert(nxt <= 15, "lgkmcnt is a 4-bit counter");
+            if constexpr (mid) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(sl[s][0]), "+v"(sl[s][1]), "+v"(sl[s][2]) : "n"(nxt) : "memory");
+            else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(sl[s][0]), "+v"(sl[s][2]) : "n"(nxt) : "memory");
             constexpr int k0 = (r == 0) ? 0 : (r == 1 ? 3 : 5);
             const f32x2 L = sl[s][0], R = sl[s][2];
             if constexpr (d == 1) {
@@ -309,7 +315,7 @@ __global__ __launch_bounds__(512, 4) void par_iterate_guide_kernel(const float* 
                 if constexpr (r != 1) fn(di, k0 + 1, sl[s][1]);
                 fn(di, k0 + (r != 1 ? 2 : 1), R);
             }
-            pin();                                               // row g is consumed HERE, between the reads of rows g+1 and g+2
+            pin();                                               // row g is consumed HERE, between the reads of the rows behind it
             __builtin_amdgcn_sched_barrier(0);
         });
     };
@@ -329,31 +335,45 @@ __global__ __launch_bounds__(512, 4) void par_iterate_guide_kernel(const float* 
         return sum;
     };
     const int np = 3 + nch;
+    // The per-pixel statistics (k2_r, k2_g, k2_b, m, 1/sum) come in ONE PLANE AHEAD, issued in front of the LDS-DMA pieces of the next plane:
+    // vmcnt retires in order, so a load issued behind those pieces - where the value is needed - made its own wait a wait for the whole
+    // next plane, and the plane pipeline did not overlap with the taps at all (round 5, read off the disassembly: `global_load` of k2,
+    // then `s_waitcnt vmcnt(0)` in the first tap row).  Issued here, it is covered by the wait the plane barrier needs anyway.  The
+    // loads stay compiler-visible (an asm load whose result is still in flight gets copied / its register reused above the wait: tried,
+    // memory fault); a schedule barrier keeps them in front of the DMA builtins.
+    auto stat_load = [&](int plane) -> f32x2 { return *reinterpret_cast<const f32x2*>(st_b + (long long)plane * HW); };
+    f32x2 st_nxt = stat_load(0), st_nx2 = f32x2{0.f, 0.f};
+    __builtin_amdgcn_sched_barrier(0);
     stage(0, 0);
 #pragma unroll 1
     for (int p = 0; p < 3; ++p) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's pieces of plane p have landed
+        // this wave's pieces of plane p and its statistics have landed.  (The statistics pass through the wait as an operand: the compiler
+        // then waits for them HERE - its own count at the first use knows nothing of the DMA pieces issued in between: vmcnt(1), measured)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(st_nxt) :: "memory");
         __builtin_amdgcn_s_barrier();                                // ... everyone's have, and everyone is done with plane p-1's buffer
+        const f32x2 nk2 = -st_nxt;
+        st_nxt = stat_load(p + 1);                                   // k2 of the next guide plane; behind plane 2: m
+        if (p == 2) st_nx2 = stat_load(4);                           //                                             and 1 / sum
+        __builtin_amdgcn_sched_barrier(0);
         stage(p + 1, (p + 1) & 1);                                   // (np >= 4) streams in behind the taps below
         if (EXCEL_DBG(dbg) & 1) continue;
         // guide channel p:  z_t += -(I_nb - I)^2 k2_p   as fma(dv dv, -k2, z), dv = nb + (-ctr): bit-identical to the affinity kernel.
         // (-ctr is opaque: the compiler otherwise folds the negation back and emits two unpacked v_sub_f32 instead of one v_pk_add_f32)
-        const f32x2 nk2 = -*reinterpret_cast<const f32x2*>(st_b + (long long)p * HW);
         f32x2 ctr;
         asm volatile("ds_read_b64 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(ctr) : "v"(org + (p & 1) * (TR * TP * 4)), "n"((HALO * TP + HALO) * 4) : "memory");
         f32x2 nctr = -ctr;
         if (EXCEL_DBG(dbg) & 16) nctr += 1e-30f * far_taps(guide + 3 * tg.base + (long long)p * HW);
         asm volatile("" : "+v"(nctr));
-        taps(p & 1, [&](int di, int k, const f32x2 nb) {
+        taps(std::integral_constant<int, 1>{}, p & 1, [&](int di, int k, const f32x2 nb) {
             const f32x2 dv = nb + nctr;
             wall[di][k] = __builtin_elementwise_fma(dv * dv, nk2, wall[di][k]);
         }, [] {});
     }
     if (!(EXCEL_DBG(dbg) & 2)) {
         // aff_t = 2^(z_t - m) / sum + pos_t : the affinity kernel's operations, one rounding each (z + (-m) == z - m)
-        f32x2 nm2 = -*reinterpret_cast<const f32x2*>(st_b + 3 * HW);
+        f32x2 nm2 = -st_nxt;                                         // (plane 3's pieces had the taps of plane 2 to land)
         asm volatile("" : "+v"(nm2));
-        const f32x2 is2 = *reinterpret_cast<const f32x2*>(st_b + 4 * HW);
+        const f32x2 is2 = st_nx2;
 #pragma unroll
         for (int di = 0; di < ND; ++di)
 #pragma unroll
@@ -366,8 +386,16 @@ __global__ __launch_bounds__(512, 4) void par_iterate_guide_kernel(const float* 
     }
     const bool valid = px < W && py < H;
     float* out_px = out + (long long)Cmax * tg.base + (long long)py * Wp + px;
+    // behind the first mask plane the newest vmcnt event in front of a plane barrier is the previous plane's output store (one per wave,
+    // if any of its lanes is inside the image): the pieces of plane p are older, so `vmcnt(1)` has them landed and leaves the store in
+    // flight instead of waiting out its round trip at every plane
+#ifndef PAR_STORE_WAIT
+#define PAR_STORE_WAIT 1
+#endif
+    const bool wstore = PAR_STORE_WAIT && __builtin_amdgcn_ballot_w64(valid) != 0 && !EXCEL_DBG(dbg);
     for (int p = 3; p < np; ++p) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (p > 3 && wstore) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (p + 1 < np) stage(p + 1, (p + 1) & 1);
         if (EXCEL_DBG(dbg) & 4) continue;
@@ -375,7 +403,7 @@ __global__ __launch_bounds__(512, 4) void par_iterate_guide_kernel(const float* 
         if (EXCEL_DBG(dbg) & 16) acc = 1e-30f * far_taps(in + (long long)Cmax * tg.base + (long long)(p - 3) * HW);
         // (acc is pinned per tap row: it is only stored under `valid`, and the whole fma chain was otherwise sunk into that branch,
         //  behind all 50 reads of the plane)
-        taps(p & 1, [&](int di, int k, const f32x2 nb) { acc = __builtin_elementwise_fma(nb, wall[di][k], acc); },   // tap order, fused
+        taps(std::integral_constant<int, PAR_MASK_DEPTH>{}, p & 1, [&](int di, int k, const f32x2 nb) { acc = __builtin_elementwise_fma(nb, wall[di][k], acc); },   // tap order, fused
              [&] { asm volatile("" : "+v"(acc)); });
         if (valid) *reinterpret_cast<f32x2*>(out_px + (long long)(p - 3) * HW) = acc;
     }
