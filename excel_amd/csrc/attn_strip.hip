@@ -46,6 +46,7 @@ struct StripArgs {
     int aff_init;         // 1: w_aff = ..., 0: w_aff += ...
     int surgery;          // 1: sweep A + sweep W, 0: sweep W only
     int split_c;          // > 0: the two sweeps of a strip are separate workgroups, split_c strips per XCD (see the launcher)
+    const float2* wstats; // [B,H,4,N] {row max (log2 units), 1 / row sum} of q.k from the flash row pass (type 0 slots): required by the W sweep
 };
 
 // VAR (round 4; bit set = on; STRIP_VAR is what ships):
@@ -161,6 +162,21 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_bptr)(unsigned long long)(xb + pi * 1024), 16, voff[pi & 3], soff + (pi >> 2) * 4096, 0, 0);
     };
 
+    // Known row statistics (W sweep, round 5): the flash row pass of the same layer has already reduced every q.k row (it needs max and
+    // sum for the attention output) and left {M, 1/L} in `wstats`.  With them a W phase needs no running maximum, no rescale, no
+    // per-tile reference, no exchange of (m, l) between the waves and no deferred fold: p = 2^(s c2 - M) goes into the accumulators as
+    // acc += p / L right behind the tile's MFMAs.  The 32 pairs of a phase (256 B) ride with the query strip: one 4-byte-per-lane LDS-DMA
+    // instruction of the wave that issues the fewest strip pieces, into the (otherwise unused) exchange slot of the phase's parity.
+    const __amdgpu_buffer_rsrc_t rsrc_st = __builtin_amdgcn_make_buffer_rsrc((void*)(p.wstats ? p.wstats + (long long)b * H * 4 * N : nullptr), 0,
+                                                                             p.wstats ? H * 4 * N * 8 : 0, 0x00020000);
+    auto issue_st = [&](int t, int par) {
+        if (wave != nw - 1) return;
+        const int h = t - 3 * H;
+        unsigned sb = lstat_addr + par * (8 * 32 * 8);
+        asm volatile("" : "+s"(sb));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_st, (lds_bptr)(unsigned long long)sb, 4, lane * 4, ((h * 4) * N + q0) * 8, 0, 0);
+    };
+
     // VAR bit 1: static cursor.  While tile j of phase t is multiplied, the tile two ahead in the stream goes out: (t, j + 2) if the wave
     // has that many tiles, else (t + 1, j + 2 - cnt); poff_cur / poff_nxt are the plane offsets of phases t and min(t + 1, t1 - 1).
     int poff_cur = 0, poff_nxt = 0;
@@ -185,14 +201,17 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
     // merge, every wave publishes (m, l) and the factor of tile j becomes 2^(m_j - M) / L with the global M, L: exact, single pass.
     // Measured (profiles/): the waves of a strip run in lock step and are bound by their own in-order instruction streams, so the
     // VALU work is written with packed fp32 operations (v_pk_fma_f32, v_pk_add_f32) and the statistics exchange is one LDS batch.
-    auto run_sweep = [&](int t0, int t1) {
+    auto run_sweep = [&](int t0, int t1, auto known_c) {
+        constexpr bool KNOWN = decltype(known_c)::value;           // row statistics come from `wstats` (W sweep behind the flash row pass)
 #pragma unroll
         for (int j = 0; j < NTW; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
         it_t = t0; it_j = 0; it_g = 0; it_t1 = t1; it_poff = plane_off(t0, false);
         issue_x(t0, 0);
+        if constexpr (KNOWN) issue_st(t0, 0);
         issue_x(min(t0 + 1, t1 - 1), 1);
+        if constexpr (KNOWN) issue_st(min(t0 + 1, t1 - 1), 1);
         issue_next();
         issue_next();
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");         // both query strips landed (the two key tiles may be in flight)
@@ -264,10 +283,30 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
                 }
                 lds_wait8(xh, xl);
             }
+            // known statistics of this phase's rows: {M, 1/L} of query row r
+            f32x2 nm2 = {0.f, 0.f}, li2 = {0.f, 0.f};
+            if constexpr (KNOWN) {
+                float2 st = lds_read8(lstat_addr + par * (8 * 32 * 8) + r * 8);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(st)::"memory");
+                nm2 = f32x2{-st.x, -st.x};
+                li2 = f32x2{st.y, st.y};
+            }
             if (pending && !late_f) apply_phase(t - 1);            // early F: before tile 0
             // finite "minus infinity": a lane whose 16 keys of the (ragged) last tile are all padding must not form (-inf) - (-inf)
             float m_run = -1e30f, l_run = 0.f;
-            auto softmax_tile = [&](int j) {
+            auto softmax_tile = [&](int j) __attribute__((always_inline)) {
+                if constexpr (KNOWN) {                             // acc += 2^(s c2 - M) / L, nothing carried
+                    const f32x2 c22 = {c2, c2};
+#pragma unroll
+                    for (int e = 0; e < 16; e += 2) {
+                        const f32x2 a = __builtin_elementwise_fma(f32x2{s[j][e], s[j][e + 1]}, c22, nm2);
+                        const f32x2 pe = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+                        const f32x2 o = __builtin_elementwise_fma(pe, li2, f32x2{acc[j][e], acc[j][e + 1]});
+                        acc[j][e] = o[0];
+                        acc[j][e + 1] = o[1];
+                    }
+                    return;
+                }
                 float tm;
                 if constexpr ((VAR & 2) != 0) {
                     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tm) : "v"(s[j][0]), "v"(s[j][1]), "v"(s[j][2]));
@@ -299,7 +338,11 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
             {
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) {
-                    if (j < NTW - 1 || full) {
+                    // (one call site per tile index for the softmax: `full ? tile NTW-1 : tile NTW-2` behind the loop let the optimiser
+                    //  fold the two sites into one body with a run-time tile index - and the accumulators went to scratch)
+                    const bool have = j < NTW - 1 || full;
+                    f32x16 sj;
+                    if (have) {
                         if constexpr ((VAR & 1) == 0) {
                             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                    // tile gc landed (gc+1 may be in flight)
                             const unsigned kr = ring_addr + ((gc & 1) * TILE_EL + r * 128) * 2;
@@ -313,7 +356,6 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
                         const unsigned kn = ring_addr + (((gc + 1) & 1) * TILE_EL + r * 128) * 2;  // (VAR bit 0) the next tile of the stream
                         if ((DBG & 1) && !(DBG & 2)) issue_next();                              // tile gc+2 -> this slot
                         ++gc;
-                        f32x16 sj;
     #pragma unroll
                         for (int e = 0; e < 16; ++e) sj[e] = 0.f;
                         if (!(DBG & 1)) {
@@ -336,9 +378,16 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
                         } else {
                             sj[0] = (float)yl[0][0] + (float)yh[3][1] + (float)xh[0][0] + (float)xl[3][1];
                         }
-                        if (NTW < 5) {                                                          // (at 5 tiles per wave the register file has no room for the overlap)
-                            if (j > 0 && !(DBG & 4)) softmax_tile(j - 1);                       // in the shadow of these MFMAs
+                        if constexpr (!KNOWN) {
+                            if (NTW < 5) {                                                      // (at 5 tiles per wave the register file has no room for the overlap)
+                                if (j > 0 && !(DBG & 4)) softmax_tile(j - 1);                   // in the shadow of these MFMAs
+                            }
                         }
+                    }
+                    if constexpr (KNOWN) {                                                      // (a wave without tile NTW-1 folds its last tile here)
+                        if (NTW < 5 && j > 0 && !(DBG & 4)) softmax_tile(j - 1);
+                    }
+                    if (have) {
                         if (ragged && first + j == last_tile) {                                 // wave-uniform: keys >= N only here
                             int lim = nvalid_last;                    // opaque: the 16 lane masks must not be hoisted into (spilled) SGPR pairs
                             asm volatile("" : "+v"(lim));
@@ -354,7 +403,7 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
             if (!(DBG & 4)) {
                 if (NTW < 5) {
                     if (full) softmax_tile(NTW - 1);
-                    else if (NTW > 1) softmax_tile(NTW > 1 ? NTW - 2 : 0);
+                    else if constexpr (!KNOWN) { if (NTW > 1) softmax_tile(NTW > 1 ? NTW - 2 : 0); }     // (KNOWN: folded inside the loop)
                 } else {
 #pragma unroll
                     for (int j = 0; j < NTW; ++j)
@@ -366,7 +415,7 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
                 for (int j = 0; j < NTW; ++j) mref[j] = 0.f;
             }
             // the two lane halves of a query row merge their (m, l); one entry per wave goes to the exchange
-            {
+            if constexpr (!KNOWN) {
                 float m_a, m_b, l_a, l_b;                     // (a: lanes 0..31, b: lanes 32..63 - in every lane, no LDS round trip)
                 wave_halves(m_run, m_a, m_b);
                 wave_halves(l_run, l_a, l_b);
@@ -375,12 +424,13 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
                 m_run = m_w;
             }
             const unsigned ls = lstat_addr + (t & 1) * (8 * 32 * 8);
-            if (kh == 0) lds_write8(ls + (wave * 32 + r) * 8, make_float2(m_run, l_run));
+            if (!KNOWN && kh == 0) lds_write8(ls + (wave * 32 + r) * 8, make_float2(m_run, l_run));
             // the query strip of phase t+1 (issued one phase ago) must have landed before the barrier publishes it
             asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");                    // (a key tile was issued after it)
             __builtin_amdgcn_s_barrier();                                                   // raw: no vmcnt(0) drain of the tile stream
             if (!(DBG & 2)) issue_x(min(t + 2, t1 - 1), par);                               // slot of phase t: every wave has its fragments
-            if (NTW < 5) pending = true;                                                    // F(t) runs inside phase t+1 (or after the loop)
+            if constexpr (KNOWN) { if (!(DBG & 2)) issue_st(min(t + 2, t1 - 1), par); }     // (its statistics have been read as well)
+            else if (NTW < 5) pending = true;                                               // F(t) runs inside phase t+1 (or after the loop)
             else apply_phase(t);                                                            // (5 tiles per wave: no registers to carry a phase)
         }
         if (pending) apply_phase(t1 - 1);
@@ -397,7 +447,7 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
     };
 
     if (p.surgery && part != 2) {
-        run_sweep(0, 3 * H);
+        run_sweep(0, 3 * H, std::false_type{});
         // A_sum: split-bf16 rows; one 32-key tile = one 128-B block [hi 32 | lo 32]
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
@@ -437,7 +487,7 @@ __global__ __launch_bounds__(512) void attn_strip_kernel(StripArgs p) {
     }
 
     if ((p.w_aff || p.attn_out) && part != 1) {
-        run_sweep(3 * H, 4 * H);
+        run_sweep(3 * H, 4 * H, std::true_type{});              // (the launcher insists on wstats: a third copy of the sweep for the exchange form spills)
         const long long P = N - 1;
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
@@ -469,17 +519,18 @@ bool excel_attn_strip_supported(int N) { return cdiv(N, 32) <= 40; }       // 8 
 
 int excel_launch_attn_strip(const unsigned short* qkvs, unsigned short* a_sum, float* w_aff, float* attn_out, int B, int H, int N,
                             int KP, int hd, float scale, int surgery, float w_scale, float aff_scale, int aff_init, const float* ex_attn,
-                            hipStream_t st) {
+                            hipStream_t st, const float* wstats) {
     EXCEL_CHECK_ARG(hd == 64, "attention: head_dim must be 64 (got %d)", hd);
     EXCEL_CHECK_ARG(qkvs && (!surgery || (a_sum && KP == cdiv(N, 32) * 32)), "attn_strip: bad a_sum/KP");
     const int ntiles = cdiv(N, 32);
+    EXCEL_CHECK_ARG(wstats || !(w_aff || attn_out), "attn_strip: the W sweep needs the flash row pass's q.k row statistics (wstats)");
     EXCEL_CHECK_ARG(excel_attn_strip_supported(N), "attn_strip: N=%d exceeds the strip-resident envelope (ask excel_attn_strip_supported)", N);
     ProfScope prof__(PROF_ATTN_ACCUM, st);
     const int ntw = cdiv(ntiles, 8);
     const int nw = cdiv(ntiles, ntw);                          // 25 tiles: 7 waves x (4,4,4,4,3,3,3)
     EXCEL_CHECK_ARG(ntiles / nw >= ntw - 1 && (long long)3 * H * N * 256 < (1LL << 31), "attn_strip: unsupported shape");
     StripArgs a{qkvs, a_sum, w_aff, attn_out, surgery ? ex_attn : nullptr, B, H, N, KP, ntiles, cdiv(N, 32), scale, w_scale, aff_scale, (float)H,
-                aff_init, surgery, 0};
+                aff_init, surgery, 0, reinterpret_cast<const float2*>(wstats)};
     // Both sweeps wanted: one workgroup per (strip, sweep).  A strip workgroup fills a CU (148 KB LDS), so B x nstrips = 800 uniform
     // workgroups on 256 CUs are 3.125 rounds = 4 rounds of 4H phases; split, the 3H-phase workgroups go first and the H-phase ones
     // level the tail: 150-156 phase-times per CU instead of 192.

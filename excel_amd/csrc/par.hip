@@ -232,7 +232,11 @@ __global__ __launch_bounds__(512, 4) void par_iterate_guide_kernel(const float* 
     const int xoffA = min(max(x0 - HALO + lane, 0), W - 1) * 4, xoffB = min(max(x0 - HALO + 64 + lane, 0), W - 1) * 4;   // replicate padding in x
     const unsigned tile_b = lds_addr(tile);
     constexpr int RPW = TR / 8;                                  // rows per wave
+#ifdef PAR_ALL_INTERIOR      // timing-only build (tools_dev): every tile takes the 16-byte path - what padded planes would buy the 2 of 7 border tiles of a 448-wide row
+    const bool interior = true;
+#else
     const bool interior = x0 - HALO >= 0 && x0 + 64 + HALO <= W;
+#endif
     const int x4off = min(x0 - HALO + 4 * (lane & 31), Wp - 4) * 4;         // (columns >= 64 + 2 HALO of the 128-float row are never read)
     auto stage = [&](int p, int buf) {                           // plane p of the sequence [guide 0..2, mask 0..nch-1] -> buffer buf
         const bool is_g = p < 3;
@@ -354,13 +358,15 @@ __global__ __launch_bounds__(512, 4) void par_iterate_guide_kernel(const float* 
         const f32x2 nk2 = -st_nxt;
         st_nxt = stat_load(p + 1);                                   // k2 of the next guide plane; behind plane 2: m
         if (p == 2) st_nx2 = stat_load(4);                           //                                             and 1 / sum
+        // the centre pixel pair is read in front of the DMA issue (its LDS round trip passes in the shadow of the four pieces)
+        f32x2 ctr;
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(ctr) : "v"(org + (p & 1) * (TR * TP * 4)), "n"((HALO * TP + HALO) * 4) : "memory");
         __builtin_amdgcn_sched_barrier(0);
         stage(p + 1, (p + 1) & 1);                                   // (np >= 4) streams in behind the taps below
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ctr) :: "memory");
         if (EXCEL_DBG(dbg) & 1) continue;
         // guide channel p:  z_t += -(I_nb - I)^2 k2_p   as fma(dv dv, -k2, z), dv = nb + (-ctr): bit-identical to the affinity kernel.
         // (-ctr is opaque: the compiler otherwise folds the negation back and emits two unpacked v_sub_f32 instead of one v_pk_add_f32)
-        f32x2 ctr;
-        asm volatile("ds_read_b64 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(ctr) : "v"(org + (p & 1) * (TR * TP * 4)), "n"((HALO * TP + HALO) * 4) : "memory");
         f32x2 nctr = -ctr;
         if (EXCEL_DBG(dbg) & 16) nctr += 1e-30f * far_taps(guide + 3 * tg.base + (long long)p * HW);
         asm volatile("" : "+v"(nctr));
