@@ -353,8 +353,9 @@ __device__ __forceinline__ void gemm_w4_body(GemmBfArgs p) {
     });
     // one specialised copy per output mode (a run-time mode inside the row loop keeps the store addresses of all three modes live at once
     // and spills)
-    auto epilogue = [&](auto MODEc) {
+    auto epilogue = [&](auto MODEc, auto RESc) {
         constexpr int MODE = decltype(MODEc)::value;
+        constexpr bool RES = decltype(RESc)::value;            // residual launches get their own copy (plain output only): the prefetch below is unconditional there
         // head-major q|k|v scatter: the 8 columns of a pair stay inside one head (hd % 8 == 0): per pair the offset of (type, head, d)
         int qoff[NT_N / 2];                                          // (row indices of the [B,3,H,tokN] planes: < 2^31 rows)
         int qdd[NT_N / 2];
@@ -368,8 +369,24 @@ __device__ __forceinline__ void gemm_w4_body(GemmBfArgs p) {
                 qoff[jp] = (qt * p.heads + qh) * p.tokN;      // + b * 3 * heads * tokN + n  -> row index of the [.., tokN, hd] planes
             });
         }
+        // The residual rows of row tile i+1 are requested as soon as those of tile i have been added - IN FRONT of tile i's stores (one
+        // register set).  vmcnt retires in order: residual loads issued behind the previous row tile's stores, where they are used, made
+        // every row tile wait for those stores to retire and then for its own loads - ten serial round trips per tile (round 5, read off the
+        // disassembly: 8 loads, vmcnt(7..0), 8-16 stores, 8 loads, ...).
+        f32x4 rs[NT_N];
+        auto load_res = [&](auto I2c) {
+            constexpr int i2 = (decltype(I2c)::value + MAIN) % NT_M;
+            const int row2 = min(m0 + wm * WTM + 16 * i2 + r16e, p.M - 1);
+            sfor<0, NT_N>([&](auto Jc) {
+                constexpr int j = decltype(Jc)::value;
+                const int c = min(colw + 32 * (j >> 1) + 4 * (j & 1), p.N - 4);
+                rs[j] = *reinterpret_cast<const f32x4*>(p.res + (long long)row2 * p.ldr + c);
+            });
+        };
+        if constexpr (RES) load_res(IC<0>{});
         sfor<0, NT_M>([&](auto Ic) {
-            constexpr int i = (decltype(Ic)::value + MAIN) % NT_M;       // the tail row tiles first: their accumulators occupy 64 VGPRs
+            constexpr int I = decltype(Ic)::value;
+            constexpr int i = (I + MAIN) % NT_M;       // the tail row tiles first: their accumulators occupy 64 VGPRs
             const int row = m0 + wm * WTM + 16 * i + r16e;
             const bool row_ok = row < p.M;
             const int rowc = row_ok ? row : p.M - 1;
@@ -380,13 +397,7 @@ __device__ __forceinline__ void gemm_w4_body(GemmBfArgs p) {
                 asm volatile("" : "+v"(v[j]));        // a clean AGPR -> VGPR copy point (left alone, the allocator splits the tiles into
                                                       // 64-bit halves for packed adds and permutes 200 AGPRs at the loop exit)
             });
-            if (p.res) {
-                f32x4 rs[NT_N];
-                sfor<0, NT_N>([&](auto Jc) {
-                    constexpr int j = decltype(Jc)::value;
-                    const int c = min(colw + 32 * (j >> 1) + 4 * (j & 1), p.N - 4);
-                    rs[j] = *reinterpret_cast<const f32x4*>(p.res + (long long)rowc * p.ldr + c);
-                });
+            if constexpr (RES) {
                 sfor<0, NT_N>([&](auto Jc) { constexpr int j = decltype(Jc)::value; v[j] += bias4[j]; });
                 if (p.act == GEMM_ACT_QUICKGELU)
                     sfor<0, NT_N>([&](auto Jc) {
@@ -395,6 +406,11 @@ __device__ __forceinline__ void gemm_w4_body(GemmBfArgs p) {
                         for (int q = 0; q < 4; ++q) v[j][q] = v[j][q] * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v[j][q]));
                     });
                 sfor<0, NT_N>([&](auto Jc) { constexpr int j = decltype(Jc)::value; v[j] += rs[j]; });
+                if constexpr (I + 1 < NT_M) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_res(IC<I + 1>{});
+                    __builtin_amdgcn_sched_barrier(0);              // ... in front of this row tile's stores
+                }
             } else {
                 sfor<0, NT_N>([&](auto Jc) { constexpr int j = decltype(Jc)::value; v[j] += bias4[j]; });
                 if (p.act == GEMM_ACT_QUICKGELU)
@@ -461,9 +477,10 @@ __device__ __forceinline__ void gemm_w4_body(GemmBfArgs p) {
             __builtin_amdgcn_sched_barrier(0);      // one row tile at a time: hoisting the next tiles' accumulator reads and residual loads spills
         });
     };
-    if (p.out_mode == GEMM_OUT_SPLIT_BF16) epilogue(IC<GEMM_OUT_SPLIT_BF16>{});
-    else if (p.out_mode == GEMM_OUT_QKV_HEADMAJOR) epilogue(IC<GEMM_OUT_QKV_HEADMAJOR>{});
-    else epilogue(IC<GEMM_OUT_PLAIN>{});
+    if (p.out_mode == GEMM_OUT_SPLIT_BF16) epilogue(IC<GEMM_OUT_SPLIT_BF16>{}, std::false_type{});
+    else if (p.out_mode == GEMM_OUT_QKV_HEADMAJOR) epilogue(IC<GEMM_OUT_QKV_HEADMAJOR>{}, std::false_type{});
+    else if (p.res) epilogue(IC<GEMM_OUT_PLAIN>{}, std::true_type{});
+    else epilogue(IC<GEMM_OUT_PLAIN>{}, std::false_type{});
     if constexpr (DBG & 128) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); phase_stamp(3); }
 }
 
@@ -471,6 +488,7 @@ __device__ __forceinline__ void gemm_w4_body(GemmBfArgs p) {
 bool excel_gemm_w4_supported(const GemmBfArgs& p, int nt_m) {
     const bool vec = (p.N & 3) == 0 && p.N >= 8 && (p.ldc & 3) == 0 && (p.ldr & 3) == 0 && (p.hd & 7) == 0;
     const int kq = 32 * ((nt_m & 1) ? 4 : 2);          // the k-loop is unrolled over 2 (4) steps of 32
+    if (p.res && p.out_mode != GEMM_OUT_PLAIN) return false;      // the residual epilogue exists for the plain output only (all the path uses); else the 8-wave kernel
     return (nt_m == 10 || nt_m == 8 || nt_m == 5) && vec && p.batch <= 1 && p.K >= kq && (p.K % kq) == 0 &&
            (long long)p.M * p.lda * 2 < 0x7fffffffLL && (long long)p.N * p.ldb * 2 < 0x7fffffffLL;
 }

@@ -17,9 +17,12 @@ if mode.startswith("bf16x3"):
     from excel_amd._lib import lib
     As, Ws = ops.split_bf16(A), ops.split_bf16(W)
     out = torch.empty((M, 2 * N if mode.endswith("split") else N), dtype=torch.float32, device="cuda")
-    so = {"bf16x3": 0, "bf16x3_split": 1, "bf16x3_noepi": 99}[mode]
+    so = {"bf16x3": 0, "bf16x3_split": 1, "bf16x3_noepi": 99, "bf16x3_res": 0}[mode]
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    f = lambda: lib().excel_gemm_bf16x3(As.data_ptr(), Ws.data_ptr(), out.data_ptr(), None, None, M, N, K, 0, so, st)
+    res = torch.randn(M, N, device="cuda", generator=g) if mode == "bf16x3_res" else None      # bias + residual epilogue (out-proj / fc2 form)
+    bias = torch.randn(N, device="cuda", generator=g) if mode == "bf16x3_res" else None
+    f = lambda: lib().excel_gemm_bf16x3(As.data_ptr(), Ws.data_ptr(), out.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                        res.data_ptr() if res is not None else None, M, N, K, 0, so, st)
 else:
     f = lambda: ops.gemm(A, W)
 for _ in range(3): f()
