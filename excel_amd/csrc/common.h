@@ -218,6 +218,31 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi2, unsi
 #endif
 }
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// QuickGELU x * sigmoid(1.702 x) (clip/clip_surgery_model.py QuickGELU) over NV register tiles of four values, written stage by stage with
+// packed fp32 operations: exactly the operations and roundings of  x * rcp(1 + __expf(-1.702f * x))  ( t = x * -1.702, u = t * log2(e),
+// e = exp2(u), d = 1 + e, r = rcp(d), x * r ) - every GEMM instance produces the same bits - but as 2 NV independent chains side by side.
+// The element-at-a-time form compiles to ONE serial chain through one temporary (mul, mul, exp, nop, add, rcp per value): on the four-wave
+// GEMM, one wave per SIMD, nothing fills its latencies - it was the largest part of the fc1 epilogue (round 5, read off the disassembly).
+template <int NV>
+__device__ __forceinline__ void quickgelu_tiles(f32x4* v) {       // v[0 .. NV)
+    f32x2 t[2 * NV];
+#pragma unroll
+    for (int i = 0; i < 2 * NV; ++i) t[i] = f32x2{v[i >> 1][2 * (i & 1)], v[i >> 1][2 * (i & 1) + 1]} * f32x2{-1.702f, -1.702f};
+#pragma unroll
+    for (int i = 0; i < 2 * NV; ++i) t[i] = t[i] * f32x2{1.4426950408889634f, 1.4426950408889634f};
+#pragma unroll
+    for (int i = 0; i < 2 * NV; ++i) t[i] = f32x2{__builtin_amdgcn_exp2f(t[i][0]), __builtin_amdgcn_exp2f(t[i][1])};
+#pragma unroll
+    for (int i = 0; i < 2 * NV; ++i) t[i] = t[i] + f32x2{1.f, 1.f};
+#pragma unroll
+    for (int i = 0; i < 2 * NV; ++i) t[i] = f32x2{__builtin_amdgcn_rcpf(t[i][0]), __builtin_amdgcn_rcpf(t[i][1])};
+#pragma unroll
+    for (int i = 0; i < 2 * NV; ++i) {
+        const f32x2 o = f32x2{v[i >> 1][2 * (i & 1)], v[i >> 1][2 * (i & 1) + 1]} * t[i];
+        v[i >> 1][2 * (i & 1)] = o[0];
+        v[i >> 1][2 * (i & 1) + 1] = o[1];
+    }
+}
 // LDS accesses of the streaming loop are written as inline asm: the compiler's wait-count pass treats every ds_read as a
 // possible reader of a pending global_load_lds and drains the whole DMA queue (s_waitcnt vmcnt(0)) in front of it, which
 // serialises the tile stream (that is what held attn_accum_bf_kernel at ~20 % matrix-core busy).  The waits here are explicit.

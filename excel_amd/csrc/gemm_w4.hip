@@ -353,8 +353,10 @@ __device__ __forceinline__ void gemm_w4_body(GemmBfArgs p) {
     });
     // one specialised copy per output mode (a run-time mode inside the row loop keeps the store addresses of all three modes live at once
     // and spills)
-    auto epilogue = [&](auto MODEc, auto RESc) {
+    auto epilogue = [&](auto MODEc, auto RESc, auto FULLc) {
         constexpr int MODE = decltype(MODEc)::value;
+        constexpr bool FULL = decltype(FULLc)::value;          // the tile lies inside the matrix (all but the last row / column of tiles): no row / column
+                                                               // predicates, no exec juggling around the stores, no clamped addresses
         constexpr bool RES = decltype(RESc)::value;            // residual launches get their own copy (plain output only): the prefetch below is unconditional there
         // head-major q|k|v scatter: the 8 columns of a pair stay inside one head (hd % 8 == 0): per pair the offset of (type, head, d)
         int qoff[NT_N / 2];                                          // (row indices of the [B,3,H,tokN] planes: < 2^31 rows)
@@ -376,10 +378,10 @@ __device__ __forceinline__ void gemm_w4_body(GemmBfArgs p) {
         f32x4 rs[NT_N];
         auto load_res = [&](auto I2c) {
             constexpr int i2 = (decltype(I2c)::value + MAIN) % NT_M;
-            const int row2 = min(m0 + wm * WTM + 16 * i2 + r16e, p.M - 1);
+            const int row2 = FULL ? m0 + wm * WTM + 16 * i2 + r16e : min(m0 + wm * WTM + 16 * i2 + r16e, p.M - 1);
             sfor<0, NT_N>([&](auto Jc) {
                 constexpr int j = decltype(Jc)::value;
-                const int c = min(colw + 32 * (j >> 1) + 4 * (j & 1), p.N - 4);
+                const int c = FULL ? colw + 32 * (j >> 1) + 4 * (j & 1) : min(colw + 32 * (j >> 1) + 4 * (j & 1), p.N - 4);
                 rs[j] = *reinterpret_cast<const f32x4*>(p.res + (long long)row2 * p.ldr + c);
             });
         };
@@ -388,7 +390,7 @@ __device__ __forceinline__ void gemm_w4_body(GemmBfArgs p) {
             constexpr int I = decltype(Ic)::value;
             constexpr int i = (I + MAIN) % NT_M;       // the tail row tiles first: their accumulators occupy 64 VGPRs
             const int row = m0 + wm * WTM + 16 * i + r16e;
-            const bool row_ok = row < p.M;
+            const bool row_ok = FULL || row < p.M;
             const int rowc = row_ok ? row : p.M - 1;
             f32x4 v[NT_N];
             sfor<0, NT_N>([&](auto Jc) {
@@ -399,12 +401,7 @@ __device__ __forceinline__ void gemm_w4_body(GemmBfArgs p) {
             });
             if constexpr (RES) {
                 sfor<0, NT_N>([&](auto Jc) { constexpr int j = decltype(Jc)::value; v[j] += bias4[j]; });
-                if (p.act == GEMM_ACT_QUICKGELU)
-                    sfor<0, NT_N>([&](auto Jc) {
-                        constexpr int j = decltype(Jc)::value;
-    #pragma unroll
-                        for (int q = 0; q < 4; ++q) v[j][q] = v[j][q] * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v[j][q]));
-                    });
+                if (p.act == GEMM_ACT_QUICKGELU) { quickgelu_tiles<NT_N / 2>(v); quickgelu_tiles<NT_N / 2>(v + NT_N / 2); }    // (eight chains at a time: all sixteen spill one register)
                 sfor<0, NT_N>([&](auto Jc) { constexpr int j = decltype(Jc)::value; v[j] += rs[j]; });
                 if constexpr (I + 1 < NT_M) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -413,18 +410,13 @@ __device__ __forceinline__ void gemm_w4_body(GemmBfArgs p) {
                 }
             } else {
                 sfor<0, NT_N>([&](auto Jc) { constexpr int j = decltype(Jc)::value; v[j] += bias4[j]; });
-                if (p.act == GEMM_ACT_QUICKGELU)
-                    sfor<0, NT_N>([&](auto Jc) {
-                        constexpr int j = decltype(Jc)::value;
-    #pragma unroll
-                        for (int q = 0; q < 4; ++q) v[j][q] = v[j][q] * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v[j][q]));
-                    });
+                if (p.act == GEMM_ACT_QUICKGELU) { quickgelu_tiles<NT_N / 2>(v); quickgelu_tiles<NT_N / 2>(v + NT_N / 2); }    // (eight chains at a time: all sixteen spill one register)
             }
             if constexpr (MODE == GEMM_OUT_PLAIN) {
                 sfor<0, NT_N>([&](auto Jc) {
                     constexpr int j = decltype(Jc)::value;
                     const int c = colw + 32 * (j >> 1) + 4 * (j & 1);
-                    if (row_ok && c < p.N) *reinterpret_cast<f32x4*>(p.C + (long long)row * p.ldc + c) = v[j];
+                    if (FULL || (row_ok && c < p.N)) *reinterpret_cast<f32x4*>(p.C + (long long)row * p.ldc + c) = v[j];
                 });
             } else {
                 int qrow = 0;
@@ -435,7 +427,7 @@ __device__ __forceinline__ void gemm_w4_body(GemmBfArgs p) {
                 sfor<0, NT_N / 2>([&](auto JPc) {
                     constexpr int jp = decltype(JPc)::value;
                     const int c = colw + 32 * jp;
-                    const bool ok0 = row_ok && c < p.N && !(DBG & 64), ok1 = row_ok && c + 4 < p.N && !(DBG & 64);   // (64: timing arm without stores)
+                    const bool ok0 = (FULL || (row_ok && c < p.N)) && !(DBG & 64), ok1 = (FULL || (row_ok && c + 4 < p.N)) && !(DBG & 64);   // (64: timing arm without stores)
                     unsigned hi[4], lo[4];          // 8 columns: packed pairs, already in store order
     #pragma unroll
                     for (int q = 0; q < 2; ++q) {
@@ -477,10 +469,14 @@ __device__ __forceinline__ void gemm_w4_body(GemmBfArgs p) {
             __builtin_amdgcn_sched_barrier(0);      // one row tile at a time: hoisting the next tiles' accumulator reads and residual loads spills
         });
     };
-    if (p.out_mode == GEMM_OUT_SPLIT_BF16) epilogue(IC<GEMM_OUT_SPLIT_BF16>{}, std::false_type{});
-    else if (p.out_mode == GEMM_OUT_QKV_HEADMAJOR) epilogue(IC<GEMM_OUT_QKV_HEADMAJOR>{}, std::false_type{});
-    else if (p.res) epilogue(IC<GEMM_OUT_PLAIN>{}, std::true_type{});
-    else epilogue(IC<GEMM_OUT_PLAIN>{}, std::false_type{});
+    auto run_epilogue = [&](auto FULLc) {
+        if (p.out_mode == GEMM_OUT_SPLIT_BF16) epilogue(IC<GEMM_OUT_SPLIT_BF16>{}, std::false_type{}, FULLc);
+        else if (p.out_mode == GEMM_OUT_QKV_HEADMAJOR) epilogue(IC<GEMM_OUT_QKV_HEADMAJOR>{}, std::false_type{}, FULLc);
+        else if (p.res) epilogue(IC<GEMM_OUT_PLAIN>{}, std::true_type{}, FULLc);
+        else epilogue(IC<GEMM_OUT_PLAIN>{}, std::false_type{}, FULLc);
+    };
+    if (m0 + BM <= p.M && n0 + BN <= p.N) run_epilogue(std::true_type{});       // (wave-uniform)
+    else run_epilogue(std::false_type{});
     if constexpr (DBG & 128) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); phase_stamp(3); }
 }
 

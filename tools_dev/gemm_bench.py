@@ -17,12 +17,13 @@ if mode.startswith("bf16x3"):
     from excel_amd._lib import lib
     As, Ws = ops.split_bf16(A), ops.split_bf16(W)
     out = torch.empty((M, 2 * N if mode.endswith("split") else N), dtype=torch.float32, device="cuda")
-    so = {"bf16x3": 0, "bf16x3_split": 1, "bf16x3_noepi": 99, "bf16x3_res": 0}[mode]
+    so = {"bf16x3": 0, "bf16x3_split": 1, "bf16x3_noepi": 99, "bf16x3_res": 0, "bf16x3_gelu_split": 1}[mode]
+    act = 1 if mode == "bf16x3_gelu_split" else 0          # bias + QuickGELU + split output: the fc1 form
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     res = torch.randn(M, N, device="cuda", generator=g) if mode == "bf16x3_res" else None      # bias + residual epilogue (out-proj / fc2 form)
-    bias = torch.randn(N, device="cuda", generator=g) if mode == "bf16x3_res" else None
+    bias = torch.randn(N, device="cuda", generator=g) if mode in ("bf16x3_res", "bf16x3_gelu_split") else None
     f = lambda: lib().excel_gemm_bf16x3(As.data_ptr(), Ws.data_ptr(), out.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                        res.data_ptr() if res is not None else None, M, N, K, 0, so, st)
+                                        res.data_ptr() if res is not None else None, M, N, K, act, so, st)
 else:
     f = lambda: ops.gemm(A, W)
 for _ in range(3): f()
