@@ -788,6 +788,15 @@ def test_gemm_bf16x3_bench_shapes(ops, M, N, K):
     if N % 32 == 0:
         hi, lo = _unsplit(host(ops.gemm_bf16x3(As, Ws, split_out=True)))
         assert np.array_equal(hi, _bf16_round(out)) and np.array_equal(lo, _bf16_round(out - hi))
+        # the fc1 form (bias + QuickGELU, split output: the stage-wise packed QuickGELU of the four-wave epilogue) must carry the bits of the
+        # plain-output launch of the same problem, and residual + split output (which the four-wave kernel hands to the 8-wave one) those
+        # of the plain residual launch: every instance and every output mode computes the same values
+        g_plain = host(ops.gemm_bf16x3(As, Ws, bias=dev(bias), act=1))
+        hi, lo = _unsplit(host(ops.gemm_bf16x3(As, Ws, bias=dev(bias), act=1, split_out=True)))
+        assert np.array_equal(hi, _bf16_round(g_plain)) and np.array_equal(lo, _bf16_round(g_plain - hi))
+        assert maxabs(g_plain, y - res) < 3e-5 * scale + 2e-6
+        hi, lo = _unsplit(host(ops.gemm_bf16x3(As, Ws, bias=dev(bias), residual=dev(res), act=1, split_out=True)))
+        assert np.array_equal(hi, _bf16_round(out2)) and np.array_equal(lo, _bf16_round(out2 - hi))
 
 
 @pytest.mark.parametrize("M,N,K", [(25120, 1001, 64), (12560, 2302, 64), (25120, 770, 96)])
