@@ -238,22 +238,18 @@ __global__ __launch_bounds__(512, 4) void par_iterate_guide_kernel(const float* 
     const bool interior = x0 - HALO >= 0 && x0 + 64 + HALO <= W;
 #endif
     const int x4off = min(x0 - HALO + 4 * (lane & 31), Wp - 4) * 4;         // (columns >= 64 + 2 HALO of the 128-float row are never read)
-    // part q (0 .. 3) of plane p: a quarter of this wave's rows (PAR_SPREAD_DMA: the parts of the next plane go out one at a time between the
-    // tap rows of the current one instead of as a burst of every wave behind the plane barrier)
-    auto stage_part = [&](auto int_c, int p, int buf, int q) {   // plane p of the sequence [guide 0..2, mask 0..nch-1] -> buffer buf
-        constexpr bool INTERIOR = decltype(int_c)::value;
+    auto stage = [&](int p, int buf) {                           // plane p of the sequence [guide 0..2, mask 0..nch-1] -> buffer buf
         const bool is_g = p < 3;
         const int plane_off = (is_g ? p : p - 3) * (int)(HW * 4);
         unsigned dst = tile_b + (buf * TR + wave * RPW) * (TP * 4);
         asm volatile("" : "+s"(dst));
         // dev arm (timing only, wrong results): stage 48 of the 64 rows = roughly the +-12-pixel apron of the round-3 review's proposal
         if ((EXCEL_DBG(dbg) & 8) && (wave == 0 || wave == 7)) return;
-        if constexpr (INTERIOR) {
+        if (interior) {
             int half = lane >> 5;                                // opaque: the per-lane source offsets are recomputed per plane (hoisted out of
             asm volatile("" : "+v"(half));                       // the plane loops they were live across the weight registers and spilled)
-            static_assert(RPW / 2 == 4, "four 16-byte pieces per wave and plane");
-            {
-                const int j = q;
+#pragma unroll
+            for (int j = 0; j < RPW / 2; ++j) {
                 const int gy = min(max(y0 - HALO + wave * RPW + 2 * j + half, 0), H - 1);   // replicate padding in y (per half-wave)
                 const int voff = gy * Wp * 4 + x4off;
                 if (is_g) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_bptr)(unsigned long long)(dst + j * (2 * TP * 4)), 16, voff, plane_off, 0, 0);
@@ -261,8 +257,8 @@ __global__ __launch_bounds__(512, 4) void par_iterate_guide_kernel(const float* 
             }
             return;
         }
-#pragma unroll
-        for (int rr = 2 * q; rr < 2 * q + 2; ++rr) {
+#pragma unroll 4
+        for (int rr = 0; rr < RPW; ++rr) {
             const int gy = min(max(y0 - HALO + wave * RPW + rr, 0), H - 1);                    // replicate padding in y (scalar)
             const int soff = plane_off + gy * Wp * 4;
             if (is_g) {
@@ -273,19 +269,6 @@ __global__ __launch_bounds__(512, 4) void par_iterate_guide_kernel(const float* 
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_m, (lds_bptr)(unsigned long long)(dst + rr * (TP * 4) + 256), 4, xoffB, soff, 0, 0);
             }
         }
-    };
-
-    auto stage = [&](auto int_c, int p, int buf) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) stage_part(int_c, p, buf, q);
-    };
-#ifndef PAR_SPREAD_DMA
-#define PAR_SPREAD_DMA 1
-#endif
-    // tap rows behind which the parts 1 .. 3 of the next plane are issued (part 0 goes out right behind the barrier)
-    auto spread = [&](auto int_c, auto g, int p, int buf) {
-        constexpr int G = decltype(g)::value;
-        if constexpr (PAR_SPREAD_DMA && (G == 1 || G == 4 || G == 7)) stage_part(int_c, p, buf, 1 + G / 3);
     };
 
     f32x2 wall[ND][8];
@@ -336,7 +319,7 @@ __global__ __launch_bounds__(512, 4) void par_iterate_guide_kernel(const float* 
                 if constexpr (r != 1) fn(di, k0 + 1, sl[s][1]);
                 fn(di, k0 + (r != 1 ? 2 : 1), R);
             }
-            pin(g);                                              // row g is consumed HERE, between the reads of the rows behind it
+            pin();                                               // row g is consumed HERE, between the reads of the rows behind it
             __builtin_amdgcn_sched_barrier(0);
         });
     };
@@ -355,9 +338,6 @@ __global__ __launch_bounds__(512, 4) void par_iterate_guide_kernel(const float* 
         }
         return sum;
     };
-    // the whole plane sequence once per tile kind (interior tiles stage with 16-byte pieces, border tiles with edge-clamped 4-byte ones): with the
-    // DMA parts between the tap rows, a run-time branch on the kind inside the taps split the live ranges of the 96 weight registers (84 spills)
-    auto planes = [&](auto int_c) {
     const int np = 3 + nch;
     // The per-pixel statistics (k2_r, k2_g, k2_b, m, 1/sum) come in ONE PLANE AHEAD, issued in front of the LDS-DMA pieces of the next plane:
     // vmcnt retires in order, so a load issued behind those pieces - where the value is needed - made its own wait a wait for the whole
@@ -368,7 +348,7 @@ __global__ __launch_bounds__(512, 4) void par_iterate_guide_kernel(const float* 
     auto stat_load = [&](int plane) -> f32x2 { return *reinterpret_cast<const f32x2*>(st_b + (long long)plane * HW); };
     f32x2 st_nxt = stat_load(0), st_nx2 = f32x2{0.f, 0.f};
     __builtin_amdgcn_sched_barrier(0);
-    stage(int_c, 0, 0);
+    stage(0, 0);
 #pragma unroll 1
     for (int p = 0; p < 3; ++p) {
         // this wave's pieces of plane p and its statistics have landed.  (The statistics pass through the wait as an operand: the compiler
@@ -382,8 +362,7 @@ __global__ __launch_bounds__(512, 4) void par_iterate_guide_kernel(const float* 
         f32x2 ctr;
         asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(ctr) : "v"(org + (p & 1) * (TR * TP * 4)), "n"((HALO * TP + HALO) * 4) : "memory");
         __builtin_amdgcn_sched_barrier(0);
-        if (PAR_SPREAD_DMA) stage_part(int_c, p + 1, (p + 1) & 1, 0);   // (np >= 4) streams in behind the taps below: part 0 here, 1 .. 3 between tap rows
-        else stage(int_c, p + 1, (p + 1) & 1);
+        stage(p + 1, (p + 1) & 1);                                   // (np >= 4) streams in behind the taps below
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ctr) :: "memory");
         if (EXCEL_DBG(dbg) & 1) continue;
         // guide channel p:  z_t += -(I_nb - I)^2 k2_p   as fma(dv dv, -k2, z), dv = nb + (-ctr): bit-identical to the affinity kernel.
@@ -394,7 +373,7 @@ __global__ __launch_bounds__(512, 4) void par_iterate_guide_kernel(const float* 
         taps(std::integral_constant<int, 1>{}, p & 1, [&](int di, int k, const f32x2 nb) {
             const f32x2 dv = nb + nctr;
             wall[di][k] = __builtin_elementwise_fma(dv * dv, nk2, wall[di][k]);
-        }, [&](auto g) { spread(int_c, g, p + 1, (p + 1) & 1); });
+        }, [] {});
     }
     if (!(EXCEL_DBG(dbg) & 2)) {
         // aff_t = 2^(z_t - m) / sum + pos_t : the affinity kernel's operations, one rounding each (z + (-m) == z - m)
@@ -424,20 +403,16 @@ __global__ __launch_bounds__(512, 4) void par_iterate_guide_kernel(const float* 
         if (p > 3 && wstore) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        const bool more = p + 1 < np;
-        if (more) { if (PAR_SPREAD_DMA) stage_part(int_c, p + 1, (p + 1) & 1, 0); else stage(int_c, p + 1, (p + 1) & 1); }
+        if (p + 1 < np) stage(p + 1, (p + 1) & 1);
         if (EXCEL_DBG(dbg) & 4) continue;
         f32x2 acc = {0.f, 0.f};
         if (EXCEL_DBG(dbg) & 16) acc = 1e-30f * far_taps(in + (long long)Cmax * tg.base + (long long)(p - 3) * HW);
         // (acc is pinned per tap row: it is only stored under `valid`, and the whole fma chain was otherwise sunk into that branch,
         //  behind all 50 reads of the plane)
         taps(std::integral_constant<int, PAR_MASK_DEPTH>{}, p & 1, [&](int di, int k, const f32x2 nb) { acc = __builtin_elementwise_fma(nb, wall[di][k], acc); },   // tap order, fused
-             [&](auto g) { asm volatile("" : "+v"(acc)); if (more) spread(int_c, g, p + 1, (p + 1) & 1); });
+             [&] { asm volatile("" : "+v"(acc)); });
         if (valid) *reinterpret_cast<f32x2*>(out_px + (long long)(p - 3) * HW) = acc;
     }
-    };
-    if (interior) planes(std::true_type{});
-    else planes(std::false_type{});
 }
 
 // ---------------------------------------------------------------------------------------------------------------
