@@ -489,15 +489,18 @@ bool excel_gemm_w4_supported(const GemmBfArgs& p, int nt_m) {
            (long long)p.M * p.lda * 2 < 0x7fffffffLL && (long long)p.N * p.ldb * 2 < 0x7fffffffLL;
 }
 
-// Modelled time (us) of one launch of the nt_m instance on n_cu CUs: rounds of tiles x (prologue + row tiles x (k-steps x 0.233 + epilogue
+// Modelled time (us) of one launch of the nt_m instance on n_cu CUs: rounds of tiles (a partial last round counts less) x (prologue + row tiles x (k-steps x 0.233 + epilogue
 // 1.8)); calibrated on the B = 32 layer shapes (profiles/r05_w4_arms.txt: a 320-row tile of K = 768 is 56 us of k-loop + 18 of epilogue + 7),
 // the short instance pays ~8 % more per row tile for its fragment reads (26 instead of 36 per 240 MFMAs-equivalent).  The launcher compares
 // this against the 8-wave tiles' model (gemm_bf16x3.hip).
 double excel_gemm_w4_model_us(const GemmBfArgs& p, int nt_m, int n_cu) {
     const long long tiles = (long long)cdiv(p.M, 32 * nt_m) * cdiv(p.N, w4::BN);
-    const long long rounds = (tiles + n_cu - 1) / n_cu;
+    const long long full = tiles / n_cu, rem = tiles - full * n_cu;
     const double per_row_tile = (p.K / 32) * 0.233 * (nt_m == 5 ? 1.08 : nt_m == 8 ? 1.02 : 1.0) + 1.8;
-    return rounds * (7.0 + nt_m * per_row_tile);
+    // a partly filled last round is cheaper than a full one (fewer CUs share the power budget and the fabric): 0.45 + 0.55 x fill of a full
+    // round's time, fitted on the B = 16 shapes (profiles/r05b_b16_shapes.txt: 360 tiles 140.6 us, 480 tiles 163.1, 624 tiles 223.8)
+    const double last = rem ? 0.45 + 0.55 * (double)rem / n_cu : 0.0;
+    return ((double)full + last) * (7.0 + nt_m * per_row_tile);
 }
 
 // one plain __global__ function per instance (a kernel TEMPLATE launched from inside a function template lost its host-side stub)
