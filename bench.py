@@ -541,9 +541,14 @@ def main(argv=None, hooks=None):
                                                "algorithmic_bytes_per_launch": int(per_launch),
                                                "kernel_minimum_bytes_per_launch": int(own_min),
                                                "traffic_over_kernel_minimum": round(par_traffic / own_min, 2) if par_traffic else None,
-                                               "note": "achieved = SURVEY 8(d) bytes of the streamed-plane algorithm / time; the kernel recomputes the 48 "
+                                               # what the recomputing kernel itself moves, against the same peak: it is VALU-bound, not HBM-bound
+                                               "moved_gbs": round(own_min / (par_it["ms"] / max(par_it["launches"], 1) * 1e-3) / 1e9, 1),
+                                               "frac_moved": round(own_min / (par_it["ms"] / max(par_it["launches"], 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                               "note": "achieved = SURVEY 8(d) bytes of the streamed-plane algorithm / time - a frac above 1 means the step "
+                                                       "runs faster than streaming 48 affinity planes at the HBM peak could; the kernel recomputes the 48 "
                                                        "weights per pixel and really moves `traffic` (halo re-fetch included) - its own minimum is "
-                                                       "kernel_minimum_bytes_per_launch",
+                                                       "kernel_minimum_bytes_per_launch, `frac_moved` of the HBM peak: the kernel is VALU-bound "
+                                                       "(profiles/r05b_pipe_busy.txt: valu_busy 0.60)",
                                                "avg_launch_ms": round(par_it["ms"] / max(par_it["launches"], 1), 5)}
             vit_ms = sum(prof_all[k]["ms"] for k in ("gemm_nt", "gemm_nn", "gemm_bf16x3", "attn_rowpass", "attn_accum", "layernorm", "embed",
                                                   "token_norm", "cam_epilogue", "cam_proj", "cam_fused") if k in prof_all)
