@@ -9,6 +9,7 @@ if os.environ.get("EXCEL_AB_LIB"):
 from excel_amd import ops
 from excel_amd._lib import lib
 M, N, K = (int(x) for x in sys.argv[1:4]) if len(sys.argv) > 3 else (25120, 2304, 768)
+ACT = int(sys.argv[4]) if len(sys.argv) > 4 else 0          # 1: QuickGELU (the fc1 form)
 g = torch.Generator(device="cuda").manual_seed(0)
 A = torch.randn(M, K, device="cuda", generator=g); W = torch.randn(N, K, device="cuda", generator=g) * 0.05
 As, Ws = ops.split_bf16(A), ops.split_bf16(W)
@@ -16,7 +17,7 @@ out = torch.empty((M, 2 * N), dtype=torch.float32, device="cuda")
 stamps = torch.zeros(max(N, 8192), dtype=torch.float32, device="cuda")
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 for _ in range(3):
-    lib().excel_gemm_bf16x3(As.data_ptr(), Ws.data_ptr(), out.data_ptr(), stamps.data_ptr(), None, M, N, K, 0, 1, st)
+    lib().excel_gemm_bf16x3(As.data_ptr(), Ws.data_ptr(), out.data_ptr(), stamps.data_ptr(), None, M, N, K, ACT, 1, st)
 torch.cuda.synchronize()
 t = stamps.view(torch.int64)[: 2 * (K // 32)].cpu().numpy().reshape(-1, 2)
 rt = stamps.view(torch.int64)[256: 256 + K // 32].cpu().numpy()
@@ -37,3 +38,12 @@ dur = se[:, 1] - se[:, 0]
 print("  all %d workgroups: entry spread %.2f us, duration min / median / max %.1f / %.1f / %.1f us, last end at %.1f us; slowest: %s" % (
     nt, se[:, 0].max() - t0, dur.min(), np.median(dur), dur.max(), se[:, 1].max() - t0, [(int(i), round(float(dur[i]), 1)) for i in np.argsort(-dur)[:6]]))
 print("  duration by XCD (b % 8):", [round(float(np.median(dur[x::8])), 1) for x in range(8)], " second-round entries:", int((se[:, 0] - t0 > 20).sum()))
+
+ep = stamps.view(torch.int64)[2000:2013].cpu().numpy().astype(np.float64)
+if ep[0]:
+    print("  epilogue of workgroup 0, wave 0 (cycles): entry -> bias loads issued %.0f | per row tile (stores issued): %s | total %.0f" % (
+        ep[1] - ep[0], [int(ep[2 + i] - ep[1 + i]) for i in range(10)], ep[11] - ep[0]))
+first = se[:, 0] - t0 < 20.0
+if (~first).any():
+    print("  first-round workgroups: median duration %.1f us; later rounds: %.1f us (an epilogue that misses the instruction cache only in the first round shows here)" % (
+        float(np.median(dur[first])), float(np.median(dur[~first]))))
