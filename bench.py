@@ -253,6 +253,34 @@ def self_launch_argv(argv, n_gpus, port=None):
             "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.abspath(__file__)] + list(argv)
 
 
+def fp16_valued_weights_sideline(args, device, batches, steps):
+    """Side-line, never the headline: the same step with every weight rounded through IEEE half first.  The published CLIP ViT-B/16 archive
+    stores fp16 parameters and the reference loads them into an fp32 model as they are (clip/build_model.py:72: convert_weights is commented
+    out), so real weights are fp16-VALUED fp32 numbers: their bf16 lo plane carries 3-4 significant bits instead of the 7 random ones of the
+    headline's seeded fp32 weights - and the matrix pipe is power-capped by its operand bits (EXPERIMENTS.md round 4; tools_dev/
+    lo_bits_probe.py: the GEMM is 10-14 % faster with 4 / 3-bit lo planes on BOTH operands; here only the weights change)."""
+    import torch
+    from excel_amd.model import ExCEL_model
+    from excel_amd.pipeline import TrainingFreePipeline
+    from excel_amd.tools import synthetic
+    sd = {k: np.asarray(v, np.float32).astype(np.float16).astype(np.float32) for k, v in synthetic.make_vit_state_dict(seed=0).items()}
+    model = ExCEL_model(clip_model="ExCEL_ViT-B/16", num_classes=21, img_size=448, mode="train", device=device, state_dict=sd,
+                        text_features=synthetic.make_text_features(45))
+    pipe = TrainingFreePipeline(model, num_classes=21, smax=max(int(b[1].sum(1).max().item()) for b in batches))
+    for i in range(3):
+        pipe.run_batch(*batches[i % len(batches)])
+    pipe.reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        pipe.run_batch(*batches[i % len(batches)])
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / steps
+    return {"images_per_s": round(args.batch / ms * 1e3, 1), "ms_per_step": round(ms, 3), "steps": steps,
+            "note": "weights rounded through fp16 (as in the published CLIP archive), activations / arithmetic unchanged (bf16x3): what the "
+                    "step runs at on checkpoint-like weights; the headline keeps the seeded full-mantissa fp32 weights"}
+
+
 def make_workload(args, rank, world, device):
     """The benchmark's model, pipeline and resident batches of this rank: rank r takes images r, r+R, ... (tools/infer_lam.py:166);
     two distinct resident batches, alternated.  -> (pipe, batches, ks, model)"""
@@ -290,6 +318,8 @@ def main(argv=None, hooks=None):
     ap.add_argument("--no-rccl", action="store_true", help="bare N=1 launch: do not bring up the one-rank RCCL group (the matrix is then not gathered)")
     ap.add_argument("--ragged-images", type=int, default=256, help="images of the harness_ragged side-line (0 = skip)")
     ap.add_argument("--power-seconds", type=float, default=3.0, help="untimed loop of the step with rocm-smi power sampling (0 = skip)")
+    ap.add_argument("--fp16w-steps", type=int, default=10, help="steps of the checkpoint-like-weights side-line (weights rounded through fp16 like the "
+                    "published CLIP archive; 0 = skip; skipped with --cpu-images 0, i.e. in profiling / A-B passes)")
     ap.add_argument("--overlap", type=int, default=int(os.environ.get("EXCEL_BENCH_OVERLAP", "0")),
                     help="1: two-stream software pipeline (PAR of batch i overlaps the ViT of batch i+1)")
     ap.add_argument("--split", type=int, default=int(os.environ.get("EXCEL_BENCH_SPLIT", "1")),
@@ -607,6 +637,8 @@ def main(argv=None, hooks=None):
             out["numerics_check"] = model.check_numerics(batches[0][0][:4], fallback=False)
         if on_gpu and world == 1 and args.power_seconds > 0:
             out["power"] = power_sideline(pipe, batches[0], args.power_seconds, B)
+        if on_gpu and world == 1 and args.fp16w_steps > 0 and args.cpu_images > 0:
+            out["checkpoint_like_weights"] = fp16_valued_weights_sideline(args, device, batches, args.fp16w_steps)
         if on_gpu and world == 1 and args.ragged_images > 0:
             gc.collect()
             gc.freeze()                                             # as infer_lam.validate does: later collections skip the start-up heap
