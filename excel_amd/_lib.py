@@ -75,12 +75,15 @@ SIGNATURES = {
     "excel_gemm_bf16x3": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
     "excel_split_f16": (c_i, [c_f, c_f, c_ll, c_i, c_f]),
     "excel_gemm_f16x3": (c_i, [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
+    "excel_pack_f16": (c_i, [c_f, c_f, c_ll, c_i, c_f, c_f]),
+    "excel_gemm_f16x2": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f]),
     "excel_layernorm": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, C.c_float, c_f]),
     "excel_vit_create": (c_i, [C.POINTER(VitConfig), C.POINTER(VitWeights), C.POINTER(C.c_void_p)]),
     "excel_vit_destroy": (None, [C.c_void_p]),
     "excel_vit_workspace_bytes": (c_sz, [C.c_void_p, c_i, c_i]),
     "excel_vit_set_gemm_mode": (c_i, [C.c_void_p, c_i]),
     "excel_vit_get_gemm_mode": (c_i, [C.c_void_p]),
+    "excel_vit_weights_fp16_exact": (c_i, [C.c_void_p]),
     "excel_vit_forward": (c_i, [C.c_void_p, c_f, c_i, c_i, c_f, c_sz, c_f, c_f, c_f, c_i, c_f, c_i, c_f, c_f]),
     "excel_vit_forward_ex": (c_i, [C.c_void_p, c_f, c_i, c_i, c_f, c_sz, c_f, c_f, c_f, c_i, c_f, c_i, c_f, c_f, c_i, c_f]),
     "excel_feature_affinity_workspace_bytes": (c_sz, [c_i, c_i, c_i]),

@@ -10,12 +10,18 @@ LIB = os.path.join(CSRC, "libexcel_hip.so")
 SOURCES = ["gemm.hip", "gemm_bf16x3.hip", "gemm_w4.hip", "norm.hip", "attn.hip", "attn_strip.hip", "cam.hip", "aff.hip", "par.hip", "attr.hip", "lvc.hip", "decoder.hip", "train.hip", "crf.hip", "abi.hip"]
 # the translation units that depend on the 16-bit type of the split operand planes are compiled twice: bf16 (namespace excel_bf16) and,
 # with -DEXCEL_SPLIT_F16, IEEE half (namespace excel_f16, objects *_f16.o) - the "f16x3" matrix-core mode (common.h, excel_internal.h)
-SPLIT_SOURCES = ["gemm.hip", "gemm_bf16x3.hip", "gemm_w4.hip", "gemm_w4.hip", "norm.hip", "attn.hip", "attn_strip.hip", "cam.hip"]
-HEADERS = ["common.h", "excel_internal.h", "excel_split_api.inc", "decoder_internal.h", os.path.join("..", "..", "include", "excel_hip.h")]
+SPLIT_SOURCES = ["gemm.hip", "gemm_bf16x3.hip", "gemm_w4.hip", "norm.hip", "attn.hip", "attn_strip.hip", "cam.hip"]
+# compiled for the IEEE-half split type only (object *_f16.o): the two-product GEMM for fp16-valued weights ("f16x2")
+F16_ONLY_SOURCES = ["gemm_w4x2.hip"]
+HEADERS = ["common.h", "excel_internal.h", "excel_split_api.inc", "gemm_w4_body.inc", "decoder_internal.h", os.path.join("..", "..", "include", "excel_hip.h")]
 # kernels that must never touch scratch memory: a spill or a dynamically indexed accumulator array inside these turns a matrix-core loop
 # into a memory loop (round 5: one `break` in an unrolled epilogue loop sent the 320x256 GEMM's accumulators to scratch, 3.5x slower,
 # all tests green).  build() reads hipcc's kernel-resource-usage remarks and refuses to link a library that violates this.
-NO_SCRATCH = ("gemm_bf16x3_kernel", "gemm_w4_kernel", "attn_strip_kernel", "par_iterate_guide_kernel", "par_stats_tile_kernel")
+NO_SCRATCH = ("gemm_bf16x3_kernel", "gemm_w4_kernel", "gemm_w4x2_kernel", "attn_strip_kernel", "par_iterate_guide_kernel", "par_stats_tile_kernel")
+# the guard must see what it guards: every object that is supposed to hold one of these kernels has to report it in hipcc's remarks (an
+# empty or re-formatted remark stream would otherwise pass vacuously - advisor, round 5)
+NO_SCRATCH_EXPECTED = {"gemm_bf16x3": "gemm_bf16x3_kernel", "gemm_w4": "gemm_w4_kernel", "gemm_w4x2": "gemm_w4x2_kernel", "attn_strip": "attn_strip_kernel",
+                       "par": "par_iterate_guide_kernel"}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
          # fully unroll the big register-tile epilogues (a partially unrolled loop indexes the accumulator array
          # dynamically and sends it to scratch)
@@ -118,9 +124,9 @@ def build(force=False, verbose=True):
     except Exception:
         resources = {}
     objs, jobs = [], []           # jobs: (command, object name, signature)
-    for s in SOURCES:
+    for s in SOURCES + F16_ONLY_SOURCES:
         src = os.path.join(CSRC, s)
-        variants = [("", [])] + ([("_f16", ["-DEXCEL_SPLIT_F16"])] if s in SPLIT_SOURCES else [])
+        variants = [("_f16", ["-DEXCEL_SPLIT_F16"])] if s in F16_ONLY_SOURCES else [("", [])] + ([("_f16", ["-DEXCEL_SPLIT_F16"])] if s in SPLIT_SOURCES else [])
         for suffix, vflags in variants:
             obj = os.path.join(CSRC, s.replace(".hip", suffix + ".o"))
             objs.append(obj)
@@ -138,6 +144,12 @@ def build(force=False, verbose=True):
                     json.dump(sigs, open(sigfile, "w"))
                     raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), res.stderr))
                 resources[name] = _parse_resources(res.stderr)
+                want = NO_SCRATCH_EXPECTED.get(name.replace("_f16.o", "").replace(".o", ""))
+                if want and not any(want in k and "scratch" in v for k, v in resources[name].items()):
+                    sigs.pop(name, None)
+                    json.dump(sigs, open(sigfile, "w"))
+                    raise RuntimeError("%s: hipcc reported no resource usage for %s - the no-scratch guard cannot see the kernel it guards "
+                                       "(remark format changed?)" % (name, want))
                 bad = {k: v for k, v in resources[name].items() if any(n in k for n in NO_SCRATCH) and (v.get("scratch", 0) or v.get("vgpr_spill", 0))}
                 if bad and "-DEXCEL_DEV" in flags:
                     # development builds carry ablation arms that raise the register pressure: report, do not refuse

@@ -17,7 +17,7 @@ void excel_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* excel_last_error(void) { return g_err; }
-extern "C" int excel_abi_version(void) { return 3; }
+extern "C" int excel_abi_version(void) { return 4; }
 #ifndef EXCEL_BUILD_ID
 #define EXCEL_BUILD_ID "unstamped"
 #endif
@@ -192,23 +192,46 @@ extern "C" int excel_gemm_f16x3(const void* A_split, const void* W_split, float*
     return excel_f16::excel_launch_gemm_bf16x3(g, ST(stream));
 }
 
+extern "C" int excel_pack_f16(const float* in, void* out, long long rows, int K, unsigned long long* inexact_dev, void* stream) {
+    EXCEL_CHECK_ARG(in && out && inexact_dev && rows > 0 && K > 0, "pack_f16: bad argument");
+    return excel_f16::excel_launch_pack_hi(in, out, rows, K, inexact_dev, ST(stream));
+}
+
+extern "C" int excel_gemm_f16x2(const void* A_split, const void* W_split, const void* W_half, float* C, const float* bias,
+                                const float* residual, int M, int N, int K, int act, int split_out, void* stream) {
+    EXCEL_CHECK_ARG(A_split && W_split && C, "gemm_f16x2: null argument");
+    GemmBfArgs g = gemm_bf_args(A_split, (const unsigned short*)W_split, C, C, bias, residual, M, N, K, N, N, act,
+                                split_out ? GEMM_OUT_SPLIT_BF16 : GEMM_OUT_PLAIN);
+    g.w_lo_zero = 1;
+    g.Bh = (const unsigned short*)W_half;
+    g.ldbh = K;
+    return excel_f16::excel_launch_gemm_bf16x3(g, ST(stream));
+}
+
 extern "C" int excel_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int D, float eps, void* stream) {
     return excel_launch_layernorm(x, nullptr, 1, w, b, y, rows, D, eps, ST(stream));
 }
 
 // ------------------------------------------------------------------------------------ ViT handle
-struct SplitBlockW { unsigned short *in_proj, *out_proj, *fc1, *fc2; };
+struct SplitBlockW {
+    unsigned short *in_proj, *out_proj, *fc1, *fc2;             // split planes [N][2][K]
+    unsigned short *h_in_proj, *h_out_proj, *h_fc1, *h_fc2;     // plain half matrices [N][K] (mode 3, "f16x2"), else null
+};
 struct excel_vit {
     excel_vit_config cfg;
     excel_vit_weights w;
     std::vector<excel_vit_block_weights> blocks;
     float* projT = nullptr;             // [C, D]
     std::map<int, float*> pos_cache;    // g -> [1+g*g, D]
-    int gemm_mode = 0;                  // 0: exact fp32 MFMA, 1: bf16x3 (split bf16, 3 MFMAs per product), 2: f16x3 (split IEEE half)
+    int gemm_mode = 0;                  // 0: exact fp32 MFMA, 1: bf16x3 (split bf16, 3 MFMAs per product), 2: f16x3 (split IEEE half), 3: f16x2 (2 + fp16-valued weights)
     int split_type = 0;                 // what the split weights hold: 0 nothing yet, 1 bf16 planes, 2 f16 planes
     unsigned short* split_arena = nullptr;   // all split weights in one allocation
     std::vector<SplitBlockW> sblocks;
     unsigned short *s_conv1 = nullptr, *s_projT = nullptr;
+    // "f16x2": the weights as plain half matrices (one allocation) and whether they are all fp16-valued (-1: not examined yet)
+    unsigned short* half_arena = nullptr;
+    unsigned short *h_conv1 = nullptr, *h_projT = nullptr;
+    int fp16_exact = -1;
 };
 
 static int vit_prepare_split_weights(excel_vit* h, int type) {
@@ -239,7 +262,7 @@ static int vit_prepare_split_weights(excel_vit* h, int type) {
         cur += rows * K;
         return dst;
     };
-    h->sblocks.resize(c.layers);
+    if (h->sblocks.size() != (size_t)c.layers) h->sblocks.assign(c.layers, SplitBlockW{});
     for (int l = 0; l < c.layers; ++l) {
         const excel_vit_block_weights& bw = h->blocks[l];
         h->sblocks[l].in_proj = put(bw.in_proj_w, 3 * D, D);
@@ -260,12 +283,72 @@ static int vit_prepare_split_weights(excel_vit* h, int type) {
     return EXCEL_OK;
 }
 
+// Packs every GEMM weight as a plain half matrix (the compact operand of the two-product GEMM) and counts the elements that are not
+// exactly representable: fp16_exact = (count == 0).  One pass, once per handle.
+static int vit_prepare_half_weights(excel_vit* h) {
+    if (h->fp16_exact >= 0) return EXCEL_OK;
+    const excel_vit_config& c = h->cfg;
+    const size_t D = c.width, Kc = (size_t)3 * c.patch * c.patch;
+    const size_t per_block = 3 * D * D + D * D + 4 * D * D + 4 * D * D;
+    const size_t total = per_block * c.layers + D * Kc + (size_t)c.out_dim * D;        // halfs
+    unsigned short* arena = nullptr;
+    unsigned long long* cnt = nullptr;
+    if (hipMalloc(&arena, total * sizeof(unsigned short) + 256) != hipSuccess) {
+        excel_set_error("excel_vit: hipMalloc(half weights) failed");
+        return EXCEL_ERR_ALLOC;
+    }
+    cnt = (unsigned long long*)((char*)arena + align_up(total * sizeof(unsigned short), 16));
+    if (hipMemsetAsync(cnt, 0, sizeof(unsigned long long), 0) != hipSuccess) { hipFree(arena); excel_set_error("excel_vit: memset failed"); return EXCEL_ERR_LAUNCH; }
+    unsigned short* cur = arena;
+    int put_rc = EXCEL_OK;
+    auto put = [&](const float* src, size_t rows, size_t K) -> unsigned short* {
+        unsigned short* dst = cur;
+        const int rc = excel_f16::excel_launch_pack_hi(src, dst, (long long)rows, (int)K, cnt, 0);
+        if (rc != EXCEL_OK && put_rc == EXCEL_OK) put_rc = rc;
+        cur += rows * K;
+        return dst;
+    };
+    if (h->sblocks.size() != (size_t)c.layers) h->sblocks.assign(c.layers, SplitBlockW{});
+    for (int l = 0; l < c.layers; ++l) {
+        const excel_vit_block_weights& bw = h->blocks[l];
+        h->sblocks[l].h_in_proj = put(bw.in_proj_w, 3 * D, D);
+        h->sblocks[l].h_out_proj = put(bw.out_proj_w, D, D);
+        h->sblocks[l].h_fc1 = put(bw.fc1_w, 4 * D, D);
+        h->sblocks[l].h_fc2 = put(bw.fc2_w, D, 4 * D);
+    }
+    h->h_conv1 = put(h->w.conv1_w, D, Kc);
+    h->h_projT = put(h->projT, c.out_dim, D);
+    unsigned long long n_bad = 1;
+    if (put_rc != EXCEL_OK || hipMemcpy(&n_bad, cnt, sizeof(n_bad), hipMemcpyDeviceToHost) != hipSuccess) {       // (synchronises)
+        for (auto& sb : h->sblocks) sb.h_in_proj = sb.h_out_proj = sb.h_fc1 = sb.h_fc2 = nullptr;
+        h->h_conv1 = h->h_projT = nullptr;
+        hipFree(arena);
+        if (put_rc != EXCEL_OK) return put_rc;
+        excel_set_error("excel_vit: packing half weights failed: %s", hipGetErrorString(hipGetLastError()));
+        return EXCEL_ERR_LAUNCH;
+    }
+    h->half_arena = arena;
+    h->fp16_exact = n_bad == 0 ? 1 : 0;
+    return EXCEL_OK;
+}
+
+extern "C" int excel_vit_weights_fp16_exact(excel_vit_t h) {
+    EXCEL_CHECK_ARG(h, "excel_vit_weights_fp16_exact: null handle");
+    if ((h->cfg.width % 32) != 0 || ((3 * h->cfg.patch * h->cfg.patch) % 32) != 0) return 0;      // no split-plane mode for this shape at all
+    TRY(vit_prepare_half_weights(h));
+    return h->fp16_exact;
+}
+
 extern "C" int excel_vit_set_gemm_mode(excel_vit_t h, int mode) {
-    EXCEL_CHECK_ARG(h && (mode == 0 || mode == 1 || mode == 2), "excel_vit_set_gemm_mode: mode must be 0 (f32), 1 (bf16x3) or 2 (f16x3)");
+    EXCEL_CHECK_ARG(h && mode >= 0 && mode <= 3, "excel_vit_set_gemm_mode: mode must be 0 (f32), 1 (bf16x3), 2 (f16x3) or 3 (f16x2)");
     if (mode >= 1) {
         EXCEL_CHECK_ARG((h->cfg.width % 32) == 0 && ((3 * h->cfg.patch * h->cfg.patch) % 32) == 0,
                         "the split-plane modes need width and 3*patch^2 to be multiples of 32");
-        TRY(vit_prepare_split_weights(h, mode));
+        if (mode == 3) {
+            TRY(vit_prepare_half_weights(h));
+            EXCEL_CHECK_ARG(h->fp16_exact == 1, "excel_vit_set_gemm_mode: mode 3 (f16x2) needs fp16-valued weights (excel_vit_weights_fp16_exact); use 2 (f16x3)");
+        }
+        TRY(vit_prepare_split_weights(h, mode == 3 ? 2 : mode));
     }
     h->gemm_mode = mode;
     return EXCEL_OK;
@@ -298,9 +381,9 @@ extern "C" int excel_vit_create(const excel_vit_config* cfg, const excel_vit_wei
         return EXCEL_ERR_LAUNCH;
     }
     *out = h;
-    const char* mode = getenv("EXCEL_GEMM_MODE");     // default numerics of new handles: "f32" | "bf16x3" | "f16x3"
-    if (mode && (!strcmp(mode, "bf16x3") || !strcmp(mode, "f16x3")) && (cfg->width % 32) == 0 && ((3 * cfg->patch * cfg->patch) % 32) == 0) {
-        int rc = excel_vit_set_gemm_mode(h, !strcmp(mode, "f16x3") ? 2 : 1);
+    const char* mode = getenv("EXCEL_GEMM_MODE");     // default numerics of new handles: "f32" | "bf16x3" | "f16x3" | "f16x2"
+    if (mode && (!strcmp(mode, "bf16x3") || !strcmp(mode, "f16x3") || !strcmp(mode, "f16x2")) && (cfg->width % 32) == 0 && ((3 * cfg->patch * cfg->patch) % 32) == 0) {
+        int rc = excel_vit_set_gemm_mode(h, !strcmp(mode, "f16x2") ? 3 : !strcmp(mode, "f16x3") ? 2 : 1);
         if (rc) return rc;
     }
     return EXCEL_OK;
@@ -310,6 +393,7 @@ extern "C" void excel_vit_destroy(excel_vit_t h) {
     if (!h) return;
     if (h->projT) hipFree(h->projT);
     if (h->split_arena) hipFree(h->split_arena);
+    if (h->half_arena) hipFree(h->half_arena);
     for (auto& kv : h->pos_cache) hipFree(kv.second);
     delete h;
 }
@@ -433,7 +517,7 @@ static int vit_forward_f16(EXCEL_VIT_FWD_ARGS) {
 }
 static int vit_forward_impl(EXCEL_VIT_FWD_ARGS) {
     EXCEL_CHECK_ARG(h, "excel_vit_forward: null handle");
-    return h->gemm_mode == 2 ? vit_forward_f16(h, img, B, S, workspace, workspace_bytes, image_features, x_raw, w_aff, aff_layers, attn_out,
+    return h->gemm_mode >= 2 ? vit_forward_f16(h, img, B, S, workspace, workspace_bytes, image_features, x_raw, w_aff, aff_layers, attn_out,
                                                n_attn_out, feats_out, ex_attn, flags, stream)
                              : vit_forward_bf16(h, img, B, S, workspace, workspace_bytes, image_features, x_raw, w_aff, aff_layers, attn_out,
                                                 n_attn_out, feats_out, ex_attn, flags, stream);

@@ -43,6 +43,12 @@ struct GemmBfArgs {
     long long sA, sB, sC, sCs;
     int mix_tall, mix_short;     // set by the launcher (mixed-height 320x256 / 256x256 row tiles, gemm_bf16x3.hip); 0 = uniform tiles
     int mix_first;               // short tiles dispatched FIRST in every XCD's chunk (the rest follow the tall ones): staggers the epilogues
+    // "f16x2" (IEEE-half split type only): the caller guarantees that B's lo plane is all zero (fp16-valued weights) - the a.hi x b.lo
+    // products are skipped (bit-identical results, 2 MFMAs per product).  Bh (optional): the same weights as a plain half matrix
+    // [N][ldbh >= K], the four-wave kernel's compact operand (gemm_w4x2.hip)
+    int w_lo_zero;
+    const unsigned short* Bh;
+    int ldbh;
 };
 
 

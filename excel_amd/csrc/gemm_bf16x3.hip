@@ -209,7 +209,10 @@ __device__ __forceinline__ void bf_epilogue_lds(const GemmBfArgs& p, const f32x4
 // `mix_tall` row tiles of 320 rows followed by `mix_short` row tiles of 256 rows (the same workgroup shape; a short tile's waves run 4
 // of their 5 row tiles) the same number of tiles covers M with less padding: a CU gets 2 tall + 1 short = 28 (3 + 1 = 38).  Tall tiles
 // are dispatched first inside every XCD's chunk (longest first), the short ones level the last round.
-template <int WM, int WN, int TI, int NSTAGE, bool MIX = false>
+// X2 ("f16x2", IEEE-half split type only): the weight operand is fp16-valued - its lo plane is all zero (GemmBfArgs::w_lo_zero) - so the
+// a.hi x b.lo instruction of every fragment pair multiplies zeros and is left out, together with the b.lo fragment reads: two MFMAs per
+// product, the bits of the three-product kernel (x + 0 = x in the fp32 accumulator).
+template <int WM, int WN, int TI, int NSTAGE, bool MIX = false, bool X2 = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16x3_kernel(GemmBfArgs p) {
     constexpr int BM = WM * TI * 32, BN = WN * 64;
     constexpr int STAGE = (BM + BN) * TROW;                  // u16 elements per stage: A rows then B rows
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16x3_kernel(GemmBfArgs
         for (int j = 0; j < 4; ++j) {
             const u16* rowp = bs + (wn * 64 + j * 16 + r16) * TROW;
             bh[j] = *reinterpret_cast<const splitx8*>(rowp + ch);
-            bl[j] = *reinterpret_cast<const splitx8*>(rowp + cl);
+            if (!X2) bl[j] = *reinterpret_cast<const splitx8*>(rowp + cl);
         }
         // A fragments are streamed one 16-row tile ahead (the accumulators leave < 100 registers for everything else in the 320 x 256
         // tile), and the scheduler may not hoist them
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16x3_kernel(GemmBfArgs
             for (int j = 0; j < 4; ++j) {
                 // small terms first, the dominant hi.hi product last
                 acc[i][j] = EXCEL_MFMA32(al[i & 1], bh[j], acc[i][j]);
-                acc[i][j] = EXCEL_MFMA32(ah[i & 1], bl[j], acc[i][j]);
+                if (!X2) acc[i][j] = EXCEL_MFMA32(ah[i & 1], bl[j], acc[i][j]);
                 acc[i][j] = EXCEL_MFMA32(ah[i & 1], bh[j], acc[i][j]);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -431,6 +434,26 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
     split_t* o = reinterpret_cast<split_t*>(out) + row * 2 * K + split_off(k, 0);
     *reinterpret_cast<uint2*>(o) = *reinterpret_cast<const uint2*>(hi);
     *reinterpret_cast<uint2*>(o + 32) = *reinterpret_cast<const uint2*>(lo);
+}
+
+// fp32 [R,K] -> the hi plane alone as a plain 16-bit matrix [R,K] (operand of the two-product GEMM, gemm_w4x2.hip) + the count of
+// elements whose lo plane would not be zero (x != (float)hi(x); a NaN counts): 0 <=> the matrix is exactly representable in the split
+// type, the precondition of the two-product mode
+__global__ __launch_bounds__(256) void pack_hi_kernel(const float* __restrict__ in, u16* __restrict__ out, long long n, unsigned long long* __restrict__ inexact) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    unsigned bad = 0;
+    if (i < n) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(in + i);
+        split_t hi[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            hi[j] = split_hi(v[j]);
+            bad += ((float)hi[j] != v[j]) ? 1u : 0u;          // (NaN: true)
+        }
+        *reinterpret_cast<uint2*>(out + i) = *reinterpret_cast<const uint2*>(hi);
+    }
+    bad = __builtin_amdgcn_readfirstlane((unsigned)wave_sum((float)bad));      // <= 256 per wave: exact in fp32
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(inexact, (unsigned long long)bad);
 }
 
 // V^T in split format vt [B][H*64][2*KP] (row = one (head, d), K axis = token m, zero padded to KP): the K-major B operand of the bf16x3
@@ -535,6 +558,16 @@ int excel_launch_gemm_bf16x3(const GemmBfArgs& p_in, hipStream_t stream) {
     { static const char* e = getenv("EXCEL_W4_MODES"); if (e) w4_mode_ok = (atoi(e) >> p.out_mode) & 1; }     // dev knob: bit per output mode (plain 1, qkv 2, split 4)
     { static const char* e = getenv("EXCEL_W4_RES"); if (e && atoi(e) == 0 && p.res) w4_mode_ok = false; }      // dev knob: 0 = residual launches stay on the 8-wave kernel
 #endif
+#ifdef EXCEL_SPLIT_F16
+    const bool want_x2 = p.w_lo_zero != 0;          // fp16-valued weights: two-product kernels
+#else
+    const bool want_x2 = false;                     // (a bf16 hi plane cannot hold an fp16 value: the flag means nothing here)
+#endif
+    int x2_force = -1;
+#ifdef EXCEL_DEV
+    { static const char* e = getenv("EXCEL_W4_X2"); if (e) x2_force = atoi(e); }        // dev knob: 0 = three-product kernels, 1 = split-layout weights only
+#endif
+    const bool x2_on = want_x2 && x2_force != 0;
     if (!no_w4 && w4_mode_ok && nb == 1 && p.M >= 2048) {
         static int n_cu3 = 0;
         if (!n_cu3) {
@@ -551,15 +584,22 @@ int excel_launch_gemm_bf16x3(const GemmBfArgs& p_in, hipStream_t stream) {
         const long long tiles8 = (long long)cdiv(p.M, bm8[kind]) * cdiv(p.N, bn8[kind]), slots8 = (long long)n_cu3 * wg8[kind];
         const double busy8 = ((double)p.M * p.N) / ((double)((tiles8 + slots8 - 1) / slots8) * slots8 * bm8[kind] * bn8[kind]);
         const double kfac = p.K <= 768 ? 0.0 : (p.K >= 3072 ? 1.0 : (p.K - 768) / 2304.0);
-        double best_us = force ? 1e30 : 2.0 * p.M * (double)p.N * p.K / (busy8 * in8[kind] * (345.0 + 55.0 * kfac) * 1e6);
-        int best_ntm = 0;
+        // (advisor, round 5: a forced 8-wave tile - "128" / "256x128" / "256" - must reach the 8-wave kernel: only "320" or no force routes here)
+        const bool force8 = force && strcmp(force, "320") != 0;
+        double best_us = force ? 1e30 : 2.0 * p.M * (double)p.N * p.K / (busy8 * in8[kind] * (345.0 + 55.0 * kfac) * (x2_on && kind != 3 ? 1.40 : 1.0) * 1e6);
+        int best_ntm = 0, best_x2 = 0;
         const int cand[3] = {10, 8, 5};
-        for (int c = 0; c < 3; ++c) {
-            if (!excel_gemm_w4_supported(p, cand[c])) continue;
-            if (force_ntm > 0) { if (cand[c] == force_ntm) { best_ntm = force_ntm; } continue; }
-            const double us = excel_gemm_w4_model_us(p, cand[c], n_cu3);
-            if (us < best_us) { best_us = us; best_ntm = cand[c]; }
+        for (int c = 0; c < 3 && !force8; ++c) {
+            // the compact-weight instance when the plain half matrix is there, else the split-layout one
+            const int x2 = !x2_on ? 0 : (x2_force != 1 && excel_gemm_w4_supported(p, cand[c], 2)) ? 2 : 1;
+            if (!excel_gemm_w4_supported(p, cand[c], x2)) continue;
+            if (force_ntm > 0) { if (cand[c] == force_ntm) { best_ntm = force_ntm; best_x2 = x2; } continue; }
+            const double us = excel_gemm_w4_model_us(p, cand[c], n_cu3, x2);
+            if (us < best_us) { best_us = us; best_ntm = cand[c]; best_x2 = x2; }
         }
+#ifdef EXCEL_SPLIT_F16
+        if (best_ntm && best_x2) return excel_launch_gemm_w4x2(p, best_ntm, best_x2, stream);
+#endif
         if (best_ntm) return excel_launch_gemm_w4(p, best_ntm, stream);
     }
     if (kind == 3 && nb == 1 && !force_uniform) {
@@ -591,6 +631,15 @@ int excel_launch_gemm_bf16x3(const GemmBfArgs& p_in, hipStream_t stream) {
             return EXCEL_OK;
         }
     }
+#ifdef EXCEL_SPLIT_F16
+    if (x2_on && kind != 3) {        // two-product instances of the tiles that small / odd-shaped weight GEMMs land on
+        if (kind == 2) hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 4, 4, 2, false, true>), dim3(cdiv(p.M, 256) * cdiv(p.N, 256), nb), dim3(512), 0, stream, p);
+        else if (kind == 1) hipLaunchKernelGGL((gemm_bf16x3_kernel<4, 2, 2, 3, false, true>), dim3(cdiv(p.M, 256) * cdiv(p.N, 128), nb), dim3(512), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 2, 2, 2, false, true>), dim3(cdiv(p.M, 128) * cdiv(p.N, 128), nb), dim3(256), 0, stream, p);
+        EXCEL_CHECK_LAUNCH("gemm_f16x2");
+        return EXCEL_OK;
+    }
+#endif
     if (kind == 3) {
         hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 4, 5, 2>), dim3(cdiv(p.M, 320) * cdiv(p.N, 256), nb), dim3(512), 0, stream, p);
     } else if (kind == 2) {
@@ -601,6 +650,14 @@ int excel_launch_gemm_bf16x3(const GemmBfArgs& p_in, hipStream_t stream) {
         hipLaunchKernelGGL((gemm_bf16x3_kernel<2, 2, 2, 2>), dim3(cdiv(p.M, 128) * cdiv(p.N, 128), nb), dim3(256), 0, stream, p);
     }
     EXCEL_CHECK_LAUNCH("gemm_bf16x3");
+    return EXCEL_OK;
+}
+
+int excel_launch_pack_hi(const float* in, void* out, long long R, int K, unsigned long long* inexact, hipStream_t st) {
+    ProfScope prof__(PROF_OTHER, st);
+    EXCEL_CHECK_ARG(in && out && inexact && R > 0 && K > 0 && ((R * K) % 4) == 0, "pack_hi: bad argument (R * K must be a multiple of 4)");
+    hipLaunchKernelGGL(pack_hi_kernel, dim3((unsigned)cdivl(R * K / 4, 256)), dim3(256), 0, st, in, (u16*)out, R * K, inexact);
+    EXCEL_CHECK_LAUNCH("pack_hi");
     return EXCEL_OK;
 }
 

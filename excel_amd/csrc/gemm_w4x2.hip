@@ -1,0 +1,51 @@
+// "f16x2": the four-wave GEMM of gemm_w4.hip for fp16-VALUED weights - two matrix-core instructions per product instead of three.
+//
+// Every published CLIP archive stores half-precision parameters; the reference loads them into an fp32 model unchanged
+// (clip/build_model.py:72 keeps the fp32 conversion off, clip/clip.py:138-154), so in the IEEE-half split  w = hi + lo  the lo plane of
+// every nn.Linear weight is exactly zero.  The three-MFMA product  a.w ~= al.wh + ah.wl + ah.wh  then carries one pass that multiplies
+// zeros: it is dropped here.  The remaining two passes run in the order and on the accumulators of the f16x3 kernel, and adding a
+// block of exact zeros to an fp32 accumulator does not change it - the results are BIT-IDENTICAL to f16x3 on the same operands
+// (tests/test_gpu_ops.py::test_gemm_f16x2_equals_f16x3_bitwise), at two thirds of the matrix-pipe work of half of the step.
+// Two instances per tile height (gemm_w4_body.inc):
+//   X2 = 1: weights in the split layout (their zero lo halves ride along in the staged lines and are never read);
+//   X2 = 2: weights as a plain half matrix [N][K] (excel_vit keeps one next to the split planes): half the weight bytes through L2, the
+//           fabric and the LDS-DMA path - one 128-byte line of a weight row feeds two k-steps.
+// Compiled for the IEEE-half split type only (build.py: F16_ONLY_SOURCES): a bf16 hi plane cannot hold an fp16 value.
+#include <stdlib.h>
+#include <type_traits>
+#include "common.h"
+#include "excel_internal.h"
+
+#ifndef EXCEL_SPLIT_F16
+#error "gemm_w4x2.hip is built for the IEEE-half split type only (-DEXCEL_SPLIT_F16)"
+#endif
+
+namespace EXCEL_SPLIT_NS {
+
+#include "gemm_w4_body.inc"
+
+#define W4X2_KERNEL(NT, X) __global__ __launch_bounds__(256, 1) void gemm_w4x2_kernel_##NT##_##X(GemmBfArgs p) { gemm_w4_body<NT, 0, X>(p); }
+// (no 320-row instance on split-layout weights: its register allocation spills two accumulator tiles at the loop exit - the compact-weight
+// instance below is the one the ViT runs; split-layout callers get the 256-row tile)
+W4X2_KERNEL(8, 1) W4X2_KERNEL(5, 1)
+W4X2_KERNEL(10, 2) W4X2_KERNEL(8, 2) W4X2_KERNEL(5, 2)
+#define W4X2_LAUNCH(NT, X) hipLaunchKernelGGL(gemm_w4x2_kernel_##NT##_##X, grid, dim3(256), 0, stream, p)
+
+// x2 = 1 (split weights, p.B) or 2 (plain half weights, p.Bh / p.ldbh); preconditions: excel_gemm_w4_supported(p, nt_m, x2)
+int excel_launch_gemm_w4x2(const GemmBfArgs& p, int nt_m, int x2, hipStream_t stream) {
+    EXCEL_CHECK_ARG(p.w_lo_zero, "gemm_w4x2: the weight operand must be declared fp16-valued (w_lo_zero)");
+    EXCEL_CHECK_ARG(excel_gemm_w4_supported(p, nt_m, x2), "gemm_w4x2: unsupported problem (vector epilogue, batch 1, K %% 64 (128) == 0, operands below 2 GB)");
+    const dim3 grid(cdiv(p.M, 32 * nt_m) * cdiv(p.N, w4::BN));
+    if (x2 == 2) {
+        if (nt_m == 10) W4X2_LAUNCH(10, 2);
+        else if (nt_m == 8) W4X2_LAUNCH(8, 2);
+        else W4X2_LAUNCH(5, 2);
+    } else {
+        if (nt_m == 8) W4X2_LAUNCH(8, 1);
+        else W4X2_LAUNCH(5, 1);
+    }
+    EXCEL_CHECK_LAUNCH("gemm_w4x2");
+    return EXCEL_OK;
+}
+
+}  // namespace EXCEL_SPLIT_NS

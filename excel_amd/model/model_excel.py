@@ -125,7 +125,9 @@ class ExCEL_model:
         (IEEE-half planes, 22 bits) stays within 1.4x of fp32 there at ~2.5 % less throughput.  This runs ViT + CAM of `img`
         [b,3,S,S] in the current mode and in exact fp32 ("f32") and compares the attr maps - the quantity the gate is stated on.
         With `fallback`, a difference above `tol` (half the gate by default) moves this model one step down the ladder
-        bf16x3 -> f16x3 -> f32 (re-checked at every step) for everything that follows.
+        bf16x3 -> f16x3 -> f32 (re-checked at every step) for everything that follows.  On fp16-VALUED weights (every published CLIP
+        archive) the f16 rung is "f16x2": the bits of f16x3 with two MFMAs per product in the nn.Linear GEMMs - it is the mode such a
+        model starts in (ops.VitHandle: "auto"), so its ladder is f16x2 -> f32.
         `reduce(diff) -> diff` shares a rung's verdict between the ranks of a job (infer_lam: all-reduce MAX, a NaN counts as +inf);
         it is called exactly once per rung on EVERY rank, also on a rank whose shard is empty (`img=None`: contributes 0), so the
         collective sequence is identical everywhere.  This is the one implementation of the ladder.
@@ -142,7 +144,8 @@ class ExCEL_model:
             finally:
                 h.set_gemm_mode(before)
         ladder, after = [], before
-        for mode in (["bf16x3", "f16x3"] if before == "bf16x3" else [before]):
+        f16_rung = "f16x2" if getattr(h, "weights_fp16_exact", lambda: False)() else "f16x3"
+        for mode in (["bf16x3", f16_rung] if before == "bf16x3" else [before]):
             diff = 0.0
             if img is not None:
                 h.set_gemm_mode(mode)

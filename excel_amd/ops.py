@@ -54,7 +54,7 @@ def gemm(A, Bm, bias=None, residual=None, act=0, b_kmajor=True):
     return out if batched else out[0]
 
 
-GEMM_MODES = {"f32": 0, "bf16x3": 1, "f16x3": 2}      # excel_vit_set_gemm_mode (include/excel_hip.h)
+GEMM_MODES = {"f32": 0, "bf16x3": 1, "f16x3": 2, "f16x2": 3}      # excel_vit_set_gemm_mode (include/excel_hip.h)
 
 
 def split_bf16(x, f16=False):
@@ -75,6 +75,28 @@ def gemm_bf16x3(A_split, W_split, bias=None, residual=None, act=0, split_out=Fal
     fn = lib().excel_gemm_f16x3 if f16 else lib().excel_gemm_bf16x3
     check(fn(_p(A_split, torch.int16), _p(W_split, torch.int16), _p(out), _p(bias), _p(residual), M, N, K, act,
              1 if split_out else 0, _stream()), "excel_gemm_f16x3" if f16 else "excel_gemm_bf16x3")
+    return out.view(torch.int16).view(M, 2, N) if split_out else out
+
+
+def pack_f16(x):
+    """fp32 [R,K] -> (the hi plane as a plain IEEE-half matrix [R,K] (int16 bit patterns), number of elements NOT representable in
+    half).  The second value is 0 exactly when `x` is fp16-valued - the precondition of gemm_f16x2 (every published CLIP archive)."""
+    x = f32c(x)
+    R, K = x.shape
+    out = torch.empty((R, K), dtype=torch.int16, device=x.device)
+    cnt = torch.zeros(1, dtype=torch.int64, device=x.device)
+    check(lib().excel_pack_f16(_p(x), _p(out, torch.int16), R, K, _p(cnt, torch.int64), _stream()), "excel_pack_f16")
+    return out, int(cnt.item())
+
+
+def gemm_f16x2(A_split, W_split, W_half=None, bias=None, residual=None, act=0, split_out=False):
+    """gemm_bf16x3(..., f16=True) for fp16-VALUED weights (the lo plane of W_split is all zero): two MFMAs per product, the same bits.
+    W_half (pack_f16 of the same weights) lets the large-tile kernel stream half the weight bytes."""
+    M, _, K = A_split.shape
+    N = W_split.shape[0]
+    out = torch.empty((M, N), dtype=torch.float32, device=A_split.device)
+    check(lib().excel_gemm_f16x2(_p(A_split, torch.int16), _p(W_split, torch.int16), _p(W_half, torch.int16) if W_half is not None else None,
+                                 _p(out), _p(bias), _p(residual), M, N, K, act, 1 if split_out else 0, _stream()), "excel_gemm_f16x2")
     return out.view(torch.int16).view(M, 2, N) if split_out else out
 
 
@@ -137,10 +159,14 @@ class VitHandle:
             check(lib().excel_vit_create(C.byref(cfg), C.byref(w), C.byref(self._h)), "excel_vit_create")
             # numerics of the linear layers and attention scores: "bf16x3" (default; fp32 operands as bf16 hi+lo, 3 bf16
             # MFMAs per product, CAM error ~1e-5 against exact fp32 on well-conditioned weights), "f16x3" (IEEE-half planes: fp32-grade
-            # results, ~2.5 % slower) or "f32" (exact fp32 MFMA).  EXCEL_GEMM_MODE overrides.
-            mode = gemm_mode or os.environ.get("EXCEL_GEMM_MODE", "bf16x3")
+            # results, ~2.5 % slower), "f16x2" (f16x3 with two MFMAs per product in the nn.Linear GEMMs - needs fp16-VALUED weights, which
+            # every published CLIP archive has: bit-identical to f16x3 there and faster than bf16x3) or "f32" (exact fp32 MFMA).
+            # Default ("auto"): f16x2 when the weights allow it, else bf16x3.  EXCEL_GEMM_MODE overrides.
+            mode = gemm_mode or os.environ.get("EXCEL_GEMM_MODE", "auto")
             if mode != "f32" and (width % 32 or (3 * patch * patch) % 32):
                 mode = "f32"
+            if mode == "auto":
+                mode = "f16x2" if self.weights_fp16_exact() else "bf16x3"
             self.set_gemm_mode(mode)
         self._ws = {}          # one workspace per launch stream: the same weights can serve concurrent streams
 
@@ -153,8 +179,17 @@ class VitHandle:
             pass
 
     def set_gemm_mode(self, mode):
-        """'f32' (exact fp32 MFMA), 'bf16x3' (split-bf16 operands, 3 bf16 MFMAs per product) or 'f16x3' (IEEE-half planes)."""
+        """'f32' (exact fp32 MFMA), 'bf16x3' (split-bf16 operands, 3 bf16 MFMAs per product), 'f16x3' (IEEE-half planes) or 'f16x2'
+        (f16x3 with two-product weight GEMMs; raises unless weights_fp16_exact())."""
         check(lib().excel_vit_set_gemm_mode(self._h, GEMM_MODES[mode]), "excel_vit_set_gemm_mode")
+
+    def weights_fp16_exact(self):
+        """True when every GEMM weight of this handle is exactly representable in IEEE half (clip/build_model.py:72 loads the published
+        fp16 archive into the fp32 model unchanged, so real CLIP weights are)."""
+        rc = lib().excel_vit_weights_fp16_exact(self._h)
+        if rc < 0:
+            check(rc, "excel_vit_weights_fp16_exact")
+        return rc == 1
 
     def gemm_mode(self):
         return {v: k for k, v in GEMM_MODES.items()}[lib().excel_vit_get_gemm_mode(self._h)]
@@ -529,7 +564,7 @@ def patch_text_cam(x_raw, text_features, num_fg=None, t=2.0, want_full=False, wa
     if full is None and sl is None:
         raise ValueError("patch_text_cam: nothing to compute (want_full=False and num_fg=None)")
     ws = _ws(lib().excel_patch_text_cam_workspace_bytes(B, N, Cc, T), dev)
-    check(lib().excel_patch_text_cam(_p(x_raw), _p(text_features), B, N, Cc, T, F_, float(t), GEMM_MODES[mode], _p(full), _p(sl),
+    check(lib().excel_patch_text_cam(_p(x_raw), _p(text_features), B, N, Cc, T, F_, float(t), GEMM_MODES["f16x3" if mode == "f16x2" else mode], _p(full), _p(sl),
                                      _p(feats), _p(ws, torch.uint8), _stream()), "excel_patch_text_cam")
     return full, sl, feats
 

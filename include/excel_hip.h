@@ -52,6 +52,17 @@ int excel_gemm_bf16x3(const void* A_split, const void* W_split, float* C, const 
 int excel_split_f16(const float* in, void* out, long long rows, int K, void* stream);
 int excel_gemm_f16x3(const void* A_split, const void* W_split, float* C, const float* bias, const float* residual,
                      int M, int N, int K, int act, int split_out, void* stream);
+/* "f16x2": the f16x3 GEMM for fp16-VALUED weights - two matrix-core instructions per product.  The published CLIP archives store
+ * half-precision parameters and the reference loads them into its fp32 model unchanged (clip/build_model.py:72, clip/clip.py:138-154),
+ * so the lo plane of every nn.Linear weight is exactly zero and the a.hi x w.lo pass of the three-product scheme multiplies zeros; it
+ * is not issued.  The results are bit-identical to excel_gemm_f16x3 on the same operands.
+ *   excel_pack_f16: fp32 [rows,K] -> the hi plane as a plain half matrix [rows,K]; adds to *inexact_dev (device, zero it first) the
+ *                   number of elements that are NOT representable in IEEE half - the mode's precondition is that count == 0.
+ *   excel_gemm_f16x2: W_split as excel_split_f16 wrote it (its lo plane must be all zero: not checked here); W_half (optional, may be
+ *                   NULL) = the excel_pack_f16 matrix of the same weights: the large-tile kernel then streams half the weight bytes. */
+int excel_pack_f16(const float* in, void* out, long long rows, int K, unsigned long long* inexact_dev, void* stream);
+int excel_gemm_f16x2(const void* A_split, const void* W_split, const void* W_half, float* C, const float* bias, const float* residual,
+                     int M, int N, int K, int act, int split_out, void* stream);
 
 /* LayerNorm over the last dim, fp32, eps as given (clip/clip_surgery_model.py:271-277). */
 int excel_layernorm(const float* x, const float* w, const float* b, float* y, int rows, int D, float eps, void* stream);
@@ -97,11 +108,18 @@ void excel_vit_destroy(excel_vit_t h);
  *       the fastest mode; its CAM error is ~12x that of fp32 arithmetic (1e-5 on well-conditioned weights);
  *   2 = "f16x3": the same scheme on IEEE-half planes (22 mantissa bits where lo stays normal): fp32-grade results (within 1.4x of fp32
  *       arithmetic's own error on every network measured), ~2.5 % slower than mode 1 (the part is power-limited), values beyond 65 504
- *       overflow.
- * Default 0, or the mode named by the environment variable EXCEL_GEMM_MODE (bf16x3 | f16x3) at create time.  Switching between 1 and
- * 2 re-splits the weights (synchronises the device). */
+ *       overflow;
+ *   3 = "f16x2": mode 2 with the nn.Linear GEMMs on two MFMAs per product (excel_gemm_f16x2 above) - available when every weight
+ *       matrix of the handle is fp16-valued (excel_vit_weights_fp16_exact; true for every published CLIP archive), refused with
+ *       EXCEL_ERR_ARG otherwise.  Bit-identical to mode 2 on such weights, and the fastest mode: a third of the GEMMs' matrix-core
+ *       work is gone.  The attention products (activation x activation) stay three-product.
+ * Default 0, or the mode named by the environment variable EXCEL_GEMM_MODE (bf16x3 | f16x3 | f16x2) at create time.  Switching between
+ * 1 and 2/3 re-splits the weights (synchronises the device). */
 int excel_vit_set_gemm_mode(excel_vit_t h, int mode);
 int excel_vit_get_gemm_mode(excel_vit_t h);
+/* 1 when every GEMM weight of the handle (in_proj, out_proj, fc1, fc2 of every block, conv1, proj) is exactly representable in IEEE
+ * half, 0 when not, < 0 on error.  The first call packs the weights (one pass over them, synchronises); the answer is cached. */
+int excel_vit_weights_fp16_exact(excel_vit_t h);
 
 size_t excel_vit_workspace_bytes(excel_vit_t h, int B, int S);
 

@@ -994,6 +994,52 @@ def test_gemm_f16x3(ops, M, N, K):
     assert np.array_equal(hi2, h16) and np.array_equal(lo2, (out - h16).astype(np.float16).astype(np.float32))      # (four-wave kernel: split_pair)
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 64, 512), (785, 2304, 768), (2100, 384, 96), (25120, 768, 768), (25120, 2304, 768), (25120, 3072, 768),
+                                   (25120, 768, 3072), (25120, 512, 768), (12560, 768, 768), (12560, 3072, 768), (16400, 768, 768),
+                                   (16400, 3072, 768), (12500, 776, 896), (12560, 768, 832)])
+def test_gemm_f16x2_equals_f16x3_bitwise(ops, M, N, K):
+    """"f16x2": fp16-VALUED weights (what every published CLIP archive holds, clip/build_model.py:72) have an all-zero lo plane, so the
+    a.hi x w.lo pass of the three-product scheme multiplies zeros and the two-product kernels leave it out.  Adding exact zeros to an fp32
+    accumulator changes nothing: every instance (the four-wave kernel on the compact half weights - 320- / 256- / 160-row tiles -, the
+    four-wave kernel on split-layout weights, the 8-wave tiles for small / ragged shapes; K = 832 is not a multiple of 128: no compact
+    instance) and every epilogue mode must reproduce the f16x3 result BIT FOR BIT, and the f16x3 result is checked against float64."""
+    rs = np.random.RandomState(M % 1000 + N + K + 2)
+    A = rs.standard_normal((M, K)).astype(np.float32)
+    W = (rs.standard_normal((N, K)) * 0.05).astype(np.float16).astype(np.float32)            # fp16-valued
+    bias = rs.standard_normal(N).astype(np.float32)
+    res = rs.standard_normal((M, N)).astype(np.float32)
+    As, Ws = ops.split_bf16(dev(A), f16=True), ops.split_bf16(dev(W), f16=True)
+    _, wlo = _unsplit_f16(host(Ws))
+    assert not wlo.any()                                                                     # the precondition, seen in the planes
+    Wh, inexact = ops.pack_f16(dev(W))
+    assert inexact == 0 and np.array_equal(host(Wh).view(np.float16).astype(np.float32), W)
+    ref = A.astype(np.float64) @ W.T.astype(np.float64)
+    db, dr = dev(bias), dev(res)
+    forms = [dict(), dict(bias=db, residual=dr, act=1), dict(bias=db, residual=dr)]
+    if N % 32 == 0:
+        forms += [dict(split_out=True), dict(bias=db, act=1, split_out=True), dict(bias=db, residual=dr, act=1, split_out=True)]
+    for kw in forms:
+        x3 = ops.gemm_bf16x3(As, Ws, f16=True, **kw)
+        for wh in (None, Wh):
+            x2 = ops.gemm_f16x2(As, Ws, wh, **kw)
+            assert torch.equal(x2, x3), (kw.keys(), wh is not None)
+    out = host(ops.gemm_f16x2(As, Ws, Wh))
+    assert maxabs(out, ref) < 1e-5 * np.sqrt(K) * 0.05 + 2e-6          # (K = 3072: 2.1e-5 measured, fp32 accumulation over 96 steps)
+
+
+def test_pack_f16_counts_inexact_values(ops):
+    """excel_pack_f16's counter: 0 exactly for fp16-valued matrices; every value with a non-zero lo plane (and a NaN) counts."""
+    rs = np.random.RandomState(5)
+    W = rs.standard_normal((96, 64)).astype(np.float16).astype(np.float32)
+    assert ops.pack_f16(dev(W))[1] == 0
+    W2 = W.copy()
+    W2[3, 5] += 2.0 ** -14
+    W2[7, 0] = 1.0e5                   # beyond the half range
+    W2[9, 9] = np.nan
+    assert ops.pack_f16(dev(W2))[1] == 3
+    assert ops.pack_f16(dev(rs.standard_normal((96, 64)).astype(np.float32)))[1] > 6000
+
+
 def test_split_f16_saturates_instead_of_overflowing(ops):
     """IEEE-half planes have a range of 65 504: the split saturates (hi = +-65504, lo = the next 65 504) instead of producing inf, so values
     up to 131 008 keep their leading bits and a product with huge activations stays finite; bf16 planes are unaffected (fp32 range)."""

@@ -1080,6 +1080,62 @@ def test_batched_pipeline_tiny_f16x3_mode_vs_oracle(gpu):
     assert res["mode_after"] == "f16x3" and res["max_abs_diff"] < 5e-4
 
 
+def test_batched_pipeline_tiny_f16x2_mode_on_fp16_valued_weights(gpu):
+    """"f16x2" (round 6): on fp16-VALUED weights - what clip/build_model.py:72 leaves in the fp32 model when it loads a published CLIP
+    archive - the nn.Linear GEMMs run two MFMAs per product.  (a) a model built on such weights starts in f16x2 by itself ("auto"), a model
+    on full-mantissa weights starts in bf16x3 and refuses f16x2; (b) the whole batched chain is BIT-IDENTICAL to the f16x3 mode on the same
+    weights (the skipped instructions multiplied zeros); (c) against the oracle on the same weights at the exact mode's tolerances;
+    (d) the numerics ladder of such a model is f16x2 -> f32."""
+    from excel_amd.model import ExCEL_model
+    from excel_amd.pipeline import TrainingFreePipeline
+    rs = np.random.RandomState(79)
+    text = rs.standard_normal((9, 64)).astype(np.float32)
+    text /= np.linalg.norm(text, axis=1, keepdims=True)
+    w = {k: (np.asarray(v, np.float32).astype(np.float16).astype(np.float32) if np.asarray(v).dtype == np.float32 else v)
+         for k, v in make_vit_weights(TINY, seed=11).items()}
+    mk = lambda sd, mode: ExCEL_model(clip_model="tiny", num_classes=5, img_size=96, mode="train", state_dict=sd, vit_cfg=TINY_KW,
+                                      text_attr=text.T.copy(), gemm_mode=mode)
+    model = mk(w, None)
+    h = model.encoder.visual.handle()
+    assert h.weights_fp16_exact() and h.gemm_mode() == "f16x2"
+    full = mk(make_vit_weights(TINY, seed=11), None)
+    hf = full.encoder.visual.handle()
+    assert not hf.weights_fp16_exact() and hf.gemm_mode() == "bf16x3"
+    with pytest.raises(RuntimeError, match="fp16-valued"):
+        hf.set_gemm_mode("f16x2")
+    assert hf.gemm_mode() == "bf16x3"
+    B, S, F = 3, 96, 4
+    imgs = rs.standard_normal((B, 3, S, S)).astype(np.float32)
+    gts = rs.randint(0, 5, (B, S, S)).astype(np.uint8)
+    cls = np.zeros((B, F), np.float32)
+    for b, c in enumerate([[0, 3], [1], [2, 1, 0]]):
+        cls[b, c] = 1
+    got = {}
+    for mode in ("f16x2", "f16x3"):
+        h.set_gemm_mode(mode)
+        pipe = TrainingFreePipeline(model, num_classes=5, smax=4)
+        labels, inter = pipe.run_batch(dev(imgs), dev(cls), dev(gts), return_intermediates=True)
+        got[mode] = (host(labels), host(inter["attr"]), host(inter["cams"]), host(pipe.hist))
+    for a2, a3 in zip(got["f16x2"], got["f16x3"]):
+        assert np.array_equal(a2, a3)
+    wo = oracle.vit.reload_self_attn(w, TINY, 6, "train")
+    ref = _oracle_batch(imgs, gts, cls, wo, TINY, text.T.copy(), F, S)
+    lab, attr, cams, _ = got["f16x2"]
+    for b in range(B):
+        k = int(cls[b].sum())
+        assert maxabs(attr[b], ref[b]["attr_maps_raw"][0]) < 2e-4
+        assert maxabs(cams[b, :k + 1], ref[b]["cams"]) < 1e-3
+        assert int((lab[b] != ref[b]["label"]).sum()) <= _label_budget(lab[b].size, "f32") + 4
+    h.set_gemm_mode("f16x2")
+    res = model.check_numerics(dev(imgs))
+    assert res["mode_before"] == res["mode_after"] == "f16x2" and res["max_abs_diff"] < 5e-4 and [m for m, _ in res["ladder"]] == ["f16x2"]
+    res = model.check_numerics(dev(imgs), tol=0.0)                 # nothing passes a zero tolerance: f16x2 -> f32 (no f16x3 rung: same bits)
+    assert res["mode_after"] == "f32" and h.gemm_mode() == "f32"
+    h.set_gemm_mode("bf16x3")
+    res = model.check_numerics(dev(imgs), tol=1e-7)                # from bf16x3 the f16 rung of such a model is f16x2
+    assert [m for m, _ in res["ladder"]] == ["bf16x3", "f16x2"]
+
+
 def test_device_feeder_hands_out_batches_and_closes(gpu):
     """datasets/loader.DeviceFeeder: the device tensors it hands out equal the host batches; leaving the loop early (break) or dropping
     the feeder right after the last batch stops the staging thread and waits for the consumer's kernels before the ring is freed
