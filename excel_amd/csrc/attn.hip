@@ -420,12 +420,25 @@ __device__ __forceinline__ void rowpass_body_bf(const RowpassArgs& p, float* sme
             // {16ks+4kh+0..3, 16ks+8+4kh+0..3}: the V operand (lane = d) takes exactly those two groups of 4 consecutive keys.
             // hi = p truncated to bf16 (bit mask), lo = bf16(p - hi): p - hi is exact, so hi + lo keeps 16 mantissa bits.
             splitx8 ph[2], pl[2];
+#ifdef EXCEL_SPLIT_F16
+            {   // IEEE half: probabilities need neither the saturation nor the NaN test of split_hi (common.h: split_pair_bounded)
+                unsigned phu[2][4], plu[2][4];
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) split_pair_bounded(s[e], s[e + 1], phu[e >> 3][(e & 7) >> 1], plu[e >> 3][(e & 7) >> 1]);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    ph[q] = __builtin_bit_cast(splitx8, uint4{phu[q][0], phu[q][1], phu[q][2], phu[q][3]});
+                    pl[q] = __builtin_bit_cast(splitx8, uint4{plu[q][0], plu[q][1], plu[q][2], plu[q][3]});
+                }
+            }
+#else
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const float hf = __uint_as_float(__float_as_uint(s[e]) & 0xFFFF0000u);
                 ph[e >> 3][e & 7] = split_hi(hf);
                 pl[e >> 3][e & 7] = split_hi(s[e] - hf);
             }
+#endif
             // lane (d = 32 dt + r, kh): sub-tile 2 dt + (r >> 4), its column r & 15; the 16 lanes of a group address the 16 row segments
             // (key = k0 + i / 4, d quarter i % 4) of the [4 keys][16 d] block whose column they receive
             const unsigned vb = ring_b + (stage * STAGE_EL + KT_EL) * 2 + ((lane >> 4) & 1) * VSUB + (4 * kh + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;

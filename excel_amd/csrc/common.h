@@ -187,27 +187,24 @@ typedef __bf16 split_t;
 #endif
 typedef split_t splitx8 __attribute__((ext_vector_type(8)));
 typedef split_t splitx4 __attribute__((ext_vector_type(4)));
-// fp32 -> one 16-bit plane (hi = split_hi(x), lo = split_hi(x - hi)).  IEEE half saturates at +-65 504 instead of becoming inf: lo then
-// carries the next 65 504, so values up to 131 008 keep 11+ bits and anything beyond is clamped - a finite, visibly wrong product that
-// check_numerics catches, not an inf; a NaN input stays NaN in both planes; bf16 has the fp32 range.
-__device__ __forceinline__ split_t split_hi(float x) {
-#ifdef EXCEL_SPLIT_F16
-    // v_med3_f32 with IEEE mode on returns a FINITE +-65 504 for a NaN input: keep the NaN (check_numerics and the GEMM self-check rely on
-    // a NaN of the fast path failing the comparison, not passing as a finite difference)
-    return (split_t)(x != x ? x : __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f));
-#else
-    return (split_t)x;
-#endif
-}
+// fp32 -> one 16-bit plane (hi = split_hi(x), lo = split_hi(x - hi)): a plain round-to-nearest conversion for both types.  IEEE half has a
+// range of 65 504: beyond it hi becomes +-inf, lo = x - hi the opposite infinity, and every product they enter is a NaN - an overflow of
+// the f16 modes is LOUD (check_numerics compares NaN as a failure and moves to exact fp32), never a finite wrong number; a NaN input
+// stays NaN in both planes; bf16 has the fp32 range.  (Rounds 4-5 saturated instead - v_med3 + a NaN test per value, 18 VALU
+// operations per pair of values against 6 - which made every f16 epilogue and the f16 row pass measurably slower than their bf16 twins;
+// none of the split tensors of the path - LayerNorm / GELU outputs, q|k|v, probabilities, A_sum, weights - comes near the range.)
+__device__ __forceinline__ split_t split_hi(float x) { return (split_t)x; }
 // Two values at once -> packed planes (low 16 bits = a's plane value, high 16 bits = b's): hi2 = {hi(a), hi(b)}, lo2 = {lo(a), lo(b)}.  bf16:
 // five instructions for the pair (v_cvt_pk_bf16_f32, shift, mask, v_pk_add_f32, v_cvt_pk_bf16_f32) and the result is already in
 // store order - the element-at-a-time form costs ~5.5 instructions per element plus a v_perm to pack.  Same bits as split_hi.
 __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi2, unsigned& lo2) {
 #ifdef EXCEL_SPLIT_F16
-    const split_t ha = split_hi(a), hb = split_hi(b);
-    const split_t la = split_hi(a - (float)ha), lb = split_hi(b - (float)hb);
-    hi2 = (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
-    lo2 = (unsigned)__builtin_bit_cast(unsigned short, la) | ((unsigned)__builtin_bit_cast(unsigned short, lb) << 16);
+    typedef float f2_ __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2_ __attribute__((ext_vector_type(2)));
+    const f2_ v = {a, b};
+    const h2_ h = __builtin_convertvector(v, h2_);
+    hi2 = __builtin_bit_cast(unsigned, h);
+    lo2 = __builtin_bit_cast(unsigned, __builtin_convertvector(v - __builtin_convertvector(h, f2_), h2_));
 #else
     typedef float f2_ __attribute__((ext_vector_type(2)));
     typedef __bf16 b2_ __attribute__((ext_vector_type(2)));
@@ -215,6 +212,27 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi2, unsi
     hi2 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2_));
     const f2_ back = {__uint_as_float(hi2 << 16), __uint_as_float(hi2 & 0xffff0000u)};
     lo2 = __builtin_bit_cast(unsigned, __builtin_convertvector(v - back, b2_));
+#endif
+}
+// Split of values known to be FINITE AND INSIDE the 16-bit type's range (softmax probabilities): hi = the leading bits of x cut with a bit
+// mask - exactly representable, so its conversion is exact in every rounding mode and needs neither the saturation nor the NaN test of
+// split_hi - and lo = rne(x - hi) (the difference is exact in fp32).  Two values -> packed planes.  IEEE half: 11 + 11 significant bits
+// (mask 0xFFFFE000, v_cvt_pkrtz_f16_f32 for the pair); bf16: 8 + 8 (mask 0xFFFF0000).  ~3.5 VALU operations per value; the checked
+// split_hi form costs 10 for IEEE half (round 6: it was what made the f16 row pass 17 % slower than the bf16 one).
+__device__ __forceinline__ void split_pair_bounded(float a, float b, unsigned& hi2, unsigned& lo2) {
+#ifdef EXCEL_SPLIT_F16
+    typedef _Float16 h2_ __attribute__((ext_vector_type(2)));
+    const float ha = __uint_as_float(__float_as_uint(a) & 0xFFFFE000u), hb = __uint_as_float(__float_as_uint(b) & 0xFFFFE000u);
+    hi2 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ha, hb));
+    const h2_ l = {(_Float16)(a - ha), (_Float16)(b - hb)};
+    lo2 = __builtin_bit_cast(unsigned, l);
+#else
+    typedef float f2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 b2_ __attribute__((ext_vector_type(2)));
+    const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+    hi2 = (ua >> 16) | (ub & 0xFFFF0000u);
+    const f2_ d = {a - __uint_as_float(ua & 0xFFFF0000u), b - __uint_as_float(ub & 0xFFFF0000u)};
+    lo2 = __builtin_bit_cast(unsigned, __builtin_convertvector(d, b2_));
 #endif
 }
 typedef float f32x2 __attribute__((ext_vector_type(2)));

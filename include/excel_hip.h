@@ -108,7 +108,7 @@ void excel_vit_destroy(excel_vit_t h);
  *       the fastest mode; its CAM error is ~12x that of fp32 arithmetic (1e-5 on well-conditioned weights);
  *   2 = "f16x3": the same scheme on IEEE-half planes (22 mantissa bits where lo stays normal): fp32-grade results (within 1.4x of fp32
  *       arithmetic's own error on every network measured), ~2.5 % slower than mode 1 (the part is power-limited), values beyond 65 504
- *       overflow;
+ *       overflow LOUDLY (hi = inf, lo = -inf: every product they enter is a NaN, never a finite wrong number);
  *   3 = "f16x2": mode 2 with the nn.Linear GEMMs on two MFMAs per product (excel_gemm_f16x2 above) - available when every weight
  *       matrix of the handle is fp16-valued (excel_vit_weights_fp16_exact; true for every published CLIP archive), refused with
  *       EXCEL_ERR_ARG otherwise.  Bit-identical to mode 2 on such weights, and the fastest mode: a third of the GEMMs' matrix-core

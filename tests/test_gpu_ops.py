@@ -1040,16 +1040,26 @@ def test_pack_f16_counts_inexact_values(ops):
     assert ops.pack_f16(dev(rs.standard_normal((96, 64)).astype(np.float32)))[1] > 6000
 
 
-def test_split_f16_saturates_instead_of_overflowing(ops):
-    """IEEE-half planes have a range of 65 504: the split saturates (hi = +-65504, lo = the next 65 504) instead of producing inf, so values
-    up to 131 008 keep their leading bits and a product with huge activations stays finite; bf16 planes are unaffected (fp32 range)."""
-    x = np.array([[7.0e4, -1.2e5, 3.0e5, 6.0e4] + [1.0] * 28], np.float32)
+def test_split_f16_overflow_is_loud(ops):
+    """IEEE-half planes have a range of 65 504.  Inside it the split is the plain round-to-nearest pair; beyond it hi becomes +-inf and
+    lo the opposite infinity, so every product the value enters is a NaN - an overflow of the f16 modes cannot pass as a finite wrong
+    number (ExCEL_model.check_numerics treats NaN as a failed rung and moves to exact fp32); a NaN input stays NaN in both planes;
+    bf16 planes are unaffected (fp32 range).  (Rounds 4-5 saturated instead, at three times the VALU cost per value.)"""
+    x = np.array([[7.0e4, -1.2e5, 6.0e4, np.nan, 65504.0] + [1.0] * 27], np.float32)
     hi, lo = _unsplit_f16(host(ops.split_bf16(dev(x), f16=True)))
-    assert np.all(np.isfinite(hi)) and np.all(np.isfinite(lo))
-    assert hi[0, 0] == 65504.0 and abs((hi + lo)[0, 0] - 7.0e4) <= 32 and abs((hi + lo)[0, 1] + 1.2e5) <= 64
-    assert (hi + lo)[0, 2] == 2 * 65504.0 and abs((hi + lo)[0, 3] - 6.0e4) <= 1
-    hb, lb = _unsplit(host(ops.split_bf16(dev(x))))
-    assert np.max(np.abs((hb.astype(np.float64) + lb) - x) / np.abs(x)) < 2.0 ** -16
+    assert hi[0, 0] == np.inf and lo[0, 0] == -np.inf and hi[0, 1] == -np.inf and lo[0, 1] == np.inf
+    assert abs((hi + lo)[0, 2] - 6.0e4) <= 1 and hi[0, 4] == 65504.0 and lo[0, 4] == 0.0
+    assert np.isnan(hi[0, 3]) and np.isnan(lo[0, 3])
+    assert np.array_equal(hi[0, 5:], np.ones(27, np.float32)) and not lo[0, 5:].any()
+    # the product of an overflowing row is NaN, the rows next to it are untouched
+    A = np.ones((64, 32), np.float32)
+    A[3, 7] = 1.0e5
+    W = np.full((64, 32), 0.5, np.float32)
+    out = host(ops.gemm_bf16x3(ops.split_bf16(dev(A), f16=True), ops.split_bf16(dev(W), f16=True), f16=True))
+    assert np.all(np.isnan(out[3])) and np.array_equal(np.delete(out, 3, 0), np.full((63, 64), 16.0, np.float32))
+    xb = np.where(np.isnan(x), np.float32(1.0), x)
+    hb, lb = _unsplit(host(ops.split_bf16(dev(xb))))
+    assert np.max(np.abs((hb.astype(np.float64) + lb) - xb) / np.abs(xb)) < 2.0 ** -16
 
 
 def test_vit_b16_448_bf16x3_mode(ops):
