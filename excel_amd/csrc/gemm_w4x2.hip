@@ -30,12 +30,38 @@ namespace EXCEL_SPLIT_NS {
 W4X2_KERNEL(8, 1) W4X2_KERNEL(5, 1)
 W4X2_KERNEL(10, 2) W4X2_KERNEL(8, 2) W4X2_KERNEL(5, 2)
 #define W4X2_LAUNCH(NT, X) hipLaunchKernelGGL(gemm_w4x2_kernel_##NT##_##X, grid, dim3(256), 0, stream, p)
+#ifdef EXCEL_DEV
+// development arms of the 320-row compact-weight instance (EXCEL_W4_DBG, as in gemm_w4.hip): 1 no LDS-DMA after the prologue, 2 no fragment
+// reads, 4 no barrier, 8 no epilogue, 16 no MFMAs, 128 cycle / phase stamps into the `bias` buffer (tools_dev/w4_stamps.py x2)
+#define W4X2_KERNEL_D(DBG) __global__ __launch_bounds__(256, 1) void gemm_w4x2_kernel_10_2_d##DBG(GemmBfArgs p) { gemm_w4_body<10, DBG, 2>(p); }
+W4X2_KERNEL_D(1) W4X2_KERNEL_D(2) W4X2_KERNEL_D(4) W4X2_KERNEL_D(8) W4X2_KERNEL_D(9) W4X2_KERNEL_D(10) W4X2_KERNEL_D(15) W4X2_KERNEL_D(128) W4X2_KERNEL_D(136) W4X2_KERNEL_D(143)
+#define W4X2_LAUNCH_D(DBG) hipLaunchKernelGGL(gemm_w4x2_kernel_10_2_d##DBG, grid, dim3(256), 0, stream, p)
+#endif
 
 // x2 = 1 (split weights, p.B) or 2 (plain half weights, p.Bh / p.ldbh); preconditions: excel_gemm_w4_supported(p, nt_m, x2)
 int excel_launch_gemm_w4x2(const GemmBfArgs& p, int nt_m, int x2, hipStream_t stream) {
     EXCEL_CHECK_ARG(p.w_lo_zero, "gemm_w4x2: the weight operand must be declared fp16-valued (w_lo_zero)");
     EXCEL_CHECK_ARG(excel_gemm_w4_supported(p, nt_m, x2), "gemm_w4x2: unsupported problem (vector epilogue, batch 1, K %% 64 (128) == 0, operands below 2 GB)");
     const dim3 grid(cdiv(p.M, 32 * nt_m) * cdiv(p.N, w4::BN));
+#ifdef EXCEL_DEV
+    static const int dbg = getenv("EXCEL_W4_DBG") ? atoi(getenv("EXCEL_W4_DBG")) : 0;
+    if (x2 == 2 && nt_m == 10 && dbg) {
+        switch (dbg) {
+            case 1: W4X2_LAUNCH_D(1); break;
+            case 2: W4X2_LAUNCH_D(2); break;
+            case 4: W4X2_LAUNCH_D(4); break;
+            case 8: W4X2_LAUNCH_D(8); break;
+            case 9: W4X2_LAUNCH_D(9); break;
+            case 10: W4X2_LAUNCH_D(10); break;
+            case 15: W4X2_LAUNCH_D(15); break;
+            case 128: W4X2_LAUNCH_D(128); break;
+            case 136: W4X2_LAUNCH_D(136); break;
+            default: W4X2_LAUNCH_D(143); break;
+        }
+        EXCEL_CHECK_LAUNCH("gemm_w4x2 (dev arm)");
+        return EXCEL_OK;
+    }
+#endif
     if (x2 == 2) {
         if (nt_m == 10) W4X2_LAUNCH(10, 2);
         else if (nt_m == 8) W4X2_LAUNCH(8, 2);

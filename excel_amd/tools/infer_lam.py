@@ -72,10 +72,10 @@ def get_parser():
                         "at ~350 ms each on ROCm 7.2, so the default avoids fork")
     p.add_argument("--clip_root", default=None, type=str, help="directory holding the published CLIP archive (ViT-B-16.pt); default $EXCEL_CLIP_ROOT, ~/.cache/clip")
     p.add_argument("--bpe_path", default=None, type=str, help="CLIP's bpe_simple_vocab_16e6.txt.gz (default $EXCEL_BPE_VOCAB)")
-    p.add_argument("--gemm_mode", default=None, type=str, help="bf16x3 (default) | f16x3 | f32")
+    p.add_argument("--gemm_mode", default=None, type=str, help="auto (default: f16x2 when every GEMM weight is fp16-valued - every published CLIP archive -, else bf16x3) | bf16x3 | f16x3 | f16x2 | f32")
     p.add_argument("--gemm_check", default=True, type=_bool,
                    help="before the loop, run the first few images in the chosen fast mode AND in exact fp32 and compare the CAMs; above "
-                        "--gemm_check_tol the run moves down the ladder bf16x3 -> f16x3 -> f32 (ill-conditioned weights; "
+                        "--gemm_check_tol the run moves down the ladder bf16x3 -> f16x3 (f16x2 on fp16-valued weights) -> f32 (ill-conditioned weights; "
                         "ExCEL_model.check_numerics)")
     p.add_argument("--gemm_check_tol", default=5e-4, type=float)
     p.add_argument("--cpu_affinity", default="auto", choices=["auto", "off"],
@@ -465,6 +465,7 @@ def validate(args=None, dataset=None, pipe=None):
                            "images_total": int(len(dataset)), "seconds_rank0": round(secs, 3), "images_per_s_rank0": round(nimg / secs, 2),
                            "images_per_s_job": round(len(dataset) / secs, 2), "miou": float(score["miou"]),
                            "per_rank_hist_mass": [int(x) for x in per_rank.reshape(per_rank.shape[0], -1).sum(1).tolist()],
+                           "hist_total": [[int(v) for v in row] for row in total.cpu().tolist()],       # the gathered confusion matrix itself
                            "batch_size": args.batch_size, "ragged": bool(args.ragged_batches), "resize_size": args.resize_size}, f)
     if getattr(args, "crf_post", False) and getattr(args, "data_folder", None):             # :173-174
         crf_score, crf_total = crf_proc(args, rank, world, device)

@@ -2,7 +2,10 @@
 (tools/infer_lam.py:133,164-167 in the reference: init_process_group + rank-strided shards) - sent through the real RCCL backend on the
 GPU box.  The box has one GPU, so the group has one rank; the call path (torch.distributed "nccl" = RCCL, device tensors, the same
 `gather_hists`) is the one N > 1 uses.  Each case runs in its own process: a process group is process-global state.
-The N > 1 control flow itself is covered on CPU (gloo, world 2 / 4 / 8) in tests/test_host_cpu.py."""
+The N > 1 control flow itself is covered on CPU (gloo, world 2 / 4 / 8) in tests/test_host_cpu.py.
+Round 6: `test_bench_and_harness_over_rccl[2]` ARMS ITSELF on a box with two or more GPUs (bench.py --gpus 2 launched bare, and the
+infer_lam harness at world 2 against its own world-1 run) and is skipped with the reason on a one-GPU box; its world-1 twin runs the
+same commands and the same checks everywhere, so the armed case cannot fail on plumbing the day a multi-GPU box runs `pytest -m gpu`."""
 import json
 import os
 import socket
@@ -91,3 +94,48 @@ def test_bench_under_torch_distributed_run_one_rank():
     print("bench under torchrun:", {k: out[k] for k in ("value", "n_gpus", "rccl_ranks", "rccl", "per_rank_hist_mass")})
     assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["rccl"].startswith("all_gather")
     assert len(out["per_rank_hist_mass"]) == 1 and out["per_rank_hist_mass"][0] > 0 and out["value"] > 0
+
+
+def _infer_lam(world, json_path, n_images=24, batch=4):
+    """The harness on `n_images` seeded synthetic 448^2 samples, one rank per GPU under torch.distributed.run (world 1: the same launcher
+    line with one rank) -> rank 0's JSON record."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "-m", "excel_amd.tools.infer_lam", "--synthetic", str(n_images), "--batch_size", str(batch),
+           "--json_out", json_path]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=_env(), cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    return json.load(open(json_path))
+
+
+@pytest.mark.timeout(3000)
+@pytest.mark.parametrize("world", [1, 2])
+def test_bench_and_harness_over_rccl(world, tmp_path):
+    """(a) `python bench.py --gpus W` launched BARE (W = 2: it re-executes itself under torch.distributed.run, bench.self_launch_argv; the
+    driver's own N > 1 line is the one-rank test above): the JSON line must say that the collective spanned W ranks and carry W non-zero
+    per-rank histogram masses.  (b) tools/infer_lam.py:133,164-167: the harness at world W over RCCL - rank-strided shards, ONE all-gather of
+    the [21,21] int64 confusion matrix - must gather exactly the matrix a one-rank run computes over the same list (every image scored
+    once, by exactly one rank)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    n = torch.cuda.device_count()
+    if n < world:
+        pytest.skip(f"needs {world} GPUs for a {world}-rank RCCL group, this box has {n} (the multi-rank control flow is covered over gloo at "
+                    "world 2 / 4 / 8 in tests/test_host_cpu.py, the RCCL call path with one rank above)")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--cpu-images", "0",
+           "--ragged-images", "0", "--power-seconds", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=_env(), cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    print("bench --gpus", world, {k: out[k] for k in ("value", "n_gpus", "rccl_ranks", "rccl", "per_rank_hist_mass")})
+    assert out["n_gpus"] == world and out["rccl_ranks"] == world and out["scaling"] == "weak" and out["value"] > 0
+    assert len(out["per_rank_hist_mass"]) == world and all(m > 0 for m in out["per_rank_hist_mass"])
+    one = _infer_lam(1, str(tmp_path / "w1.json"))
+    assert one["world"] == 1 and one["images_total"] == 24 and len(one["per_rank_hist_mass"]) == 1
+    if world == 1:
+        assert sum(map(sum, one["hist_total"])) == one["per_rank_hist_mass"][0] > 0
+        return
+    many = _infer_lam(world, str(tmp_path / f"w{world}.json"))
+    assert many["world"] == world and many["rccl_ranks"] == world and many["images_total"] == 24
+    assert len(many["per_rank_hist_mass"]) == world and all(m > 0 for m in many["per_rank_hist_mass"])
+    assert sum(many["per_rank_hist_mass"]) == one["per_rank_hist_mass"][0]
+    assert many["hist_total"] == one["hist_total"]              # the gathered matrix == the one-rank matrix of the same list, integer-exact

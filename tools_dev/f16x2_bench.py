@@ -3,7 +3,11 @@ python tools_dev/f16x2_bench.py [reps]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+if os.environ.get("EXCEL_AB_LIB"):      # A/B a differently built library on the same box
+    import excel_amd._lib as _L
+    _L.LIB_PATH = os.path.abspath(os.environ["EXCEL_AB_LIB"])
 from excel_amd import ops
+ONLY = os.environ.get("F16X2_ONLY")      # "half": time only the compact-weight two-product kernel (A/B runs)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 SHAPES = [(25120, 768, 768, "proj+res"), (25120, 2304, 768, "qkv"), (25120, 3072, 768, "fc1"), (25120, 768, 3072, "fc2+res"),
           (25120, 512, 768, "final proj"), (12560, 768, 768, "b16 proj"), (12560, 2304, 768, "b16 qkv"), (12560, 3072, 768, "b16 fc1"),
@@ -30,6 +34,9 @@ for M, N, K, name in SHAPES:
     Ab, Wb = ops.split_bf16(A), ops.split_bf16(W)
     t = {}
     for rnd in range(2):
+        if ONLY == "half":
+            t.setdefault("f16x2/half", []).append(timeit(lambda: ops.gemm_f16x2(As, Ws, Wh, bias=bias, residual=res, act=act, split_out=so)))
+            continue
         t.setdefault("bf16x3", []).append(timeit(lambda: ops.gemm_bf16x3(Ab, Wb, bias=bias, residual=res, act=act, split_out=so)))
         t.setdefault("f16x3", []).append(timeit(lambda: ops.gemm_bf16x3(As, Ws, bias=bias, residual=res, act=act, split_out=so, f16=True)))
         t.setdefault("f16x2/split", []).append(timeit(lambda: ops.gemm_f16x2(As, Ws, None, bias=bias, residual=res, act=act, split_out=so)))

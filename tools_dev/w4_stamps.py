@@ -10,21 +10,29 @@ from excel_amd import ops
 from excel_amd._lib import lib
 M, N, K = (int(x) for x in sys.argv[1:4]) if len(sys.argv) > 3 else (25120, 2304, 768)
 ACT = int(sys.argv[4]) if len(sys.argv) > 4 else 0          # 1: QuickGELU (the fc1 form)
+X2 = len(sys.argv) > 5 and sys.argv[5] == "x2"              # the two-product compact-weight kernel (gemm_w4x2.hip) on fp16-valued weights
+NMFMA = 160 if X2 else 240
 g = torch.Generator(device="cuda").manual_seed(0)
 A = torch.randn(M, K, device="cuda", generator=g); W = torch.randn(N, K, device="cuda", generator=g) * 0.05
-As, Ws = ops.split_bf16(A), ops.split_bf16(W)
+if X2:
+    W = W.half().float()
+    As, Ws = ops.split_bf16(A, f16=True), ops.split_bf16(W, f16=True)
+    Wh, _bad = ops.pack_f16(W)
+else:
+    As, Ws = ops.split_bf16(A), ops.split_bf16(W)
 out = torch.empty((M, 2 * N), dtype=torch.float32, device="cuda")
 stamps = torch.zeros(max(N, 8192), dtype=torch.float32, device="cuda")
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 for _ in range(3):
-    lib().excel_gemm_bf16x3(As.data_ptr(), Ws.data_ptr(), out.data_ptr(), stamps.data_ptr(), None, M, N, K, ACT, 1, st)
+    if X2: lib().excel_gemm_f16x2(As.data_ptr(), Ws.data_ptr(), Wh.data_ptr(), out.data_ptr(), stamps.data_ptr(), None, M, N, K, ACT, 1, st)
+    else: lib().excel_gemm_bf16x3(As.data_ptr(), Ws.data_ptr(), out.data_ptr(), stamps.data_ptr(), None, M, N, K, ACT, 1, st)
 torch.cuda.synchronize()
 t = stamps.view(torch.int64)[: 2 * (K // 32)].cpu().numpy().reshape(-1, 2)
 rt = stamps.view(torch.int64)[256: 256 + K // 32].cpu().numpy()
 step = t[1:, 0] - t[:-1, 0]
 print("  shader clock over the k-loop: %d cycles in %d ticks of the 100 MHz real-time counter -> %.2f GHz" % (t[-1, 0] - t[0, 0], rt[-1] - rt[0], (t[-1, 0] - t[0, 0]) / max(rt[-1] - rt[0], 1) * 0.1))
 print("dbg", os.environ.get("EXCEL_W4_DBG"), "shape", M, N, K, "| cycles per step (barrier arrival to next barrier arrival):", step.tolist())
-print("  mean step %.0f (240 MFMAs x 16 = 3840), barrier wait per step mean %.0f, max %.0f; s_memtime ticks are at 100 MHz x? check: total %.0f ticks" % (step.mean(), (t[:, 1] - t[:, 0]).mean(), (t[:, 1] - t[:, 0]).max(), t[-1, 0] - t[0, 0]))
+print("  mean step %.0f (" + str(NMFMA) + " MFMAs x 16 = " + str(NMFMA * 16) + "), barrier wait per step mean %.0f, max %.0f; s_memtime ticks are at 100 MHz x? check: total %.0f ticks" % (step.mean(), (t[:, 1] - t[:, 0]).mean(), (t[:, 1] - t[:, 0]).max(), t[-1, 0] - t[0, 0]))
 ph = stamps.view(torch.int64)[400:424].cpu().numpy().reshape(3, 8)[:, :4]
 for wgi, r in enumerate(ph):
     if r[0]:
