@@ -355,8 +355,11 @@ def make_workload(args, rank, world, device):
     from excel_amd.tools import synthetic
     from excel_amd.tools.infer_lam import shard_indices
     B, S, NC = args.batch, 448, 21
+    sd = synthetic.make_vit_state_dict(seed=0)
+    if getattr(args, "weights", "seeded") == "fp16":
+        sd = {k: np.asarray(v, np.float32).astype(np.float16).astype(np.float32) for k, v in sd.items()}
     model = ExCEL_model(clip_model="ExCEL_ViT-B/16", num_classes=NC, img_size=S, mode="train", device=device,
-                        state_dict=synthetic.make_vit_state_dict(seed=0), text_features=synthetic.make_text_features(45))
+                        state_dict=sd, text_features=synthetic.make_text_features(45))
     n_batches = 2
     ds = synthetic.SyntheticSegDataset(world * B * n_batches, (S, S), num_classes=NC, seed=1234)
     mine = shard_indices(len(ds), rank, world)
@@ -385,6 +388,10 @@ def main(argv=None, hooks=None):
     ap.add_argument("--power-seconds", type=float, default=3.0, help="untimed loop of the step with rocm-smi power sampling (0 = skip)")
     ap.add_argument("--fp16w-steps", type=int, default=10, help="steps of the checkpoint-like-weights side-line (weights rounded through fp16 like the "
                     "published CLIP archive; 0 = skip; skipped with --cpu-images 0, i.e. in profiling / A-B passes)")
+    ap.add_argument("--weights", choices=["seeded", "fp16"], default="seeded",
+                    help="seeded (default, the headline: full-mantissa fp32 weights as in rounds 1-5) | fp16: the SAME weights rounded through IEEE "
+                         "half like the published CLIP archive - the model then starts in f16x2; for profiling that path under rocprofv3 "
+                         "(the line says so in config.weights; it is not the headline)")
     ap.add_argument("--overlap", type=int, default=int(os.environ.get("EXCEL_BENCH_OVERLAP", "0")),
                     help="1: two-stream software pipeline (PAR of batch i overlaps the ViT of batch i+1)")
     ap.add_argument("--split", type=int, default=int(os.environ.get("EXCEL_BENCH_SPLIT", "1")),
@@ -541,11 +548,14 @@ def main(argv=None, hooks=None):
             "metric": "images/sec (CAM+PAR refine, 448x448)", "value": round(value, 3), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"f32": "f32", "f16x3": "f16x3 (fp32 as IEEE-half hi+lo, fp32 accumulate)"}.get(gmode, "bf16x3 (fp32 as bf16 hi+lo, fp32 accumulate)"),
+            "dtype": {"f32": "f32", "f16x3": "f16x3 (fp32 as IEEE-half hi+lo, fp32 accumulate)",
+                      "f16x2": "f16x2 (fp32 as IEEE-half hi+lo, fp16-valued weights: 2 MFMAs per product, fp32 accumulate)"}.get(gmode, "bf16x3 (fp32 as bf16 hi+lo, fp32 accumulate)"),
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: VOC-shaped 448x448, batch=32/GPU, ViT-B/16 surgery + patch-text CAM "
                                    "(T=45,F=20) + affinity random walk + PAR(20 it, 6 dilations) + argmax + confusion, "
-                                   "full HIP path; seeded random weights, shipped VOC attribute bank",
+                                   "full HIP path; seeded random weights, shipped VOC attribute bank"
+                                   + ("" if args.weights == "seeded" else " - SIDE-LINE RUN: weights rounded through fp16 (checkpoint-like), not the headline"),
+                       "weights": args.weights, "gemm_mode": gmode,
                        "batch_per_gpu": B, "image": "448x448", "parallelism": f"image-sharded x{world}, 1 RCCL all-gather of [21,21] int64",
                        "concurrent_sub_batches": 1 if args.overlap else max(args.split, 1),
                        "k_present_classes_mean": float(np.mean(np.concatenate(ks)))},
@@ -580,7 +590,7 @@ def main(argv=None, hooks=None):
             if os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath))
-                    traffic, par_traffic = tj.get(cat + "_bytes_per_launch"), tj.get("par_iterate_bytes_per_launch")
+                    traffic, par_traffic = tj.get(("gemm_f16x2" if mode == "f16x2" else cat) + "_bytes_per_launch"), tj.get("par_iterate_bytes_per_launch")
                     src = dict(tj.get("_source") or {})
                     src["file"] = "profiles/hbm_traffic.json"
                     src["measured_on_this_kernel_source"] = bool(src.get("csrc_sha16")) and src.get("csrc_sha16") == csrc_sha16()
@@ -592,7 +602,10 @@ def main(argv=None, hooks=None):
                 kname = ("gemm_w4_kernel + gemm_bf16x3_kernel (fp32 operands as bf16 hi+lo planes, 3 x v_mfma_f32_16x16x32_bf16 per product; all "
                          "nn.Linear / patch-embed / proj GEMMs: the 320x256-tile launches - 51 of 59 per step, 94 % of the time - run on the "
                          "four-wave hand-scheduled kernel gemm_w4.hip)") if mode == "bf16x3" else (
-                         "gemm_w4_kernel + gemm_bf16x3_kernel, IEEE-half instances (fp32 operands as f16 hi+lo planes, 3 x v_mfma_f32_16x16x32_f16 per product)")
+                         "gemm_w4_kernel + gemm_bf16x3_kernel, IEEE-half instances (fp32 operands as f16 hi+lo planes, 3 x v_mfma_f32_16x16x32_f16 per product)"
+                         if mode == "f16x3" else
+                         "gemm_w4x2_kernel (four-wave hand-scheduled tile; fp32 activations as f16 hi+lo planes x fp16-VALUED weights streamed as a plain half "
+                         "matrix: 2 x v_mfma_f32_16x16x32_f16 per product) + the 8-wave tiles for the batched A_sum.V products (3 per product)")
             else:
                 peak = F32_MATRIX_PEAK_TF
                 kname = "gemm_f32_kernel<NT> (fp32 MFMA 32x32x2; all nn.Linear / patch-embed / proj / sim GEMMs)"
@@ -606,16 +619,18 @@ def main(argv=None, hooks=None):
                 "algorithmic_bytes_per_launch": int(gemm_bytes_per_step(B)[0] / gemm_bytes_per_step(B)[1]) if mode != "f32" else None,
             }
             if mode != "f32":
-                # the kernel issues 3 bf16 MFMAs per algorithmic product: matrix-pipe utilisation is 3x the algorithmic fraction
-                out["roofline"]["mfma_issue_frac"] = round(3 * achieved / peak, 4)
-                out["roofline"]["fp32_equivalent_peak"] = round(peak / 3, 1)
+                # the kernel issues 3 (f16x2: 2) 16-bit MFMAs per algorithmic product: matrix-pipe utilisation is 3x (2x) the algorithmic fraction
+                nm = 2 if mode == "f16x2" else 3
+                out["roofline"]["mfma_per_product"] = nm
+                out["roofline"]["mfma_issue_frac"] = round(nm * achieved / peak, 4)
+                out["roofline"]["fp32_equivalent_peak"] = round(peak / nm, 1)
                 # what the whole chip sustains on THIS MFMA stream with random operand bits, operands in registers, no memory traffic
                 # (tools_dev/micro/mfma_power.hip, profiles/r04_micro_mfma_power.txt: 2 470 TFLOP/s with zero operands; with random mantissas
                 # 1 680-1 810 for the 32x32x16 form and 2 130 for the 16x16x32 form the kernel uses - the clock drops from 2.37 to 1.7 /
                 # 2.04 GHz between 128 and 256 busy CUs): the power-capped ceiling
                 sustained = MFMA_SUSTAINED_RANDOM_TF[mode]
                 out["roofline"]["sustained_peak_random_operands"] = sustained
-                out["roofline"]["mfma_frac_of_sustained"] = round(3 * achieved / sustained, 4)
+                out["roofline"]["mfma_frac_of_sustained"] = round(nm * achieved / sustained, 4)
                 out["roofline"]["sustained_source"] = "profiles/r04_micro_mfma_power.txt (measured constant, not re-measured by this run)"
                 # where the rest goes, from in-kernel s_memtime / s_memrealtime stamps of the four-wave kernel (profiles/r05_w4_cycle_stamps.txt,
                 # measured constants): a 32-k step of 240 MFMAs takes 4 300 shader cycles (3 840 of matrix-pipe time: 0.89 busy INSIDE the

@@ -50,7 +50,7 @@ def main(fetch_csv, write_csv, head=None):
                       bytes_per_launch=int((2 * f_kb + w_kb) * 1024))
     top = {}
     # (the bf16x3 GEMM category of bench.py = the four-wave kernel gemm_w4_kernel_* + the 8-wave gemm_bf16x3_kernel instances)
-    for cat, prefix in (("gemm_bf16x3", ("gemm_bf16x3_kernel", "gemm_w4_kernel")), ("par_iterate", ("par_iterate",)), ("attn_rowpass", ("attn_rowpass",)),
+    for cat, prefix in (("gemm_bf16x3", ("gemm_bf16x3_kernel", "gemm_w4_kernel", "gemm_w4x2_kernel")), ("par_iterate", ("par_iterate",)), ("attn_rowpass", ("attn_rowpass",)),
                         ("attn_accum", ("attn_accum",)), ("attn_strip", ("attn_strip",)), ("par_iterate_guide", ("par_iterate_guide",))):
         ks = [v for k, v in out.items() if any(px in k for px in prefix)]
         n = sum(v["launches"] for v in ks)

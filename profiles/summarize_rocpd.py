@@ -18,7 +18,7 @@ def main(path):
     # bench.py's profiling categories span several template instances: launch-weighted aggregates for direct comparison
     # with its roofline.avg_launch_ms / roofline_par_iterate.avg_launch_ms
     print()
-    for cat, key in (("gemm_bf16x3 (w4 + 8-wave tiles)", ("gemm_bf16x3_kernel", "gemm_w4_kernel")), ("par_iterate", ("par_iterate",)),
+    for cat, key in (("gemm_bf16x3 (w4 + 8-wave tiles)", ("gemm_bf16x3_kernel", "gemm_w4_kernel", "gemm_w4x2_kernel")), ("par_iterate", ("par_iterate",)),
                      ("attn_rowpass", ("attn_rowpass",)), ("attn_accum + attn_strip", ("attn_accum", "attn_strip"))):
         sel = [r for r in rows if any(k in r[0] for k in key)]
         n = sum(r[1] for r in sel)
