@@ -35,8 +35,9 @@ def make_text_tower(vocab, width=64, layers=2, embed=512, ctx=77, seed=5):
     return w
 
 
-def write_tiny_clip(tmp_dir, seed=11):
-    """-> (checkpoint path, merges path, full state_dict of numpy arrays)."""
+def write_tiny_clip(tmp_dir, seed=11, half=False):
+    """-> (checkpoint path, merges path, full state_dict of numpy arrays).  half: store the parameters as fp16 tensors, like the published
+    archives do (clip/clip.py:138-154 loads them, clip/build_model.py:72 keeps the model fp32: the weights are then fp16-VALUED)."""
     tmp_dir = str(tmp_dir)
     bpe_path = os.path.join(tmp_dir, "bpe_tiny_vocab.txt.gz")
     with gzip.open(bpe_path, "wb") as f:
@@ -46,7 +47,11 @@ def write_tiny_clip(tmp_dir, seed=11):
     full = {"visual." + k: v for k, v in vis.items()}
     full.update(make_text_tower(vocab))
     ckpt = os.path.join(tmp_dir, "ViT-B-16.pt")                  # the published archive's file name (state_dict form, clip/clip.py:147)
-    torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in full.items()}, ckpt)
+    if half:
+        full = {k: np.asarray(v, np.float32).astype(np.float16).astype(np.float32) if np.asarray(v).dtype == np.float32 else v for k, v in full.items()}
+        torch.save({k: (torch.from_numpy(np.asarray(v)).half() if np.asarray(v).dtype == np.float32 else torch.from_numpy(np.asarray(v))) for k, v in full.items()}, ckpt)
+    else:
+        torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in full.items()}, ckpt)
     return ckpt, bpe_path, full
 
 

@@ -11,7 +11,9 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
-def test_parity_script_on_tiny_checkpoint(tmp_path):
+@pytest.mark.parametrize("half", [False, True])
+def test_parity_script_on_tiny_checkpoint(tmp_path, half):
+    """half: the checkpoint stores fp16 parameters like the published CLIP archives - the model then starts in f16x2 by itself."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -20,7 +22,7 @@ def test_parity_script_on_tiny_checkpoint(tmp_path):
     from excel_amd.tools import synthetic
     root, lists = str(tmp_path / "VOC2012"), str(tmp_path / "lists")
     synthetic.write_voc_tree(root, lists, 5, seed=21)
-    ckpt, bpe_path, _ = write_tiny_clip(tmp_path)
+    ckpt, bpe_path, _ = write_tiny_clip(tmp_path, half=half)
     out = parity_real_weights.main(["--model", ckpt, "--bpe_path", bpe_path, "--data_folder", root, "--list_folder", lists,
                                     "--infer_set", "train", "--resize_size", "224", "--batch_size", "3", "--n_images", "5",
                                     "--label_gate", "0.995"])
@@ -28,5 +30,8 @@ def test_parity_script_on_tiny_checkpoint(tmp_path):
     assert out["images"] == 5 and out["scored_pixels"] > 0
     assert out["cam_max_abs"] < 1e-3                                   # the north-star gate, on this checkpoint
     assert out["label_agreement_mean"] >= 0.995 and out["ok"]
-    assert out["gemm_rung"]["started_in"] == "bf16x3" and out["gemm_rung"]["settled_on"] in ("bf16x3", "f16x3", "f32")
+    if half:
+        assert out["gemm_rung"]["started_in"] == "f16x2" and out["gemm_rung"]["settled_on"] in ("f16x2", "f32")
+    else:
+        assert out["gemm_rung"]["started_in"] == "bf16x3" and out["gemm_rung"]["settled_on"] in ("bf16x3", "f16x3", "f32")
     assert 0.0 <= out["miou_hip"] <= 1.0 and abs(out["miou_hip"] - out["miou_cpu"]) < 0.02
