@@ -701,7 +701,11 @@ def main(argv=None, hooks=None):
             out["kernel_ms_per_step"] = {k: round(v, 4) for k, v in sorted(ms.items(), key=lambda kv: -kv[1])}
         if on_gpu and world == 1 and args.cpu_images > 0:
             ncpu = min(args.cpu_images, n_batches * B)
-            out["cpu_baseline"], cpu_labels = cpu_baseline(ncpu, seed=1234)
+            sd_cpu = None
+            if args.weights == "fp16":           # the checker runs on the weights the GPU ran on
+                from excel_amd.tools import synthetic as _syn
+                sd_cpu = {k: np.asarray(v, np.float32).astype(np.float16).astype(np.float32) for k, v in _syn.make_vit_state_dict(seed=0).items()}
+            out["cpu_baseline"], cpu_labels = cpu_baseline(ncpu, seed=1234, state_dict=sd_cpu)
             # the labels of the timed kernels (same resident batches, one more untimed pass) against the CPU port's labels of the same
             # images: what was timed is what is checked
             agree, px = [], 0

@@ -327,8 +327,14 @@ static int vit_prepare_half_weights(excel_vit* h) {
         excel_set_error("excel_vit: packing half weights failed: %s", hipGetErrorString(hipGetLastError()));
         return EXCEL_ERR_LAUNCH;
     }
-    h->half_arena = arena;
     h->fp16_exact = n_bad == 0 ? 1 : 0;
+    if (h->fp16_exact) {
+        h->half_arena = arena;
+    } else {                           // full-mantissa weights: the packed matrices are of no use (the two-product mode is refused)
+        for (auto& sb : h->sblocks) sb.h_in_proj = sb.h_out_proj = sb.h_fc1 = sb.h_fc2 = nullptr;
+        h->h_conv1 = h->h_projT = nullptr;
+        hipFree(arena);
+    }
     return EXCEL_OK;
 }
 

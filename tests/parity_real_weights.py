@@ -11,7 +11,7 @@ runs the first N images of the list through
 both built from THE SAME checkpoint (visual + text tower, shipped attribute bank), and prints ONE JSON line:
   cam_max_abs            max over images of |attr_maps_raw(HIP) - attr_maps_raw(CPU)|           gate 1e-3
   label_agreement_mean / _min   fraction of identical label pixels per image                    expect >= 0.999
-  gemm_rung              the matrix-core mode ExCEL_model.check_numerics settles on for these weights (bf16x3 -> f16x3 -> f32) and the
+  gemm_rung              the matrix-core mode ExCEL_model.check_numerics settles on for these weights (a published fp16 archive starts in f16x2 -> f32; fp32 weights: bf16x3 -> f16x3 -> f32) and the
                          CAM difference of every rung against exact fp32
   miou_hip / miou_cpu    training-free mIoU of both paths over the sample (and the histograms' L1 distance)
 Exit status 0 when the CAM gate and the 99.9 % label gate hold, 3 otherwise.
