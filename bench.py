@@ -26,6 +26,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 F32_MATRIX_PEAK_TF = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 BF16_MFMA_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak
+PROF_EVERY = 8          # the two roofline kernels are bracketed with a HIP-event pair at every 8th launch of their category inside the timed region (59 GEMM
+                        # launches per step: 8 is coprime to it, every layer shape is sampled; an event pair costs ~10 us of GPU idle - every 4th launch,
+                        # rounds 1-5, took ~0.9 % off `value`)
 MFMA_SUSTAINED_RANDOM_TF = {"bf16x3": 2130.0, "f16x3": 2040.0, "f16x2": 2040.0}   # whole-chip MFMA-only stream (16x16x32 form) on random operand bits (see the roofline block)
 # SURVEY.md 8 flop table @448^2 (per image, GFLOP): rows that run on the gemm_f32 kernel
 GEMM_GFLOP_PER_IMG = 0.925 + 12 * (2.778 + 0.926 + 7.408) + 5 * (0.926 + 0.947) + 0.617 + 0.036
@@ -482,15 +485,15 @@ def main(argv=None, hooks=None):
     dom_cat = "gemm_bf16x3" if gmode in ("bf16x3", "f16x3", "f16x2") else "gemm_nt"
     if timing:
         # the warm-up runs with the same event bracketing as the timed region, so nothing is used for the first time inside it
-        ops.prof_enable(True, categories=[dom_cat, "par_iterate"], every=4)
+        ops.prof_enable(True, categories=[dom_cat, "par_iterate"], every=PROF_EVERY)
     for i in range(args.warmup):
         pipe.run_batch(*batches[i % n_batches])
     pipe.reset()
     if timing:
-        # inside the timed region the two roofline kernels are bracketed with HIP events on their launch stream, every 4th
-        # launch of each (an event pair costs ~10 us of GPU idle: all ~290 launches/step would take 5 % off `value`)
+        # inside the timed region the two roofline kernels are bracketed with HIP events on their launch stream, every 8th
+        # launch of each - PROF_EVERY - (an event pair costs ~10 us of GPU idle: all ~290 launches/step would take 5 % off `value`)
         ops.prof_collect()
-        ops.prof_enable(True, categories=[dom_cat, "par_iterate"], every=4)
+        ops.prof_enable(True, categories=[dom_cat, "par_iterate"], every=PROF_EVERY)
     # no cyclic-GC pass inside the timed loop (what `timeit` does too): a full collection over the interpreter's heap (torch, numpy, the
     # data set) takes 40-70 ms of host time, and the allocation count that triggers it landed in timed step 0 or 1 - on a fresh box, where
     # the GPU had no queued work to hide it behind, 1 080-1 230 instead of 1 370 img/s over 10 steps (found with host_enqueue_ms_steps)

@@ -96,6 +96,11 @@ def write(base, n, procs=16, seed=1234, coco=False):
     full = {"visual." + k: v for k, v in synthetic.make_vit_state_dict(seed=0).items()}
     full.update(text_tower(256 + 256 + len(MERGES) + 2))
     torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in full.items()}, os.path.join(base, "ViT-B-16.pt"))
+    # the same parameters stored as fp16 tensors, like the published archives (clip/clip.py:138-154 loads them, clip/build_model.py:72 keeps the
+    # model fp32: fp16-VALUED weights - the harness then starts in f16x2 by itself):  run ... --model <base>/ViT-B-16.fp16.pt
+    os.makedirs(os.path.join(base, "fp16"), exist_ok=True)
+    torch.save({k: (torch.from_numpy(np.asarray(v)).half() if np.asarray(v).dtype == np.float32 else torch.from_numpy(np.asarray(v))) for k, v in full.items()},
+               os.path.join(base, "fp16", "ViT-B-16.pt"))
     nbytes = sum(os.path.getsize(os.path.join(dirs[0], i + ".jpg")) for i in ids)
     meta = {"dataset": "coco" if coco else "voc", "images": n, "scored_pixels": int(npix), "jpeg_bytes": int(nbytes), "write_seconds": round(time.time() - t0, 1)}
     json.dump(meta, open(os.path.join(base, "meta.json"), "w"))
