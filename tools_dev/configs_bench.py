@@ -2,7 +2,8 @@
     configs[1]  VOC 448x448 batch=16: ViT attention + patch-text CAM only (no affinity / PAR)
     configs[4]  COCO-shaped 512x512 batch=16 per GPU: 80-class path (T=103 text rows, 224-cluster bank) incl. PAR, and the
                 flip + multi-scale LAM fuse on its own
-Usage: python tools_dev/configs_bench.py [steps]"""
+Usage: python tools_dev/configs_bench.py [steps] [fp16]        (fp16: checkpoint-like weights - rounded through IEEE half like the published CLIP
+archive; the model then starts in f16x2)"""
 import os
 import sys
 import time
@@ -18,6 +19,9 @@ from excel_amd.utils.camutils import multi_scale_lam
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 dev = torch.device("cuda", 0)
 sd = synthetic.make_vit_state_dict(seed=0)
+if len(sys.argv) > 2 and sys.argv[2] == "fp16":
+    import numpy as np
+    sd = {k: np.asarray(v, np.float32).astype(np.float16).astype(np.float32) for k, v in sd.items()}
 
 
 def timed(fn, n):
@@ -39,6 +43,7 @@ ds = synthetic.SyntheticSegDataset(B, (S, S), num_classes=21, seed=7)
 _, imgs, gts, cls = ds.batch(range(B))
 x = torch.from_numpy(imgs).to(dev)
 dt = timed(lambda: model(x), steps)
+print("gemm mode:", model.encoder.visual.handle().gemm_mode())
 print(f"configs[1] VOC 448^2 batch=16, ViT + patch-text CAM only: {dt * 1e3:.2f} ms/step  {B / dt:.1f} images/s")
 del model
 
