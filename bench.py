@@ -133,7 +133,12 @@ def cpu_baseline(max_images, seed, budget_s=60.0, state_dict=None, threads=None)
         phys = len(pairs) or ncpu
     except OSError:
         pass
+    per = sorted(getattr(torch_cpu.build_validation, "last_per_image_seconds", []) or [dt / max(n, 1)])
+    q = lambda f: per[min(len(per) - 1, int(f * len(per)))]
     return {"value": n / dt, "unit": "images/s", "cores": int(threads), "threads_used": int(threads), "host_physical_cores": phys,
+            # the same sample by its MEDIAN image (the GPU boxes are shared hosts: `value` - images over wall time - moved 4-11 % between
+            # consecutive runs on one box while the median image did not; both are printed, `value` keeps its definition)
+            "value_at_median_image": round(1.0 / q(0.5), 4), "seconds_per_image_quartiles": [round(q(0.25), 4), round(q(0.5), 4), round(q(0.75), 4)],
             "host_cpu_quota": quota,
             "host_logical_cpus": ncpu, "kind": "port", "cpu": model_name, "images_done": n, "images_requested": max_images,
             "vit_seconds_by_thread_count": tried, "vit_probe_seconds": probes, "thread_candidates_capped_at": cap,

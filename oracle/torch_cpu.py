@@ -143,7 +143,7 @@ def build_validation(samples, w, cfg, text_attr, num_classes=21, resize_size=448
     vit = TorchVit(w, cfg, resize_size // cfg.patch)
     par = TorchPAR(dilations, num_iter)
     stage = dict(vit=0.0, cam=0.0, aff_random_walk=0.0, upsample_par_argmax=0.0, score=0.0)
-    gts, preds = [], []
+    gts, preds, per_image = [], [], []
     t_start = time.perf_counter()
     for img, gt, cls_label in samples:
         t0 = time.perf_counter()
@@ -161,9 +161,11 @@ def build_validation(samples, w, cfg, text_attr, num_classes=21, resize_size=448
         gts.append(np.asarray(gt).astype(np.int16))
         for k, d in zip(("vit", "cam", "aff_random_walk", "upsample_par_argmax"), (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
             stage[k] += d
+        per_image.append(t4 - t0)
         if time_budget_s is not None and len(preds) >= min_images and time.perf_counter() - t_start > time_budget_s:
             break
     t0 = time.perf_counter()
     hist = _ev.hist_of(gts, preds, num_classes)                                                                     # :121
     stage["score"] = time.perf_counter() - t0
+    build_validation.last_per_image_seconds = per_image        # (per-image wall times of the last call: bench.py reports their quartiles)
     return hist, preds, stage
