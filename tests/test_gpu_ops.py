@@ -961,6 +961,39 @@ def test_par_uniform_narrow_images(ops):
         assert torch.equal(out, streamed), (H, W)
 
 
+def test_vit_b16_448_outlier_net_checkpoint_like_weights_start_in_f16x2(ops):
+    """The extreme stress net of the test above (sharp 2.0: every head near one-hot, where bf16x3 exceeds the 1e-3 gate) with its weights
+    rounded through IEEE half - the form every published CLIP archive has (clip/build_model.py:72).  A model built on such weights starts
+    in f16x2 BY ITSELF and that mode holds the gate against a float64 run of the oracle on the same weights, within 3x the fp32 oracle's own
+    deviation; the start-up check keeps it (no fall-back needed): on real checkpoints the fast default is the accurate mode."""
+    cfg = VitConfig(width=768, layers=12, heads=12, patch=16, out_dim=512, input_resolution=224, n_surgery=5)
+    w = {k: np.asarray(v, np.float32).astype(np.float16).astype(np.float32) for k, v in make_vit_weights(cfg, seed=1, attn_gain=2.0, outliers=True, sharp=2.0).items()}
+    imgs = np.random.RandomState(4).standard_normal((1, 3, 448, 448)).astype(np.float32)
+    text = np.random.RandomState(8).standard_normal((45, 512)).astype(np.float32)
+    text /= np.linalg.norm(text, axis=1, keepdims=True)
+
+    def cam_of(x, dt):
+        f = x / np.sqrt((x * x).sum(axis=1, keepdims=True))
+        return oracle.cam.clip_feature_surgery(f.astype(dt), text.astype(dt))
+
+    with oracle.vit.precision(np.float64):
+        x64, _, _ = oracle.vit.vit_forward(imgs.astype(np.float64), {k: np.asarray(v, np.float64) for k, v in w.items()}, cfg)
+    cam64 = cam_of(x64, np.float64)
+    x32, _, _ = oracle.vit.vit_forward(imgs, w, cfg)
+    o_cam = maxabs(cam_of(x32, np.float32), cam64)
+    from excel_amd.model import ExCEL_model
+    model = ExCEL_model(clip_model="ExCEL_ViT-B/16", num_classes=21, img_size=448, mode="train", state_dict=w, text_attr=np.ascontiguousarray(text.T))
+    h = model.encoder.visual.handle()
+    assert h.weights_fp16_exact() and h.gemm_mode() == "f16x2"
+    r = h.forward(dev(imgs), want_raw=True)
+    full, _ = ops.clip_feature_surgery(r["image_features"], dev(text), num_fg=20)
+    e_cam = maxabs(host(full), cam64)
+    print(f"checkpoint-like outlier net (sharp 2.0): fp32 oracle vs float64 CAM {o_cam:.2e}, GPU f16x2 vs float64 CAM {e_cam:.2e}")
+    assert e_cam < 1e-3 and e_cam < max(5e-4, 3 * o_cam)
+    res = model.check_numerics(dev(imgs), tol=5e-4)
+    assert res["mode_before"] == res["mode_after"] == "f16x2" and res["max_abs_diff"] < 5e-4
+
+
 def _unsplit_f16(t):
     """split tensor [R,2,K] (int16 view) with IEEE-half planes -> (hi, lo) fp32 [R,K]."""
     R, K = t.shape[0], t.shape[2]
