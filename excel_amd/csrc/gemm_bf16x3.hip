@@ -199,8 +199,9 @@ __device__ __forceinline__ void bf_epilogue_lds(const GemmBfArgs& p, const f32x4
 }
 
 // WM x WN waves, each owning TI x 2 MFMA tiles (TI*32 rows x 64 columns): block tile = (WM*TI*32) x (WN*64);
-// NSTAGE-deep LDS ring filled by global_load_lds.  The staging path (L2 -> LDS) saturates near 27 GB/s per CU whatever
-// the tile, so the lever is bytes per flop:
+// NSTAGE-deep LDS ring filled by global_load_lds.  Inside this kernel the staging path (L2 -> LDS) delivered ~27 B/clk per CU whatever
+// the tile (round 1; the port itself sustains 65 B/clk per CU with nothing else running, tools_dev/micro/ldsdma_rate.hip), so the lever is
+// bytes per flop:
 //   <2,2,2,2>: 128x128, 64 KB LDS, 2 workgroups/CU                      (small / batched problems)
 //   <4,2,2,3>: 256x128, 144 KB, 8 waves, counted vmcnt ring             (N = 768 GEMMs: keeps 594 tiles for 256 CUs)
 //   <2,4,4,2>: 256x256, 128 KB, 8 waves x (128x64), half the bytes/flop of 128x128   (QKV, fc1)
