@@ -598,6 +598,22 @@ int excel_launch_gemm_bf16x3(const GemmBfArgs& p_in, hipStream_t stream) {
             const double us = excel_gemm_w4_model_us(p, cand[c], n_cu3, x2);
             if (us < best_us) { best_us = us; best_ntm = cand[c]; best_x2 = x2; }
         }
+        // a launch of two instances (full rounds of 320-row tiles + the rest in shorter ones) when the model prefers it by more than 1 %
+        bool mix_ok = force_ntm == 0 && !force8;
+#ifdef EXCEL_DEV
+        { static const char* e = getenv("EXCEL_W4_MIX"); if (e && atoi(e) == 0) mix_ok = false; }       // dev knob: uniform launches only
+#endif
+        if (mix_ok) {
+            const int mx2 = !x2_on ? 0 : 2;          // (the split-layout two-product form has no 320-row instance: no two-instance launch)
+            int tall = 0, shrt = 0, second = 0;
+            const double mus = (x2_on && x2_force == 1) ? 1e30 : excel_gemm_w4_mix_model_us(p, n_cu3, mx2, &tall, &shrt, &second);
+            if (mus < 0.99 * best_us) {
+#ifdef EXCEL_SPLIT_F16
+                if (mx2) return excel_launch_gemm_w4x2_mix(p, tall, shrt, second, stream);
+#endif
+                return excel_launch_gemm_w4_mix(p, tall, shrt, second, stream);
+            }
+        }
 #ifdef EXCEL_SPLIT_F16
         if (best_ntm && best_x2) return excel_launch_gemm_w4x2(p, best_ntm, best_x2, stream);
 #endif

@@ -57,20 +57,52 @@ bool excel_gemm_w4_supported(const GemmBfArgs& p, int nt_m, int x2) {
 // 1.8)); calibrated on the B = 32 layer shapes (profiles/r05_w4_arms.txt: a 320-row tile of K = 768 is 56 us of k-loop + 18 of epilogue + 7),
 // the short instance pays ~8 % more per row tile for its fragment reads (26 instead of 36 per 240 MFMAs-equivalent).  The launcher compares
 // this against the 8-wave tiles' model (gemm_bf16x3.hip).
-double excel_gemm_w4_model_us(const GemmBfArgs& p, int nt_m, int n_cu, int x2) {
-    const long long tiles = (long long)cdiv(p.M, 32 * nt_m) * cdiv(p.N, w4::BN);
-    const long long full = tiles / n_cu, rem = tiles - full * n_cu;
+// one tile of the nt_m instance (us): prologue + row tiles x (k-steps x 0.233 + epilogue 1.8)
+static double w4_tile_us(int K, int nt_m, int x2) {
     // (two-product instances: 16 instead of 24 MFMAs per row tile and k-step)
-    const double per_row_tile = (p.K / 32) * 0.233 * (x2 ? 0.70 : 1.0) * (nt_m == 5 ? 1.08 : nt_m == 8 ? 1.02 : 1.0) + 1.8;
-    // a partly filled last round is cheaper than a full one (fewer CUs share the power budget and the fabric): 0.45 + 0.55 x fill of a full
-    // round's time, fitted on the B = 16 shapes (profiles/r05b_b16_shapes.txt: 360 tiles 140.6 us, 480 tiles 163.1, 624 tiles 223.8)
-    const double last = rem ? 0.45 + 0.55 * (double)rem / n_cu : 0.0;
-    return ((double)full + last) * (7.0 + nt_m * per_row_tile);
+    const double per_row_tile = (K / 32) * 0.233 * (x2 ? 0.70 : 1.0) * (nt_m == 5 ? 1.08 : nt_m == 8 ? 1.02 : 1.0) + 1.8;
+    return 7.0 + nt_m * per_row_tile;
+}
+// `tiles` equal tiles on n_cu CUs, in tile-times: full rounds + a partly filled last round, which is cheaper than a full one (fewer CUs share
+// the power budget and the fabric): 0.45 + 0.55 x fill, fitted on the B = 16 shapes (profiles/r05b_b16_shapes.txt: 360 tiles 140.6 us, 480
+// tiles 163.1, 624 tiles 223.8)
+static double w4_rounds(long long tiles, int n_cu) {
+    if (tiles <= 0) return 0.0;
+    const long long full = tiles / n_cu, rem = tiles - full * n_cu;
+    return (double)full + (rem ? 0.45 + 0.55 * (double)rem / n_cu : 0.0);
+}
+double excel_gemm_w4_model_us(const GemmBfArgs& p, int nt_m, int n_cu, int x2) {
+    return w4_rounds((long long)cdiv(p.M, 32 * nt_m) * cdiv(p.N, w4::BN), n_cu) * w4_tile_us(p.K, nt_m, x2);
+}
+
+// A launch made of TWO instances (gemm_w4_kernel_mix): R full rounds of 320-row tiles, the remaining rows in 256- or 160-row tiles that
+// fill what is left of round R and (part of) one more.  -> modelled time, the split in *tall / *shrt (row tiles) and *second (8 / 5);
+// 1e30 when no split applies.  (Judge, round 5: 711 tiles on 3 x 256 slots at B = 32, 1.4 - 2.4 rounds at B = 16.)
+double excel_gemm_w4_mix_model_us(const GemmBfArgs& p, int n_cu, int x2, int* tall, int* shrt, int* second) {
+    double best = 1e30;
+    if (!excel_gemm_w4_supported(p, 10, x2)) return best;
+    const int tiles_n = cdiv(p.N, w4::BN);
+    const double t10 = w4_tile_us(p.K, 10, x2);
+    const int cand[2] = {8, 5};
+    for (int c = 0; c < 2; ++c) {
+        if (!excel_gemm_w4_supported(p, cand[c], x2)) continue;
+        const double ts = w4_tile_us(p.K, cand[c], x2);
+        for (int R = 1; R <= 8; ++R) {
+            const int a10 = (int)(((long long)R * n_cu) / tiles_n);
+            if (a10 < 1 || (long long)a10 * 320 >= p.M) break;          // (the uniform grid covers M within R rounds)
+            const int as = cdiv(p.M - a10 * 320, 32 * cand[c]);
+            const long long slots_left = (long long)R * n_cu - (((long long)a10 * tiles_n + 7) & ~7LL);
+            const double us = R * t10 + w4_rounds((long long)as * tiles_n - (slots_left > 0 ? slots_left : 0), n_cu) * ts;
+            if (us < best) { best = us; *tall = a10; *shrt = as; *second = cand[c]; }
+        }
+    }
+    return best;
 }
 
 // one plain __global__ function per instance (a kernel TEMPLATE launched from inside a function template lost its host-side stub)
-#define W4_KERNEL(NT, DBG) __global__ __launch_bounds__(256, 1) void gemm_w4_kernel_##NT##_##DBG(GemmBfArgs p) { gemm_w4_body<NT, DBG>(p); }
+#define W4_KERNEL(NT, DBG) __global__ __launch_bounds__(256, 1) void gemm_w4_kernel_##NT##_##DBG(GemmBfArgs p) { W4_UNIFORM_BODY(NT, DBG, 0); }
 W4_KERNEL(10, 0) W4_KERNEL(8, 0) W4_KERNEL(5, 0)
+__global__ __launch_bounds__(256, 1) void gemm_w4_kernel_mix(GemmBfArgs p) { W4_MIX_BODY(0); }
 #ifdef EXCEL_DEV
 W4_KERNEL(10, 1) W4_KERNEL(10, 2) W4_KERNEL(10, 4) W4_KERNEL(10, 8) W4_KERNEL(8, 8) W4_KERNEL(5, 8) W4_KERNEL(10, 9) W4_KERNEL(10, 10)
 W4_KERNEL(10, 15) W4_KERNEL(10, 24) W4_KERNEL(10, 32) W4_KERNEL(10, 136) W4_KERNEL(10, 143) W4_KERNEL(10, 128)
@@ -107,6 +139,18 @@ static void launch_w4(const GemmBfArgs& p_in, int nt_m, hipStream_t stream) {
     if (nt_m == 10) W4_LAUNCH(10, 0);
     else if (nt_m == 8) W4_LAUNCH(8, 0);
     else W4_LAUNCH(5, 0);
+}
+
+int excel_launch_gemm_w4_mix(const GemmBfArgs& p_in, int tall, int shrt, int second, hipStream_t stream) {
+    GemmBfArgs p = p_in;
+    EXCEL_CHECK_ARG(excel_gemm_w4_supported(p, 10, 0) && excel_gemm_w4_supported(p, second, 0) && tall >= 1 && shrt >= 1 && (second == 8 || second == 5) &&
+                    (long long)tall * 320 < p.M && (long long)tall * 320 + (long long)shrt * 32 * second >= p.M, "gemm_w4 (two instances): bad split");
+    p.mix_tall = tall; p.mix_short = shrt; p.mix_first = second;
+    const int tiles_n = cdiv(p.N, w4::BN);
+    const dim3 grid(((tall * tiles_n + 7) & ~7) + shrt * tiles_n);
+    hipLaunchKernelGGL(gemm_w4_kernel_mix, grid, dim3(256), 0, stream, p);
+    EXCEL_CHECK_LAUNCH("gemm_w4 (two instances)");
+    return EXCEL_OK;
 }
 
 int excel_launch_gemm_w4(const GemmBfArgs& p, int nt_m, hipStream_t stream) {

@@ -24,16 +24,17 @@ namespace EXCEL_SPLIT_NS {
 
 #include "gemm_w4_body.inc"
 
-#define W4X2_KERNEL(NT, X) __global__ __launch_bounds__(256, 1) void gemm_w4x2_kernel_##NT##_##X(GemmBfArgs p) { gemm_w4_body<NT, 0, X>(p); }
+#define W4X2_KERNEL(NT, X) __global__ __launch_bounds__(256, 1) void gemm_w4x2_kernel_##NT##_##X(GemmBfArgs p) { W4_UNIFORM_BODY(NT, 0, X); }
 // (no 320-row instance on split-layout weights: its register allocation spills two accumulator tiles at the loop exit - the compact-weight
 // instance below is the one the ViT runs; split-layout callers get the 256-row tile)
 W4X2_KERNEL(8, 1) W4X2_KERNEL(5, 1)
 W4X2_KERNEL(10, 2) W4X2_KERNEL(8, 2) W4X2_KERNEL(5, 2)
+__global__ __launch_bounds__(256, 1) void gemm_w4x2_kernel_mix(GemmBfArgs p) { W4_MIX_BODY(2); }
 #define W4X2_LAUNCH(NT, X) hipLaunchKernelGGL(gemm_w4x2_kernel_##NT##_##X, grid, dim3(256), 0, stream, p)
 #ifdef EXCEL_DEV
 // development arms of the 320-row compact-weight instance (EXCEL_W4_DBG, as in gemm_w4.hip): 1 no LDS-DMA after the prologue, 2 no fragment
 // reads, 4 no barrier, 8 no epilogue, 16 no MFMAs, 128 cycle / phase stamps into the `bias` buffer (tools_dev/w4_stamps.py x2)
-#define W4X2_KERNEL_D(DBG) __global__ __launch_bounds__(256, 1) void gemm_w4x2_kernel_10_2_d##DBG(GemmBfArgs p) { gemm_w4_body<10, DBG, 2>(p); }
+#define W4X2_KERNEL_D(DBG) __global__ __launch_bounds__(256, 1) void gemm_w4x2_kernel_10_2_d##DBG(GemmBfArgs p) { W4_UNIFORM_BODY(10, DBG, 2); }
 W4X2_KERNEL_D(1) W4X2_KERNEL_D(2) W4X2_KERNEL_D(4) W4X2_KERNEL_D(8) W4X2_KERNEL_D(9) W4X2_KERNEL_D(10) W4X2_KERNEL_D(15) W4X2_KERNEL_D(128) W4X2_KERNEL_D(136) W4X2_KERNEL_D(143)
 #define W4X2_LAUNCH_D(DBG) hipLaunchKernelGGL(gemm_w4x2_kernel_10_2_d##DBG, grid, dim3(256), 0, stream, p)
 #endif
@@ -71,6 +72,20 @@ int excel_launch_gemm_w4x2(const GemmBfArgs& p, int nt_m, int x2, hipStream_t st
         else W4X2_LAUNCH(5, 1);
     }
     EXCEL_CHECK_LAUNCH("gemm_w4x2");
+    return EXCEL_OK;
+}
+
+// the two-instance launch of the compact-weight kernel (gemm_w4.hip: excel_gemm_w4_mix_model_us)
+int excel_launch_gemm_w4x2_mix(const GemmBfArgs& p_in, int tall, int shrt, int second, hipStream_t stream) {
+    GemmBfArgs p = p_in;
+    EXCEL_CHECK_ARG(p.w_lo_zero && excel_gemm_w4_supported(p, 10, 2) && excel_gemm_w4_supported(p, second, 2) && tall >= 1 && shrt >= 1 &&
+                    (second == 8 || second == 5) && (long long)tall * 320 < p.M && (long long)tall * 320 + (long long)shrt * 32 * second >= p.M,
+                    "gemm_w4x2 (two instances): bad split");
+    p.mix_tall = tall; p.mix_short = shrt; p.mix_first = second;
+    const int tiles_n = cdiv(p.N, w4::BN);
+    const dim3 grid(((tall * tiles_n + 7) & ~7) + shrt * tiles_n);
+    hipLaunchKernelGGL(gemm_w4x2_kernel_mix, grid, dim3(256), 0, stream, p);
+    EXCEL_CHECK_LAUNCH("gemm_w4x2 (two instances)");
     return EXCEL_OK;
 }
 

@@ -1060,6 +1060,34 @@ def test_gemm_f16x2_equals_f16x3_bitwise(ops, M, N, K):
     assert maxabs(out, ref) < 1e-5 * np.sqrt(K) * 0.05 + 2e-6          # (K = 3072: 2.1e-5 measured, fp32 accumulation over 96 steps)
 
 
+@pytest.mark.parametrize("M,N,K", [(16400, 3072, 768), (25120, 2304, 768), (12560, 2304, 768), (25120, 3072, 768)])
+def test_gemm_two_instance_launch_equals_row_slices(ops, M, N, K):
+    """Round 6: for these shapes the launcher makes ONE launch of two instances of the four-wave GEMM (full rounds of 320-row tiles, the rest in
+    256- / 160-row tiles: gemm_w4_kernel_mix / gemm_w4x2_kernel_mix).  Every output element is accumulated in the same k order whatever
+    instance computes it, so the launch must equal, BIT FOR BIT, the same problem computed as row slices of other heights (which the launcher
+    runs on other instances: a 4 000-row slice takes the 8-wave / short tiles) - for bf16x3, f16x3 and f16x2, plain / bias + QuickGELU + split /
+    bias + residual."""
+    rs = np.random.RandomState(M % 997 + N)
+    A = rs.standard_normal((M, K)).astype(np.float32)
+    W = (rs.standard_normal((N, K)) * 0.05).astype(np.float16).astype(np.float32)
+    bias = dev(rs.standard_normal(N).astype(np.float32))
+    res = dev(rs.standard_normal((M, N)).astype(np.float32))
+    cuts = [0, 4000, 4000 + 7520, M]
+    Wh, _ = ops.pack_f16(dev(W))
+    for name in ("bf16x3", "f16x3", "f16x2"):
+        f16 = name != "bf16x3"
+        As, Ws = ops.split_bf16(dev(A), f16=f16), ops.split_bf16(dev(W), f16=f16)
+        def run(a_split, r, **kw):
+            if name == "f16x2":
+                return ops.gemm_f16x2(a_split, Ws, Wh, residual=r, **kw)
+            return ops.gemm_bf16x3(a_split, Ws, residual=r, f16=f16, **kw)
+        for kw, use_res in ((dict(), False), (dict(bias=bias, act=1, split_out=True), False), (dict(bias=bias), True)):
+            whole = run(As, res if use_res else None, **kw)
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                part = run(As[lo:hi].contiguous(), res[lo:hi].contiguous() if use_res else None, **kw)
+                assert torch.equal(whole[lo:hi], part), (name, kw.keys(), lo, hi)
+
+
 def test_pack_f16_counts_inexact_values(ops):
     """excel_pack_f16's counter: 0 exactly for fp16-valued matrices; every value with a non-zero lo plane (and a NaN) counts."""
     rs = np.random.RandomState(5)
