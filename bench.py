@@ -608,8 +608,9 @@ def main(argv=None, hooks=None):
             if mode in ("bf16x3", "f16x3", "f16x2"):
                 peak = BF16_MFMA_PEAK_TF
                 kname = ("gemm_w4_kernel + gemm_bf16x3_kernel (fp32 operands as bf16 hi+lo planes, 3 x v_mfma_f32_16x16x32_bf16 per product; all "
-                         "nn.Linear / patch-embed / proj GEMMs: the 320x256-tile launches - 51 of 59 per step, 94 % of the time - run on the "
-                         "four-wave hand-scheduled kernel gemm_w4.hip)") if mode == "bf16x3" else (
+                         "nn.Linear / patch-embed / proj GEMMs: 51 of 59 launches per step, 94 % of the time, run on the four-wave hand-scheduled "
+                         "kernel gemm_w4.hip - the QKV / fc1 launches as gemm_w4_kernel_mix, two instances in one launch: full rounds of 320-row "
+                         "tiles + the rest in 256-row tiles)") if mode == "bf16x3" else (
                          "gemm_w4_kernel + gemm_bf16x3_kernel, IEEE-half instances (fp32 operands as f16 hi+lo planes, 3 x v_mfma_f32_16x16x32_f16 per product)"
                          if mode == "f16x3" else
                          "gemm_w4x2_kernel (four-wave hand-scheduled tile; fp32 activations as f16 hi+lo planes x fp16-VALUED weights streamed as a plain half "
