@@ -606,17 +606,7 @@ int excel_launch_gemm_bf16x3(const GemmBfArgs& p_in, hipStream_t stream) {
         if (mix_ok) {
             const int mx2 = !x2_on ? 0 : 2;          // (the split-layout two-product form has no 320-row instance: no two-instance launch)
             int tall = 0, shrt = 0, second = 0;
-            double mus = (x2_on && x2_force == 1) ? 1e30 : excel_gemm_w4_mix_model_us(p, n_cu3, mx2, &tall, &shrt, &second);
-#ifdef EXCEL_DEV
-            {   // dev knob EXCEL_W4_MIXSPEC="tall:second": force this split wherever it is valid (tools_dev/r06_mix_scan.py)
-                static const char* e = getenv("EXCEL_W4_MIXSPEC");
-                int ft = 0, fs = 0;
-                if (e && sscanf(e, "%d:%d", &ft, &fs) == 2 && ft >= 1 && (fs == 8 || fs == 5) && (long long)ft * 320 < p.M &&
-                    excel_gemm_w4_supported(p, 10, mx2) && excel_gemm_w4_supported(p, fs, mx2)) {
-                    tall = ft; second = fs; shrt = cdiv(p.M - ft * 320, 32 * fs); mus = 0.0;
-                }
-            }
-#endif
+            const double mus = (x2_on && x2_force == 1) ? 1e30 : excel_gemm_w4_mix_model_us(p, n_cu3, mx2, &tall, &shrt, &second);
             if (mus < 0.99 * best_us) {
 #ifdef EXCEL_SPLIT_F16
                 if (mx2) return excel_launch_gemm_w4x2_mix(p, tall, shrt, second, stream);

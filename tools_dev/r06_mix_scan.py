@@ -1,4 +1,4 @@
-"""dev (EXCEL_DEV library as tools_dev/ab/dev.so): scan the split of a two-instance GEMM launch - `tall` row tiles of 320 rows + the rest in
+"""dev (EXCEL_DEV library built with tools_dev/w4_mixspec.patch applied - the EXCEL_W4_MIXSPEC knob lives in that patch, not in the tree -, saved as tools_dev/ab/dev.so): scan the split of a two-instance GEMM launch - `tall` row tiles of 320 rows + the rest in
 256- / 160-row tiles - per layer shape, against the uniform launch (EXCEL_W4_MIX=0) and the launcher's own pick.  One process per point
 (the knob is read once).   python tools_dev/r06_mix_scan.py"""
 import os, subprocess, sys
