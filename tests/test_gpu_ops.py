@@ -821,18 +821,31 @@ def test_gemm_bf16x3_scalar_epilogue_big_tiles(ops, M, N, K):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("M,N,K", [(12560, 768, 768), (16400, 768, 768), (25120, 768, 768)])
-def test_gemm_bf16x3_with_neighbours_on_other_streams(ops, M, N, K):
+@pytest.mark.parametrize("M,N,K,mode", [(12560, 768, 768, "bf16x3"), (16400, 768, 768, "bf16x3"), (25120, 768, 768, "bf16x3"),
+                                        (12560, 768, 768, "f16x2"), (12560, 2304, 768, "f16x2"), (16400, 3072, 768, "bf16x3")])
+def test_gemm_bf16x3_with_neighbours_on_other_streams(ops, M, N, K, mode):
     """The four-wave GEMM instances (160- / 256- / 320-row tiles for these shapes) while ANOTHER kernel's waves share their CUs: the 160- and
     256-row instances leave registers and LDS for a neighbour, and with one the timing of their LDS reads changes.  Round 5 found the
     kernel's post-loop wait scheduled BEHIND the epilogue's lane-id computation - whose register was still the destination of an in-flight
     ds_read: a garbage lane id and wild addresses, only under such a neighbour (memory fault in `bench.py --split 2`).  Two GEMM streams + a
     LayerNorm stream, every result bit-identical to the serial launch."""
+    # (round 6: the same with the two-product kernels - "f16x2" - and with launches made of two instances: N = 2304 / 3072)
     g = torch.Generator(device="cuda").manual_seed(M)
-    As = [ops.split_bf16(torch.randn(M, K, device="cuda", generator=g)) for _ in range(2)]
-    W = ops.split_bf16(torch.randn(N, K, device="cuda", generator=g) * 0.05)
+    f16 = mode == "f16x2"
+    As = [ops.split_bf16(torch.randn(M, K, device="cuda", generator=g), f16=f16) for _ in range(2)]
+    Wf = (torch.randn(N, K, device="cuda", generator=g) * 0.05).half().float()
+    W = ops.split_bf16(Wf, f16=f16)
+    Wh = ops.pack_f16(Wf)[0] if f16 else None
     bias = torch.randn(N, device="cuda", generator=g)
     res = torch.randn(M, N, device="cuda", generator=g)
+    _ops = ops
+
+    class _G:                                   # the mode's GEMM behind the name the body below uses
+        @staticmethod
+        def gemm_bf16x3(a, w, **kw):
+            return _ops.gemm_f16x2(a, w, Wh, **kw) if f16 else _ops.gemm_bf16x3(a, w, **kw)
+        layernorm = staticmethod(_ops.layernorm)
+    ops = _G
     ref = [ops.gemm_bf16x3(a, W, bias=bias, residual=res, act=1) for a in As]
     refs = [ops.gemm_bf16x3(a, W, bias=bias, split_out=True).clone() for a in As]
     x = torch.randn(25120, 768, device="cuda", generator=g)
